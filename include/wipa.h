@@ -1,0 +1,239 @@
+/* wipa.h -- C ABI of libwipa.so: the MI355X (gfx950) Whisper -> IPA hot path.
+ *
+ * The reference (barathanaslan/whisper-ipa) has no FFI of its own: its hot path
+ * sits behind Python calls into mlx_whisper / mlx.  Each entry
+ * point below names the reference call site it replaces.  Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller unless it says "host";
+ *     the library never allocates or frees caller-visible memory -- scratch comes in
+ *     as (workspace, bytes) with a *_bytes() query;
+ *   - row-major, contiguous unless a leading dimension is given (in ELEMENTS);
+ *   - asynchronous on the given hipStream_t, no hidden synchronisation;
+ *   - returns 0 or a negative error code; wipa_last_error() has the text;
+ *   - no torch / C++ types cross this boundary.
+ * dtype: "T" below is the matrix/activation type of the call (f32 or bf16);
+ * biases, LayerNorm parameters, positional tables, the residual stream and the
+ * logits are always f32; all accumulation is f32.
+ */
+#ifndef WIPA_H
+#define WIPA_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* wipa_stream_t; /* hipStream_t */
+
+enum { WIPA_F32 = 0, WIPA_BF16 = 1 };
+enum { WIPA_OK = 0, WIPA_ERR_ARG = -1, WIPA_ERR_HIP = -2, WIPA_ERR_STATE = -3 };
+
+#define WIPA_N_SAMPLES 480000 /* 30 s at 16 kHz (mlx_whisper.audio.N_SAMPLES) */
+#define WIPA_N_FRAMES 3000
+#define WIPA_N_FFT 400
+#define WIPA_HOP 160
+#define WIPA_HEAD_DIM 64
+
+int wipa_version(void);
+const char* wipa_last_error(void);
+
+/* ------------------------------------------------------------------ K1 log-mel
+ * replaces mlx_whisper.audio.log_mel_spectrogram (+ pad_or_trim) at
+ * scripts/ipa_data_loader.py:80-82, scripts/transcribe_single.py:44-45,
+ * scripts/evaluate_model.py:188-189.
+ * tables: DFT(window folded in) + mel filterbank, built once by wipa_logmel_init.
+ * audio  [B, 480000] f32 (already pad_or_trim'ed);
+ * mel    [B*3002 + 4, n_mels] T ("padded mel"): frame t of clip b at row b*3002 + t + 1,
+ *        rows b*3002 and b*3002+3001 (the conv1 halo) and the 4 tail rows written as zero,
+ *        values = (max(log10(max(mel,1e-10)), gmax-8)+4)/4. */
+#define WIPA_MEL_ROWS(B) ((int64_t)(B) * 3002 + 4)
+size_t wipa_logmel_tables_bytes(int n_mels);
+int wipa_logmel_init(void* tables, int n_mels, wipa_stream_t s);
+size_t wipa_logmel_workspace_bytes(int batch, int n_mels);
+int wipa_logmel(const float* audio, int batch, int n_mels, const void* tables, void* mel, int mel_dtype,
+                void* workspace, size_t workspace_bytes, wipa_stream_t s);
+/* [B,3000,n_mels] f32 (any producer) -> padded mel [B*3002 + 4, n_mels] T for the encoder. */
+int wipa_mel_pad_cast(const float* mel, int batch, int n_mels, void* mel_padded, int dtype, wipa_stream_t s);
+
+/* ------------------------------------------------------------------ K4 GEMM
+ * C = epilogue(A * W^T): every nn.Linear / Conv1d of mlx_whisper.whisper
+ * (AudioEncoder, TextDecoder, MultiHeadAttention, ResidualAttentionBlock).
+ * A: row m starts at A + m*lda (rows may OVERLAP: conv-as-GEMM, STFT framing), K contiguous.
+ * W: [N,K] row-major (nn.Linear layout [out,in]); K must be a multiple of 128/sizeof(T)
+ *    bytes-wise (64 bf16 / 32 f32): pad W with zero columns, A must stay readable.
+ * epilogue, in order: + bias, * col_scale (columns < col_scale_n), gelu(erf),
+ *    + pos[(m % rg_in) * ldpos + n], + residual, cast, store.
+ * output element (m,n) lives at
+ *    C + c_offset + (*c_offset_dev) + (m / rg_in) * rg_stride + (m % rg_in) * ldc
+ *      + (n / cg_in) * cg_stride + (n % cg_in)
+ *    rows with (m % rg_in) >= rg_valid are skipped (or written as 0 if zero_invalid_rows).
+ *    Defaults rg_in = M (rg_valid = M), cg_in = N give the plain C[m*ldc + n].
+ * residual uses the same addressing and dtype as C and may alias it. */
+typedef struct wipa_gemm_desc {
+    const void* A;
+    const void* W;
+    void* C;
+    const float* bias;
+    const void* residual;
+    const float* pos;
+    const int64_t* c_offset_dev;
+    int64_t lda, ldw, ldc, ldpos;
+    int64_t rg_stride, cg_stride, c_offset;
+    int32_t M, N, K;
+    int32_t in_dtype, out_dtype;
+    int32_t rg_in, rg_valid, cg_in;
+    int32_t zero_invalid_rows;
+    int32_t bias_along_m;
+    int32_t act; /* 0 none, 1 gelu(erf) */
+    int32_t col_scale_n;
+    float col_scale;
+    int32_t reserved;
+} wipa_gemm_desc;
+int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t s);
+
+/* ------------------------------------------------------------------ K3 LayerNorm
+ * nn.LayerNorm(eps=1e-5) rows of width D (attn_ln, cross_attn_ln, mlp_ln, ln_post, ln). */
+int wipa_layernorm(const void* x, int x_dtype, int64_t ldx, void* y, int y_dtype, int64_t ldy, const float* w,
+                   const float* b, int rows, int D, float eps, wipa_stream_t s);
+
+/* ------------------------------------------------------------------ K8 embedding
+ * TextDecoder: token_embedding[tokens] + positional_embedding[offset : offset+T].
+ * tokens [B, ld_tok] int32; row (b,t) uses token tokens[b][p] and position p,
+ * p = t_start + (pos_dev ? *pos_dev : 0) + t.  x [B*T, D] f32. */
+int wipa_embed_tokens(const int32_t* tokens, int64_t ld_tok, int B, int T, int t_start, const int32_t* pos_dev,
+                      const void* tok_emb, int emb_dtype, const float* pos_emb, float* x, int D, wipa_stream_t s);
+
+/* ------------------------------------------------------------------ attention
+ * MultiHeadAttention.qkv_attention with head_dim 64; q and k arrive already
+ * scaled by 64**-0.25 (GEMM epilogue col_scale), softmax in f32.
+ * generic kernel (f32 math): encoder self-attn in f32, decoder causal self-attn,
+ * teacher-forced cross-attn.  Element (b, t, h, d) of X is at
+ *   X + b*x_bs + t*x_rs + h*x_hs + d.
+ * Tk = (tk_dev ? *tk_dev : 0) + Tk;  causal: query i sees keys <= i + (Tk - Tq). */
+typedef struct wipa_attn_desc {
+    const void* q;
+    const void* k;
+    const void* v;
+    void* out;
+    const int32_t* tk_dev;
+    const int32_t* q_row_dev; /* optional device int: first query row = *q_row_dev (decode step) */
+    int64_t q_bs, q_rs, q_hs;
+    int64_t k_bs, k_rs, k_hs;
+    int64_t v_bs, v_rs, v_hs;
+    int64_t o_bs, o_rs, o_hs;
+    int32_t B, H, Tq, Tk;
+    int32_t causal, dtype;
+} wipa_attn_desc;
+int wipa_attention(const wipa_attn_desc* d, wipa_stream_t s);
+
+/* K5 encoder self-attention, bf16 MFMA flash kernel (non-causal, T keys).
+ * qk  [B*T, ldqk] bf16: q of head h at column h*64, k at column D + h*64;
+ * vt  [B][D][ldvt] bf16: V transposed per clip (row h*64+d, column t), ldvt >= ceil64(T),
+ *     columns >= T must hold finite values (zero);
+ * out [B*T, ldo] bf16. */
+int wipa_flash_attn_enc_bf16(const void* qk, int64_t ldqk, const void* vt, int64_t ldvt, void* out, int64_t ldo,
+                             int B, int H, int T, wipa_stream_t s);
+
+/* K11 decode-step cross-attention (HBM-bound): one query row per (b,h) against the
+ * cached cross K/V.  q [B, H*64] T; kv [B][2H][Tk][64] T (K heads then V heads);
+ * out [B, H*64] T. */
+int wipa_decode_cross_attn(const void* q, const void* kv, void* out, int B, int H, int Tk, int dtype,
+                           wipa_stream_t s);
+
+/* ------------------------------------------------------------------ K13 greedy step
+ * GreedyDecoder.update + SuppressBlank + SuppressTokens of mlx_whisper.decoding
+ * (transcribe_single.py:49-55).  p = *pos_dev is the position whose logits these are.
+ * If p + 1 < n_init the next token is already given (prompt) and nothing is written.
+ * Otherwise: logits += (p + 1 == n_init ? mask_first : mask_always) (0 / -inf, f32 [V]);
+ * next = argmax (lowest index on ties); sum_logprobs += log_softmax[next] unless the
+ * previous token was eot; next = eot if previous was eot; tokens[b][p+1] = next.
+ * not_done is incremented by the number of rows whose next != eot. */
+int wipa_greedy_step(const float* logits, int64_t ldl, int B, int V, const float* mask_first,
+                     const float* mask_always, int32_t* tokens, int64_t ld_tok, const int32_t* pos_dev, int n_init,
+                     int eot, float* sum_logprobs, int32_t* not_done, wipa_stream_t s);
+int wipa_add_i32(int32_t* p, int32_t v, wipa_stream_t s);
+
+/* ------------------------------------------------------------------ model runtime
+ * Sequencing of the kernels above for a whole encoder / decoder pass, in C++ so the
+ * decode loop runs from a hipGraph with no per-kernel host work. */
+typedef struct wipa_model_cfg {
+    int32_t n_mels, n_audio_ctx, n_audio_state, n_audio_head, n_audio_layer;
+    int32_t n_vocab, n_text_ctx, n_text_state, n_text_head, n_text_layer;
+    int32_t dtype; /* WIPA_F32 or WIPA_BF16: matrices, activations, KV caches */
+    int32_t reserved;
+} wipa_model_cfg;
+
+/* Encoder weight table (const void* [WIPA_ENC_GLOBAL + WIPA_ENC_PER_LAYER * n_layer]):
+ *   0 conv1.weight [d, K1] T   (mlx layout [d,3,n_mels] flattened, K1 = 3*n_mels padded to the GEMM K multiple)
+ *   1 conv1.bias f32   2 conv2.weight [d, 3d] T   3 conv2.bias   4 positional [n_audio_ctx, d] f32
+ *   5 ln_post.weight   6 ln_post.bias
+ *   per layer: 0 attn_ln.w 1 attn_ln.b 2 qk.w [2d,d] T (query|key) 3 qk.b [2d] (key half zero)
+ *              4 value.w [d,d] T 5 value.b 6 out.w 7 out.b 8 mlp_ln.w 9 mlp_ln.b
+ *              10 mlp1.w [4d,d] 11 mlp1.b 12 mlp2.w [d,4d] 13 mlp2.b */
+#define WIPA_ENC_GLOBAL 7
+#define WIPA_ENC_PER_LAYER 14
+/* Decoder weight table (const void* [WIPA_DEC_GLOBAL + WIPA_DEC_PER_LAYER * n_layer]):
+ *   0 token_embedding [V, d] T   1 positional_embedding [n_text_ctx, d] f32   2 ln.w   3 ln.b
+ *   per layer: 0 attn_ln.w 1 attn_ln.b 2 qkv.w [3d,d] T 3 qkv.b [3d] (key third zero) 4 out.w 5 out.b
+ *              6 cross_attn_ln.w 7 cross_attn_ln.b 8 cross.query.w 9 cross.query.b
+ *              10 cross.kv.w [2d,d] T (key|value) 11 cross.kv.b [2d] (key half zero) 12 cross.out.w 13 cross.out.b
+ *              14 mlp_ln.w 15 mlp_ln.b 16 mlp1.w 17 mlp1.b 18 mlp2.w 19 mlp2.b */
+#define WIPA_DEC_GLOBAL 4
+#define WIPA_DEC_PER_LAYER 20
+
+/* AudioEncoder.__call__ / Whisper.embed_audio (train_whisper_ipa.py:223,
+ * transcribe_single.py:54).  mel_padded [B,3002,n_mels] T -> out [B, n_audio_ctx, d] T. */
+size_t wipa_encoder_workspace_bytes(const wipa_model_cfg* cfg, int B);
+int wipa_encoder_forward(const wipa_model_cfg* cfg, const void* const* weights, const void* mel_padded, void* out,
+                         void* workspace, size_t workspace_bytes, int B, wipa_stream_t s);
+
+/* KV-cached greedy decoding: mlx_whisper.decoding.decode / DecodingTask.run
+ * (transcribe_single.py:55, train_whisper_ipa.py:356, evaluate_model.py:200).
+ * All decode state lives in ONE caller-owned blob; wipa_decoder_layout gives byte offsets. */
+typedef struct wipa_dec_layout {
+    int64_t total_bytes;
+    int64_t tokens;       /* int32 [B, ld_tok] */
+    int64_t ld_tok;       /* elements */
+    int64_t pos;          /* int32 scalar: index of the last filled token */
+    int64_t not_done;     /* int32 scalar, accumulated by greedy steps */
+    int64_t sum_logprobs; /* f32 [B] */
+    int64_t logits;       /* f32 [B, ld_logits]: logits of the last step */
+    int64_t ld_logits;
+    int64_t cross_kv;     /* T [n_layer][B][2H][n_audio_ctx][64] */
+    int64_t self_kv;      /* T [n_layer][3][B][n_text_ctx][d]  (slot 0 q staging, 1 K, 2 V) */
+    int64_t scratch;
+} wipa_dec_layout;
+int wipa_decoder_layout(const wipa_model_cfg* cfg, int B, wipa_dec_layout* out);
+/* cross K/V projection of the encoder output (MultiHeadAttention with xa, computed once). */
+int wipa_decoder_set_audio(const wipa_model_cfg* cfg, const void* const* weights, const void* features, void* state,
+                           int B, wipa_stream_t s);
+/* write the prompt (host int32 [n_init]) to every row, pos = 0, clear counters. */
+int wipa_decoder_begin(const wipa_model_cfg* cfg, void* state, int B, const int32_t* initial_tokens_host, int n_init,
+                       wipa_stream_t s);
+/* n_steps decoder steps (each: one token position through all layers + greedy update).
+ * The prompt is consumed one position per step.  use_graph != 0 captures one step into a
+ * hipGraph and replays it. */
+int wipa_decoder_run(const wipa_model_cfg* cfg, const void* const* weights, void* state, int B, int n_init, int eot,
+                     const float* mask_first, const float* mask_always, int n_steps, int use_graph,
+                     wipa_stream_t s);
+/* drop the cached step graphs that reference this state blob (call before freeing it). */
+int wipa_decoder_release(void* state);
+
+/* Teacher-forced TextDecoder.__call__ = Whisper.logits (train_whisper_ipa.py:232).
+ * tokens [B,T] int32, features [B, n_audio_ctx, d] T -> logits [B*T, ld_logits] f32. */
+size_t wipa_decoder_logits_workspace_bytes(const wipa_model_cfg* cfg, int B, int T);
+int wipa_decoder_logits(const wipa_model_cfg* cfg, const void* const* weights, const int32_t* tokens, const void* features,
+                        float* logits, int64_t ld_logits, void* workspace, size_t workspace_bytes, int B, int T,
+                        wipa_stream_t s);
+
+/* ------------------------------------------------------------------ K9 masked CE
+ * compute_loss of train_whisper_ipa.py:207-263 on teacher-forced logits.
+ * logits [B*T, ldl] f32 (T = tokens_len - 1), tokens [B, ld_tok] int32: input t, target t+1.
+ * mask = (tgt != eot) | (cumsum(tgt == eot) == 1).  row_buf f32 [2*B*T] receives the
+ * per-row mask*ce and mask; out2[0] = sum(mask*ce), out2[1] = sum(mask) (fixed-order sum). */
+int wipa_masked_ce(const float* logits, int64_t ldl, const int32_t* tokens, int64_t ld_tok, int B, int T, int V, int eot,
+                   float* row_buf, float* out2, wipa_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WIPA_H */

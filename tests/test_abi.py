@@ -1,0 +1,85 @@
+"""CPU: the C-ABI library loads and exports every symbol include/wipa.h declares, the ctypes
+structs mirror the C layouts, and importing the package needs no GPU.  No compute calls."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "wipa.h")
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+
+    g.build()
+    from whisper_ipa_amd import _lib
+
+    return _lib
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(wipa_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported_and_bound(built):
+    names = _declared()
+    assert len(names) >= 20
+    lib = built.lib()
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in wipa.h but not exported by libwipa.so"
+        assert n in built.SIGNATURES, f"{n} has no ctypes signature in _lib.py"
+    extra = set(built.SIGNATURES) - set(names)
+    assert not extra, f"bound but not declared in wipa.h: {extra}"
+
+
+def test_version_and_error_string(built):
+    lib = built.lib()
+    assert lib.wipa_version() >= 100
+    assert isinstance(lib.wipa_last_error(), bytes)
+
+
+def test_struct_layouts_match_c(built, tmp_path):
+    """Compile a tiny C program against wipa.h and compare sizeof/offsetof with ctypes."""
+    prog = tmp_path / "lay.c"
+    prog.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "wipa.h"\n'
+        "int main(){\n"
+        'printf("%zu %zu %zu %zu\\n", sizeof(wipa_gemm_desc), sizeof(wipa_attn_desc), sizeof(wipa_model_cfg), sizeof(wipa_dec_layout));\n'
+        'printf("%zu %zu %zu %zu\\n", offsetof(wipa_gemm_desc, lda), offsetof(wipa_gemm_desc, M), offsetof(wipa_gemm_desc, col_scale), offsetof(wipa_gemm_desc, cg_in));\n'
+        'printf("%zu %zu %zu\\n", offsetof(wipa_attn_desc, q_bs), offsetof(wipa_attn_desc, B), offsetof(wipa_attn_desc, dtype));\n'
+        "return 0;}\n"
+    )
+    exe = tmp_path / "lay"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).split("\n")
+    sizes = [int(x) for x in out[0].split()]
+    assert sizes == [C.sizeof(built.GemmDesc), C.sizeof(built.AttnDesc), C.sizeof(built.ModelCfg), C.sizeof(built.DecLayout)]
+    g = [int(x) for x in out[1].split()]
+    assert g == [built.GemmDesc.lda.offset, built.GemmDesc.M.offset, built.GemmDesc.col_scale.offset, built.GemmDesc.cg_in.offset]
+    a = [int(x) for x in out[2].split()]
+    assert a == [built.AttnDesc.q_bs.offset, built.AttnDesc.B.offset, built.AttnDesc.dtype.offset]
+
+
+def test_missing_library_fails_loudly(monkeypatch, built):
+    """No silent fallback: a missing .so is an error, not a CPU path."""
+    from whisper_ipa_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libwipa.so")
+    with pytest.raises(_lib.WipaError):
+        _lib.lib()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "whisper_ipa_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in txt.replace("# oracle", ""), f"{f} mentions the oracle"

@@ -1,0 +1,210 @@
+"""GPU parity tests, kernel level: every HIP kernel through the C ABI (ctypes) against a plain
+torch fp32 statement of the same op.  Run with ``pytest -m gpu`` on an MI355X."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from whisper_ipa_amd import ops as o
+
+    return o
+
+
+def _rel(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 96), (64, 768, 768), (1, 51865, 128), (1000, 402, 416)])
+def test_gemm_f32_plain(ops, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g)
+    ldc = (N + 7) // 8 * 8
+    out = torch.full((M, ldc), 7.0, device="cuda")
+    ops.gemm(A.cuda(), W.cuda(), out, M=M, N=N, K=K, lda=K, ldw=K, ldc=ldc)
+    torch.cuda.synchronize()
+    ref = A.double() @ W.double().T
+    assert _rel(out[:, :N], ref) < 2e-6
+    if ldc > N:
+        assert (out[:, N:] == 7.0).all()  # padding columns untouched
+
+
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+def test_gemm_bf16_epilogue(ops, out_dtype):
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 333, 256, 192
+    A = torch.randn(M, K, generator=g).bfloat16()
+    W = (torch.randn(N, K, generator=g) * 0.1).bfloat16()
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g).to(out_dtype)
+    out = res.clone().cuda()
+    ops.gemm(A.cuda(), W.cuda(), out, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, bias=bias.cuda(), act=1, residual=out,
+             col_scale_n=100, col_scale=0.5)
+    torch.cuda.synchronize()
+    y = A.float() @ W.float().T + bias
+    y[:, :100] *= 0.5
+    ref = torch.nn.functional.gelu(y) + res.float()
+    tol = 1e-2 if out_dtype == torch.bfloat16 else 2e-5
+    assert _rel(out, ref) < tol
+
+
+def test_gemm_overlapping_rows_and_remap(ops):
+    """conv1d(k=3, pad=1) as a GEMM over a halo-padded, row-overlapping A, output shifted by one
+    row with zeroed dead rows -- the layout trick of the encoder front end."""
+    g = torch.Generator().manual_seed(5)
+    B, L, Cin, Cout = 2, 50, 32, 64
+    x = torch.randn(B, L, Cin, generator=g)
+    w = torch.randn(Cout, 3, Cin, generator=g) * 0.2
+    bias = torch.randn(Cout, generator=g)
+    P = L + 2
+    xp = torch.zeros(B * P + 4, Cin)
+    for b in range(B):
+        xp[b * P + 1 : b * P + 1 + L] = x[b]
+    out = torch.full((B * P + 4, Cout), 9.0)
+    out[0] = 0
+    out = out.cuda()
+    ops.gemm(xp.cuda(), w.reshape(Cout, 3 * Cin).contiguous().cuda(), out, M=B * P, N=Cout, K=3 * Cin, lda=Cin, ldw=3 * Cin,
+             ldc=Cout, bias=bias.cuda(), rg_in=P, rg_valid=L, rg_stride=P * Cout, zero_invalid_rows=True, c_offset=Cout)
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.conv1d(x.transpose(1, 2), w.permute(0, 2, 1), bias, padding=1).transpose(1, 2)
+    got = out.cpu()
+    for b in range(B):
+        assert _rel(got[b * P + 1 : b * P + 1 + L], ref[b]) < 1e-5
+        assert (got[b * P] == 0).all() and (got[b * P + L + 1] == 0).all()
+
+
+def test_gemm_transposed_output_groups(ops):
+    """bias along M + column groups: the V^T-per-clip layout of the encoder."""
+    g = torch.Generator().manual_seed(6)
+    d, B, T, Tp = 64, 3, 20, 32
+    Wv = torch.randn(d, d, generator=g)
+    x = torch.randn(B * T, d, generator=g)
+    bv = torch.randn(d, generator=g)
+    out = torch.zeros(B, d, Tp).cuda()
+    ops.gemm(Wv.cuda(), x.cuda(), out, M=d, N=B * T, K=d, lda=d, ldw=d, ldc=Tp, bias=bv.cuda(), bias_along_m=True, cg_in=T,
+             cg_stride=d * Tp)
+    torch.cuda.synchronize()
+    ref = (x @ Wv.T + bv).view(B, T, d).transpose(1, 2)
+    assert _rel(out[:, :, :T], ref) < 1e-5
+    assert (out[:, :, T:] == 0).all()
+
+
+@pytest.mark.parametrize("din,dout", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16)])
+@pytest.mark.parametrize("D", [128, 384, 768, 1280])
+def test_layernorm(ops, din, dout, D):
+    g = torch.Generator().manual_seed(D)
+    x = (torch.randn(37, D, generator=g) * 3 + 1).to(din)
+    w = torch.randn(D, generator=g)
+    b = torch.randn(D, generator=g)
+    y = ops.layernorm(x.cuda(), w.cuda(), b.cuda(), out_dtype=dout)
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.layer_norm(x.float(), (D,), w, b, 1e-5)
+    assert _rel(y, ref) < (1e-2 if dout == torch.bfloat16 else 1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Tq,Tk,causal", [(37, 150, False), (21, 21, True), (1, 300, False), (5, 69, True), (130, 1500, False)])
+def test_attention_generic(ops, dtype, Tq, Tk, causal):
+    g = torch.Generator().manual_seed(Tq * 1000 + Tk)
+    B, H = 2, 3
+    q = (torch.randn(B, Tq, H, 64, generator=g) * 0.5).to(dtype)
+    k = (torch.randn(B, Tk, H, 64, generator=g) * 0.5).to(dtype)
+    v = torch.randn(B, Tk, H, 64, generator=g).to(dtype)
+    out = ops.attention(q.cuda(), k.cuda(), v.cuda(), causal=causal)
+    torch.cuda.synchronize()
+    s = torch.einsum("bqhd,bkhd->bhqk", q.float(), k.float())
+    if causal:
+        mask = torch.triu(torch.full((Tk, Tk), float("-inf")), 1)[Tk - Tq :]
+        s = s + mask
+    ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1), v.float())
+    assert _rel(out, ref) < (1e-2 if dtype == torch.bfloat16 else 1e-5)
+
+
+@pytest.mark.parametrize("T", [1500, 128, 200])
+def test_flash_attention_encoder_bf16(ops, T):
+    g = torch.Generator().manual_seed(T)
+    B, H = 2, 2
+    D = H * 64
+    q = (torch.randn(B, T, H, 64, generator=g) * 0.6).bfloat16()
+    k = (torch.randn(B, T, H, 64, generator=g) * 0.6).bfloat16()
+    v = torch.randn(B, T, H, 64, generator=g).bfloat16()
+    qk = torch.cat([q.reshape(B * T, D), k.reshape(B * T, D)], dim=1).contiguous()
+    Tp = (T + 63) // 64 * 64
+    vt = torch.zeros(B, D, Tp, dtype=torch.bfloat16)
+    vt[:, :, :T] = v.reshape(B, T, D).transpose(1, 2)
+    out = ops.flash_attn_enc(qk.cuda(), vt.cuda(), B, H, T)
+    torch.cuda.synchronize()
+    s = torch.einsum("bqhd,bkhd->bhqk", q.float(), k.float())
+    ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1), v.float()).reshape(B * T, D)
+    assert _rel(out, ref) < 1.5e-2
+
+
+def test_flash_attention_spiked_scores(ops):
+    """force large running-max jumps between key tiles (online-softmax rescale path)."""
+    g = torch.Generator().manual_seed(11)
+    B, H, T = 1, 1, 256
+    q = (torch.randn(B, T, H, 64, generator=g) * 0.3).bfloat16()
+    k = (torch.randn(B, T, H, 64, generator=g) * 0.3).bfloat16()
+    v = torch.randn(B, T, H, 64, generator=g).bfloat16()
+    for t in (70, 140, 250):  # later tiles hold much larger scores for some queries
+        k[0, t, 0] = (q[0, t % 37, 0].float() * (t / 10.0)).bfloat16()
+    qk = torch.cat([q.reshape(T, 64), k.reshape(T, 64)], dim=1).contiguous()
+    vt = v.reshape(1, T, 64).transpose(1, 2).contiguous()
+    out = ops.flash_attn_enc(qk.cuda(), vt.cuda(), B, H, T)
+    torch.cuda.synchronize()
+    s = torch.einsum("bqhd,bkhd->bhqk", q.float(), k.float())
+    ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1), v.float()).reshape(T, 64)
+    assert _rel(out, ref) < 1.5e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Tk", [1500, 97, 8])
+def test_decode_cross_attention(ops, dtype, Tk):
+    g = torch.Generator().manual_seed(Tk)
+    B, H = 3, 2
+    q = (torch.randn(B, H * 64, generator=g) * 0.5).to(dtype)
+    kv = torch.randn(B, 2 * H, Tk, 64, generator=g).to(dtype)
+    out = ops.decode_cross_attn(q.cuda(), kv.cuda())
+    torch.cuda.synchronize()
+    qf = q.float().view(B, H, 64)
+    K, V = kv[:, :H].float(), kv[:, H:].float()
+    s = torch.einsum("bhd,bhtd->bht", qf, K)
+    ref = torch.einsum("bht,bhtd->bhd", torch.softmax(s, -1), V).reshape(B, H * 64)
+    assert _rel(out, ref) < (1e-2 if dtype == torch.bfloat16 else 1e-5)
+
+
+def test_embed_tokens(ops):
+    g = torch.Generator().manual_seed(1)
+    V, D, B, T = 1000, 128, 3, 7
+    emb = torch.randn(V, D, generator=g)
+    pos = torch.randn(448, D, generator=g)
+    tok = torch.randint(0, V, (B, T), generator=g, dtype=torch.int32)
+    x = ops.embed_tokens(tok.cuda(), emb.cuda(), pos.cuda())
+    torch.cuda.synchronize()
+    ref = emb[tok.long()] + pos[:T]
+    assert torch.equal(x.cpu().view(B, T, D), ref)
+
+
+def test_masked_ce(ops):
+    g = torch.Generator().manual_seed(2)
+    B, T, V, eot = 3, 9, 51865, 50257
+    logits = torch.randn(B * T, V + 7, generator=g) * 2
+    tokens = torch.randint(0, 50000, (B, T + 1), generator=g, dtype=torch.int32)
+    tokens[0, 6:] = eot
+    tokens[1, 3:] = eot
+    out, rows = ops.masked_ce(logits.cuda(), tokens.cuda(), V, eot)
+    torch.cuda.synchronize()
+    tgt = tokens[:, 1:].long()
+    is_eot = tgt == eot
+    mask = (~is_eot) | (torch.cumsum(is_eot.long(), 1) == 1)
+    ce = torch.nn.functional.cross_entropy(logits[:, :V], tgt.reshape(-1), reduction="none")
+    ref_sum = float((ce * mask.reshape(-1)).sum())
+    assert abs(float(out[0]) - ref_sum) / ref_sum < 1e-5
+    assert int(out[1]) == int(mask.sum())

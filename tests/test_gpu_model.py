@@ -1,0 +1,233 @@
+"""GPU parity tests, path level: log-mel -> encoder -> (teacher-forced | KV-cached greedy)
+decoder through the C ABI, against the CPU oracle on the same seeded inputs and against the
+committed golden fixtures.  ``pytest -m gpu`` on an MI355X."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import whisper_ref as R
+
+pytestmark = pytest.mark.gpu
+
+MICRO = R.ModelDimensions(80, 1500, 128, 2, 2, 51865, 448, 128, 2, 2)
+SMALL2 = R.ModelDimensions(80, 1500, 768, 12, 2, 51865, 448, 768, 12, 2)  # whisper-small width, 2+2 layers
+
+
+def _model(dims_o, W, dtype):
+    from whisper_ipa_amd.whisper import ModelDimensions, Whisper
+
+    m = Whisper(ModelDimensions(**dims_o.__dict__), dtype=dtype)
+    m.load_weights(W)
+    return m
+
+
+@pytest.fixture(scope="module")
+def clips():
+    return np.stack([R.synthetic_clip(0, 30.0), R.synthetic_clip(1, 5.0)])
+
+
+@pytest.fixture(scope="module")
+def micro(clips):
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    W = R.synthetic_weights(MICRO, seed=7)
+    mels = np.stack([R.log_mel_spectrogram(a) for a in clips])
+    with torch.no_grad():
+        xa = R.encoder_forward(W, MICRO, torch.from_numpy(mels))
+    return W, mels, xa
+
+
+@pytest.mark.parametrize("n_mels", [80, 128])
+def test_logmel_matches_oracle_and_golden(clips, golden_dir, n_mels):
+    import whisper_ipa_amd as wipa
+
+    mel = wipa.log_mel_spectrogram(clips, n_mels=n_mels)
+    assert tuple(mel.shape) == (2, 3000, n_mels) and mel.dtype == torch.float32
+    got = mel.cpu().numpy()
+    for i, name in enumerate(("full", "short")):
+        ref = R.log_mel_spectrogram(clips[i], n_mels)
+        assert np.abs(got[i] - ref).max() < 1e-3, np.abs(got[i] - ref).max()
+        g = np.load(os.path.join(golden_dir, "mel.npz"))
+        rows = g[f"{name}_{n_mels}_rows"]
+        assert np.abs(got[i][rows] - g[f"{name}_{n_mels}_slices"]).max() < 1e-3
+    single = wipa.log_mel_spectrogram(clips[0], n_mels=n_mels)
+    assert tuple(single.shape) == (3000, n_mels)
+    assert torch.equal(single, mel[0])
+
+
+def test_logmel_padded_layout(clips):
+    from whisper_ipa_amd import audio
+
+    a = torch.from_numpy(clips).cuda()
+    p = audio.log_mel_padded(a, 80, torch.bfloat16)
+    assert tuple(p.shape) == (2 * 3002 + 4, 80)
+    v = p[: 2 * 3002].view(2, 3002, 80).float()
+    assert (v[:, 0] == 0).all() and (v[:, 3001] == 0).all() and (p[2 * 3002 :] == 0).all()
+    ref = R.log_mel_spectrogram(clips[1])
+    assert np.abs(v[1, 1:3001].cpu().numpy() - ref).max() < 2e-2  # bf16 storage
+
+
+def test_encoder_f32_matches_oracle_and_golden(micro, golden_dir):
+    W, mels, xa = micro
+    m = _model(MICRO, W, torch.float32)
+    feats = m.encoder(torch.from_numpy(mels).cuda())
+    assert tuple(feats.shape) == (2, 1500, 128)
+    err = (feats.cpu() - xa).abs().max().item()
+    assert err < 1e-3, err
+    g = np.load(os.path.join(golden_dir, "micro_model.npz"))
+    assert np.abs(feats.cpu().numpy()[:, g["enc_rows"]] - g["enc_slices"]).max() < 1e-3
+
+
+def test_logits_and_loss_f32_match_oracle_and_golden(micro, golden_dir):
+    from whisper_ipa_amd import ops
+
+    W, mels, xa = micro
+    g = np.load(os.path.join(golden_dir, "micro_model.npz"))
+    tokens = torch.from_numpy(g["tokens"])
+    m = _model(MICRO, W, torch.float32)
+    logits = m.logits(tokens[:, :-1].cuda(), xa.cuda())
+    with torch.no_grad():
+        ref = R.decoder_forward(W, MICRO, tokens[:, :-1], xa)
+        ref_loss = R.loss_from_features(W, MICRO, xa, tokens, 50257)
+    err = (logits.cpu() - ref).abs().max().item()
+    assert err < 1e-3, err  # north_star: logits within 1e-3 in fp32
+    assert np.abs(logits.cpu().numpy()[:, :, g["logit_cols"]] - g["logit_slices"]).max() < 2e-3
+    B, T = tokens.shape[0], tokens.shape[1] - 1
+    flat = logits.reshape(B * T, -1)
+    base = logits.as_strided((B * T, logits.stride(1)), (logits.stride(1), 1))
+    out, _ = ops.masked_ce(base, tokens.to(torch.int32).cuda(), MICRO.n_vocab, 50257)
+    loss = float(out[0] / out[1].clamp(min=1))
+    assert abs(loss - float(ref_loss)) < 1e-3, (loss, float(ref_loss))
+    assert abs(loss - float(g["loss"][0])) < 1e-3
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_greedy_f32_bit_exact_vs_oracle_and_golden(micro, golden_dir, use_graph):
+    from whisper_ipa_amd.decoding import greedy_decode_tokens
+
+    W, mels, xa = micro
+    sp = R.SpecialTokens.multilingual()
+    always, first = R.suppress_lists(sp)
+    init = list(sp.sot_sequence_including_notimestamps(0))
+    m = _model(MICRO, W, torch.float32)
+    res = greedy_decode_tokens(m, xa.cuda(), init, always, first, sp.eot, max_new_tokens=24, stop_on_eot=False,
+                               use_graph=use_graph)
+    with torch.no_grad():
+        ref = R.greedy_decode(W, MICRO, xa, init, always, first, sp.eot, sample_len=24, stop_on_eot=False)
+    assert res.tokens.shape == ref.tokens.shape
+    assert (res.tokens == ref.tokens).all(), (res.tokens.tolist(), ref.tokens.tolist())
+    assert np.abs(res.sum_logprobs - ref.sum_logprobs).max() < 1e-2
+    g = np.load(os.path.join(golden_dir, "micro_model.npz"))
+    n = g["greedy_tokens"].shape[1]
+    assert (res.tokens[:, :n] == g["greedy_tokens"]).all()
+
+
+def test_greedy_eot_latch_and_early_stop():
+    from whisper_ipa_amd.decoding import greedy_decode_tokens
+
+    dims = R.ModelDimensions(80, 1500, 64, 1, 1, 51865, 448, 64, 1, 1)
+    W = R.synthetic_weights(dims, seed=3)
+    torch.manual_seed(0)
+    xa = torch.randn(3, 1500, 64)
+    sp = R.SpecialTokens.multilingual()
+    allowed = {sp.eot, 100, 200, 300}
+    always = [t for t in range(dims.n_vocab) if t not in allowed]
+    init = list(sp.sot_sequence_including_notimestamps(0))
+    m = _model(dims, W, torch.float32)
+    res = greedy_decode_tokens(m, xa.cuda(), init, always, [], sp.eot, max_new_tokens=40)
+    with torch.no_grad():
+        ref = R.greedy_decode(W, dims, xa, init, always, [], sp.eot, sample_len=40)
+    assert res.n_steps == ref.n_steps
+    assert (res.tokens == ref.tokens).all(), (res.tokens.tolist(), ref.tokens.tolist())
+    assert np.abs(res.sum_logprobs - ref.sum_logprobs).max() < 1e-3
+
+
+def test_detect_language_matches_oracle(micro):
+    from whisper_ipa_amd.decoding import detect_language
+    from whisper_ipa_amd.tokenizer import get_tokenizer
+
+    W, mels, xa = micro
+    m = _model(MICRO, W, torch.float32)
+    tok = get_tokenizer(True)
+    lang, probs = detect_language(m, xa.cuda(), tok)
+    with torch.no_grad():
+        ref = R.detect_language(W, MICRO, xa, R.SpecialTokens.multilingual())
+    assert (np.asarray(lang) == ref).all()
+    assert probs.shape == (2, 99) and abs(probs.sum(axis=1) - 1).max() < 1e-4
+
+
+def test_decode_api_surface(micro):
+    """transcribe_single.py:49-56 shape of use: features in, list of results with .text/.tokens."""
+    import whisper_ipa_amd as wipa
+
+    W, mels, xa = micro
+    m = _model(MICRO, W, torch.float32)
+    opts = wipa.DecodingOptions(language="en", without_timestamps=True, fp16=False, sample_len=6)
+    out = wipa.decode(m, xa.cuda(), opts)
+    assert isinstance(out, list) and len(out) == 2 and isinstance(out[0].text, str)
+    one = m.decode(torch.from_numpy(mels[0]).cuda(), opts)
+    assert isinstance(one, wipa.DecodingResult) and one.tokens == out[0].tokens
+    sp = R.SpecialTokens.multilingual()
+    always, first = R.suppress_lists(sp)
+    with torch.no_grad():
+        ref = R.greedy_decode(W, MICRO, xa, sp.sot_sequence_including_notimestamps(0), always, first, sp.eot, sample_len=6)
+    for i in range(2):
+        row = ref.tokens[i, 4:].tolist()
+        if sp.eot in row:
+            row = row[: row.index(sp.eot)]
+        assert out[i].tokens == row
+
+
+@pytest.fixture(scope="module")
+def small2(clips):
+    W = R.synthetic_weights(SMALL2, seed=11)
+    mels = np.stack([R.log_mel_spectrogram(a) for a in clips])
+    with torch.no_grad():
+        xa = R.encoder_forward(W, SMALL2, torch.from_numpy(mels))
+    return W, mels, xa
+
+
+def test_small_width_f32_encoder_and_greedy(small2):
+    """whisper-small width (d=768, 12 heads) exercises the full-size tiles in f32."""
+    from whisper_ipa_amd.decoding import greedy_decode_tokens
+
+    W, mels, xa = small2
+    m = _model(SMALL2, W, torch.float32)
+    feats = m.encoder(torch.from_numpy(mels).cuda())
+    err = (feats.cpu() - xa).abs().max().item()
+    assert err < 1e-3, err
+    sp = R.SpecialTokens.multilingual()
+    always, first = R.suppress_lists(sp)
+    init = list(sp.sot_sequence_including_notimestamps(0))
+    res = greedy_decode_tokens(m, feats, init, always, first, sp.eot, max_new_tokens=16, stop_on_eot=False)
+    with torch.no_grad():
+        ref = R.greedy_decode(W, SMALL2, xa, init, always, first, sp.eot, sample_len=16, stop_on_eot=False)
+    assert (res.tokens == ref.tokens).all(), (res.tokens.tolist(), ref.tokens.tolist(), ref.margins.min())
+
+
+def test_small_width_bf16_close_and_tokens_match_where_margin_allows(small2):
+    """bf16 path (the bench configuration's arithmetic) against the f32 oracle: features within
+    bf16 tolerance; greedy tokens must equal the oracle's up to the first step whose oracle
+    top-1 margin is below the bf16 noise floor (margin gating)."""
+    from whisper_ipa_amd.decoding import greedy_decode_tokens
+
+    W, mels, xa = small2
+    m = _model(SMALL2, W, torch.bfloat16)
+    feats = m.encoder(torch.from_numpy(mels).cuda())
+    assert feats.dtype == torch.bfloat16
+    rel = ((feats.float().cpu() - xa).abs().max() / xa.abs().max()).item()
+    assert rel < 5e-2, rel
+    sp = R.SpecialTokens.multilingual()
+    always, first = R.suppress_lists(sp)
+    init = list(sp.sot_sequence_including_notimestamps(0))
+    res = greedy_decode_tokens(m, feats, init, always, first, sp.eot, max_new_tokens=16, stop_on_eot=False)
+    with torch.no_grad():
+        ref = R.greedy_decode(W, SMALL2, xa, init, always, first, sp.eot, sample_len=16, stop_on_eot=False, keep_logits=True)
+    finite = ref.step_logits[np.isfinite(ref.step_logits)]
+    gate = 0.05 * float(finite.std())
+    for b in range(res.tokens.shape[0]):
+        for t in range(16):
+            if ref.margins[b, t] < gate:
+                break
+            assert res.tokens[b, 4 + t] == ref.tokens[b, 4 + t], (b, t, ref.margins[b, t], gate)

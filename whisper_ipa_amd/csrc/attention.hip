@@ -1,0 +1,468 @@
+// Attention kernels (head_dim = 64; q and k arrive pre-scaled by 64^-0.25 each).
+//   * attn_generic_kernel  : f32-math flash-style kernel for any (Tq, Tk), causal or not,
+//                            T in {f32, bf16} storage.  Parity path + decoder self-attn.
+//   * flash_enc_bf16_kernel: K5 encoder self-attention on bf16 MFMA 32x32x16 (swapped
+//                            QK^T so a P row is lane-local; P feeds PV from registers).
+//   * decode_cross_attn_kernel: K11, one query per (b,h) against the cached cross K/V,
+//                            HBM-bound streaming with 16-byte coalesced loads.
+// Replaces MultiHeadAttention.qkv_attention of mlx_whisper.whisper
+// (call sites scripts/train_whisper_ipa.py:223,232; scripts/transcribe_single.py:54-55).
+#include "wipa_common.h"
+
+namespace {
+
+constexpr float NEG_BIG = -1.0e30f;
+constexpr float NEG_TEST = -1.0e29f;
+
+// =============================================================================
+// generic attention, f32 math
+// =============================================================================
+struct AttnParams {
+    const char* q;
+    const char* k;
+    const char* v;
+    char* out;
+    const int32_t* tk_dev;
+    const int32_t* q_row_dev;
+    int64_t q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, v_bs, v_rs, v_hs, o_bs, o_rs, o_hs;
+    int Tq, Tk, causal;
+};
+
+constexpr int GA_LD = 68;  // padded f32 row (64 + 4): conflict-free ds_read_b128 across 16 keys
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_generic_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) float Ks[64 * GA_LD];
+    __shared__ __attribute__((aligned(16))) float Vs[64 * GA_LD];
+    constexpr int EPL = Vec16<T>::EPL;
+    const int tid = threadIdx.x;
+    const int ql = tid >> 4, kl = tid & 15;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int Tk = p.Tk + (p.tk_dev ? *p.tk_dev : 0);
+    const int qi = blockIdx.x * 16 + ql;
+    const int qc = min(qi, p.Tq - 1);
+    const int q_row0 = p.q_row_dev ? *p.q_row_dev : 0;
+    const T* qp = reinterpret_cast<const T*>(p.q) + b * p.q_bs + (int64_t)(q_row0 + qc) * p.q_rs + h * p.q_hs;
+    float q[64];
+#pragma unroll
+    for (int c = 0; c < 64 / EPL; ++c) {
+        Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(qp + c * EPL);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) q[c * EPL + e] = v.get(e);
+    }
+    float acc[64];
+#pragma unroll
+    for (int d = 0; d < 64; ++d) acc[d] = 0.f;
+    float m = NEG_BIG, l = 0.f;
+    const int kmax = p.causal ? (qc + (Tk - p.Tq)) : (Tk - 1);  // last visible key of this query
+    // staging role: key row srow, 16-element segment sseg
+    const int srow = tid >> 2, sseg = (tid & 3) * 16;
+    const T* kb = reinterpret_cast<const T*>(p.k) + b * p.k_bs + h * p.k_hs;
+    const T* vb = reinterpret_cast<const T*>(p.v) + b * p.v_bs + h * p.v_hs;
+    // causal: no query of this block sees keys beyond the block's last query
+    const int q_last = min(blockIdx.x * 16 + 15, p.Tq - 1);
+    const int k_end = p.causal ? min(Tk, q_last + (Tk - p.Tq) + 1) : Tk;
+    for (int k0 = 0; k0 < k_end; k0 += 64) {
+        __syncthreads();
+        {
+            const int key = k0 + srow;
+            float kv[16], vv[16];
+            if (key < Tk) {
+                const T* kp = kb + (int64_t)key * p.k_rs + sseg;
+                const T* vp = vb + (int64_t)key * p.v_rs + sseg;
+#pragma unroll
+                for (int c = 0; c < 16 / EPL; ++c) {
+                    Vec16<T> a = *reinterpret_cast<const Vec16<T>*>(kp + c * EPL);
+                    Vec16<T> bb = *reinterpret_cast<const Vec16<T>*>(vp + c * EPL);
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) {
+                        kv[c * EPL + e] = a.get(e);
+                        vv[c * EPL + e] = bb.get(e);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) kv[e] = vv[e] = 0.f;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                *reinterpret_cast<f32x4*>(&Ks[srow * GA_LD + sseg + 4 * c]) =
+                    f32x4{kv[4 * c], kv[4 * c + 1], kv[4 * c + 2], kv[4 * c + 3]};
+                *reinterpret_cast<f32x4*>(&Vs[srow * GA_LD + sseg + 4 * c]) =
+                    f32x4{vv[4 * c], vv[4 * c + 1], vv[4 * c + 2], vv[4 * c + 3]};
+            }
+        }
+        __syncthreads();
+        float s[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kk = kl + 16 * i;
+            const float* kr = &Ks[kk * GA_LD];
+            float a = 0.f;
+#pragma unroll
+            for (int d4 = 0; d4 < 16; ++d4) {
+                const f32x4 k4 = *reinterpret_cast<const f32x4*>(kr + 4 * d4);
+                a = fmaf(q[4 * d4], k4[0], a);
+                a = fmaf(q[4 * d4 + 1], k4[1], a);
+                a = fmaf(q[4 * d4 + 2], k4[2], a);
+                a = fmaf(q[4 * d4 + 3], k4[3], a);
+            }
+            s[i] = (k0 + kk <= kmax) ? a : NEG_BIG;
+        }
+        const float m_new = fmaxf(fmaxf(fmaxf(m, s[0]), fmaxf(s[1], s[2])), s[3]);
+        const float alpha = __expf(m - m_new);
+        l *= alpha;
+#pragma unroll
+        for (int d = 0; d < 64; ++d) acc[d] *= alpha;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float pr = (s[i] <= NEG_TEST) ? 0.f : __expf(s[i] - m_new);
+            l += pr;
+            const float* vr = &Vs[(kl + 16 * i) * GA_LD];
+#pragma unroll
+            for (int d4 = 0; d4 < 16; ++d4) {
+                const f32x4 v4 = *reinterpret_cast<const f32x4*>(vr + 4 * d4);
+                acc[4 * d4] = fmaf(pr, v4[0], acc[4 * d4]);
+                acc[4 * d4 + 1] = fmaf(pr, v4[1], acc[4 * d4 + 1]);
+                acc[4 * d4 + 2] = fmaf(pr, v4[2], acc[4 * d4 + 2]);
+                acc[4 * d4 + 3] = fmaf(pr, v4[3], acc[4 * d4 + 3]);
+            }
+        }
+        m = m_new;
+    }
+    // merge the 16 key lanes of this query (consecutive lanes of one wave)
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        const float m_o = __shfl_xor(m, o, 64);
+        const float l_o = __shfl_xor(l, o, 64);
+        const float m_n = fmaxf(m, m_o);
+        const float a = __expf(m - m_n), bsc = __expf(m_o - m_n);
+        l = l * a + l_o * bsc;
+#pragma unroll
+        for (int d = 0; d < 64; ++d) acc[d] = acc[d] * a + __shfl_xor(acc[d], o, 64) * bsc;
+        m = m_n;
+    }
+    if (qi < p.Tq) {
+        const float inv = 1.f / l;
+        T* op = reinterpret_cast<T*>(p.out) + b * p.o_bs + (int64_t)qi * p.o_rs + h * p.o_hs;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (kl == j) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) op[4 * j + e] = from_f32<T>(acc[4 * j + e] * inv);
+            }
+        }
+    }
+}
+
+// =============================================================================
+// K11 decode-step cross-attention
+// =============================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void decode_cross_attn_kernel(const T* __restrict__ q, const T* __restrict__ kv,
+                                                                T* __restrict__ out, int H, int Tk) {
+    constexpr int EPL = Vec16<T>::EPL;  // elements per 16-byte load
+    constexpr int LPK = 64 / EPL;       // lanes per key row (64 dims)
+    constexpr int G = 64 / LPK;         // keys per wave instruction
+    constexpr int U = 4;                // independent key groups in flight per iteration
+    __shared__ float s_m[4], s_l[4];
+    __shared__ float s_acc[4][64];
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane / LPK, c = lane % LPK;
+    const int D = H * 64;
+    float qf[EPL];
+    {
+        Vec16<T> qv = *reinterpret_cast<const Vec16<T>*>(q + (int64_t)b * D + h * 64 + c * EPL);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) qf[e] = qv.get(e);
+    }
+    const T* Kb = kv + ((int64_t)(b * 2 * H + h) * Tk) * 64 + c * EPL;
+    const T* Vb = kv + ((int64_t)(b * 2 * H + H + h) * Tk) * 64 + c * EPL;
+    float m = NEG_BIG, l = 0.f;
+    float acc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+    for (int t0 = wave * G * U; t0 < Tk; t0 += 4 * G * U) {
+        Vec16<T> kvec[U], vvec[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = min(t0 + u * G + g, Tk - 1);
+            kvec[u] = *reinterpret_cast<const Vec16<T>*>(Kb + (int64_t)t * 64);
+            vvec[u] = *reinterpret_cast<const Vec16<T>*>(Vb + (int64_t)t * 64);
+        }
+        float s[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float a = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) a = fmaf(qf[e], kvec[u].get(e), a);
+#pragma unroll
+            for (int o = 1; o < LPK; o <<= 1) a += __shfl_xor(a, o, 64);
+            s[u] = (t0 + u * G + g < Tk) ? a : NEG_BIG;
+        }
+        float m_new = m;
+#pragma unroll
+        for (int u = 0; u < U; ++u) m_new = fmaxf(m_new, s[u]);
+        const float alpha = __expf(m - m_new);
+        l *= alpha;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[e] *= alpha;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float pr = (s[u] <= NEG_TEST) ? 0.f : __expf(s[u] - m_new);
+            l += pr;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc[e] = fmaf(pr, vvec[u].get(e), acc[e]);
+        }
+        m = m_new;
+    }
+    // merge the G key groups of this wave (lanes with equal c)
+#pragma unroll
+    for (int o = LPK; o < 64; o <<= 1) {
+        const float m_o = __shfl_xor(m, o, 64);
+        const float l_o = __shfl_xor(l, o, 64);
+        const float m_n = fmaxf(m, m_o);
+        const float a = __expf(m - m_n), bsc = __expf(m_o - m_n);
+        l = l * a + l_o * bsc;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[e] = acc[e] * a + __shfl_xor(acc[e], o, 64) * bsc;
+        m = m_n;
+    }
+    if (lane < LPK) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) s_acc[wave][c * EPL + e] = acc[e];
+        if (lane == 0) {
+            s_m[wave] = m;
+            s_l[wave] = l;
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const float mm = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float sc = __expf(s_m[w] - mm);
+            num += s_acc[w][tid] * sc;
+            den += s_l[w] * sc;
+        }
+        out[(int64_t)b * D + h * 64 + tid] = from_f32<T>(num / den);
+    }
+}
+
+// =============================================================================
+// K5 encoder flash attention, bf16 MFMA 32x32x16
+// =============================================================================
+constexpr int FA_ROWB = 128;                // bytes per LDS row (64 bf16)
+constexpr int FA_TILE = 64 * FA_ROWB;       // 8 KiB
+constexpr float LOG2E = 1.4426950408889634f;
+
+__global__ __launch_bounds__(256, 2) void flash_enc_bf16_kernel(const __bf16* __restrict__ qk, int64_t ldqk,
+                                                                const __bf16* __restrict__ vt, int64_t ldvt,
+                                                                __bf16* __restrict__ out, int64_t ldo, int H, int T) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * FA_TILE];  // [buf][K tile | V^T tile]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int D = H * 64;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int nkt = (T + 63) / 64;
+
+    // Q fragments: B operand of S^T = K * Q^T.  lane (r,hh) holds Q[q0+r][16s + 8hh + 0..7]
+    bf16x8 qf[4];
+    {
+        const int qrow = min(q0 + r, T - 1);
+        const __bf16* qp = qk + ((int64_t)b * T + qrow) * ldqk + h * 64 + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+    }
+    // staging roles: rows srow, srow+32 ; 16-byte chunk schunk
+    const int srow = tid >> 3, schunk = tid & 7;
+    const __bf16* kg = qk + (int64_t)b * T * ldqk + D + h * 64 + schunk * 8;      // + key*ldqk
+    const __bf16* vg = vt + ((int64_t)b * D + h * 64) * ldvt + schunk * 8;        // + d*ldvt + k0
+    int lds_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = srow + 32 * i;
+        lds_off[i] = row * FA_ROWB + ((schunk ^ ((row >> 1) & 7)) << 4);
+    }
+    f32x4 rk[2], rv[2];
+    auto gload = [&](int kt) {
+        const int k0 = kt * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = srow + 32 * i;
+            const int key = min(k0 + row, T - 1);
+            rk[i] = *reinterpret_cast<const f32x4*>(kg + (int64_t)key * ldqk);
+            rv[i] = *reinterpret_cast<const f32x4*>(vg + (int64_t)row * ldvt + k0);
+        }
+    };
+    auto swrite = [&](int buf) {
+        char* base = smem + buf * 2 * FA_TILE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<f32x4*>(base + lds_off[i]) = rk[i];
+            *reinterpret_cast<f32x4*>(base + FA_TILE + lds_off[i]) = rv[i];
+        }
+    };
+
+    f32x16 O[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) O[0][i] = O[1][i] = 0.f;
+    float m = NEG_BIG, l = 0.f;  // m in the log2 domain (scores * log2e)
+    const int rsw = (r >> 1) & 7;  // swizzle term of rows 32x + r
+
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) gload(kt + 1);
+        const char* kbuf = smem + (kt & 1) * 2 * FA_TILE;
+        const char* vbuf = kbuf + FA_TILE;
+        f32x16 S[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) S[u][i] = 0.f;
+            const char* krow = kbuf + (32 * u + r) * FA_ROWB;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + (((2 * s + hh) ^ rsw) << 4));
+                S[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], S[u], 0, 0, 0);
+            }
+        }
+        // scale to log2 domain, mask the ragged last tile
+        const bool ragged = (kt * 64 + 64 > T);
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float sv = S[u][i] * LOG2E;
+                if (ragged) {
+                    const int key = kt * 64 + 32 * u + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    if (key >= T) sv = NEG_BIG;
+                }
+                S[u][i] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m, mx);
+        const float alpha = exp2f(m - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float pv = (S[u][i] <= NEG_TEST) ? 0.f : exp2f(S[u][i] - m_new);
+                S[u][i] = pv;
+                psum += pv;
+            }
+        l = l * alpha + psum;
+        m = m_new;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            O[0][i] *= alpha;
+            O[1][i] *= alpha;
+        }
+        // O^T += V^T * P^T : P^T comes straight from the S accumulators (k order of the
+        // 32x32 C layout: element j of half hh is key 16s' + 8(j>>2) + 4hh + (j&3))
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                bf16x8 pb;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pb[j] = (__bf16)S[u][8 * sp + j];
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const char* vrow = vbuf + (32 * dt + r) * FA_ROWB + 8 * hh;
+                    const int c0 = 4 * u + 2 * sp;
+                    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow + ((c0 ^ rsw) << 4));
+                    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + (((c0 + 1) ^ rsw) << 4));
+                    const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, O[dt], 0, 0, 0);
+                }
+            }
+        if (kt + 1 < nkt) swrite((kt + 1) & 1);
+        __syncthreads();
+    }
+    l += __shfl_xor(l, 32, 64);
+    const int qrow = q0 + r;
+    if (qrow < T) {
+        const float inv = 1.f / l;
+        __bf16* op = out + ((int64_t)b * T + qrow) * ldo + h * 64 + 4 * hh;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                bf16x4 o = {(__bf16)(O[dt][4 * g4] * inv), (__bf16)(O[dt][4 * g4 + 1] * inv),
+                            (__bf16)(O[dt][4 * g4 + 2] * inv), (__bf16)(O[dt][4 * g4 + 3] * inv)};
+                *reinterpret_cast<bf16x4*>(op + 32 * dt + 8 * g4) = o;
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int wipa_attention(const wipa_attn_desc* d, wipa_stream_t stream) {
+    WIPA_REQUIRE(d && d->q && d->k && d->v && d->out, "wipa_attention: null pointer");
+    WIPA_REQUIRE(d->B > 0 && d->H > 0 && d->Tq > 0, "wipa_attention: bad shape");
+    WIPA_REQUIRE(d->dtype == WIPA_F32 || d->dtype == WIPA_BF16, "wipa_attention: bad dtype %d", d->dtype);
+    const int64_t al = d->dtype == WIPA_BF16 ? 8 : 4;
+    WIPA_REQUIRE(d->q_rs % al == 0 && d->k_rs % al == 0 && d->v_rs % al == 0 && d->q_hs % al == 0 && d->k_hs % al == 0 &&
+                     d->v_hs % al == 0 && d->q_bs % al == 0 && d->k_bs % al == 0 && d->v_bs % al == 0,
+                 "wipa_attention: strides must keep 16-byte alignment");
+    AttnParams p;
+    p.q = (const char*)d->q;
+    p.k = (const char*)d->k;
+    p.v = (const char*)d->v;
+    p.out = (char*)d->out;
+    p.tk_dev = d->tk_dev;
+    p.q_row_dev = d->q_row_dev;
+    p.q_bs = d->q_bs; p.q_rs = d->q_rs; p.q_hs = d->q_hs;
+    p.k_bs = d->k_bs; p.k_rs = d->k_rs; p.k_hs = d->k_hs;
+    p.v_bs = d->v_bs; p.v_rs = d->v_rs; p.v_hs = d->v_hs;
+    p.o_bs = d->o_bs; p.o_rs = d->o_rs; p.o_hs = d->o_hs;
+    p.Tq = d->Tq;
+    p.Tk = d->Tk;
+    p.causal = d->causal;
+    dim3 grid((d->Tq + 15) / 16, d->H, d->B);
+    if (d->dtype == WIPA_F32)
+        hipLaunchKernelGGL((attn_generic_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL((attn_generic_kernel<__bf16>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+extern "C" int wipa_flash_attn_enc_bf16(const void* qk, int64_t ldqk, const void* vt, int64_t ldvt, void* out, int64_t ldo,
+                                        int B, int H, int T, wipa_stream_t stream) {
+    WIPA_REQUIRE(qk && vt && out, "wipa_flash_attn_enc_bf16: null pointer");
+    WIPA_REQUIRE(ldqk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "wipa_flash_attn_enc_bf16: ld alignment");
+    WIPA_REQUIRE(ldvt >= ((T + 63) / 64) * 64, "wipa_flash_attn_enc_bf16: ldvt=%lld must cover ceil64(T)", (long long)ldvt);
+    WIPA_REQUIRE(B > 0 && H > 0 && T > 0, "wipa_flash_attn_enc_bf16: bad shape");
+    dim3 grid((T + 127) / 128, H, B);
+    hipLaunchKernelGGL(flash_enc_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)qk, ldqk,
+                       (const __bf16*)vt, ldvt, (__bf16*)out, ldo, H, T);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+extern "C" int wipa_decode_cross_attn(const void* q, const void* kv, void* out, int B, int H, int Tk, int dtype,
+                                      wipa_stream_t stream) {
+    WIPA_REQUIRE(q && kv && out, "wipa_decode_cross_attn: null pointer");
+    WIPA_REQUIRE(B > 0 && H > 0 && Tk > 0, "wipa_decode_cross_attn: bad shape");
+    dim3 grid(H, B);
+    if (dtype == WIPA_F32)
+        hipLaunchKernelGGL((decode_cross_attn_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)q,
+                           (const float*)kv, (float*)out, H, Tk);
+    else if (dtype == WIPA_BF16)
+        hipLaunchKernelGGL((decode_cross_attn_kernel<__bf16>), grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)q,
+                           (const __bf16*)kv, (__bf16*)out, H, Tk);
+    else
+        WIPA_REQUIRE(false, "wipa_decode_cross_attn: bad dtype %d", dtype);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}

@@ -1,0 +1,347 @@
+// K3 LayerNorm, K8 embedding, K13 greedy step, K9 masked cross-entropy, small utilities.
+// All HBM-bound row kernels: one wave (LayerNorm) or one workgroup (vocab reductions) per
+// row, 8/16-byte vector loads, wave64 shuffle reductions, f32 math.
+#include "wipa_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ LayerNorm
+template <typename TI>
+__device__ __forceinline__ f32x4 ld4(const TI* p);
+template <>
+__device__ __forceinline__ f32x4 ld4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <>
+__device__ __forceinline__ f32x4 ld4<__bf16>(const __bf16* p) {
+    bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+template <typename TO>
+__device__ __forceinline__ void st4(TO* p, f32x4 v);
+template <>
+__device__ __forceinline__ void st4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <>
+__device__ __forceinline__ void st4<__bf16>(__bf16* p, f32x4 v) {
+    *reinterpret_cast<bf16x4*>(p) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+}
+
+constexpr int LN_MAXV = 8;  // D <= 8 * 256 = 2048
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x, int64_t ldx, TO* __restrict__ y,
+                                                        int64_t ldy, const float* __restrict__ w,
+                                                        const float* __restrict__ b, int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const TI* xr = x + (int64_t)row * ldx;
+    TO* yr = y + (int64_t)row * ldy;
+    f32x4 v[LN_MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < D) {
+            v[i] = ld4<TI>(xr + c);
+            sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        } else {
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float mean = wave_reduce_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < D) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mean;
+                sq += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_reduce_sum(sq) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < D) {
+            const f32x4 ww = *reinterpret_cast<const f32x4*>(w + c);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(b + c);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * ww[e] + bb[e];
+            st4<TO>(yr + c, o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ embedding
+template <typename TE>
+__global__ __launch_bounds__(256) void embed_kernel(const int32_t* __restrict__ tokens, int64_t ld_tok, int T, int t_start,
+                                                    const int32_t* __restrict__ pos_dev, const TE* __restrict__ emb,
+                                                    const float* __restrict__ pos_emb, float* __restrict__ x, int D) {
+    const int row = blockIdx.x;  // b*T + t
+    const int b = row / T, t = row - b * T;
+    const int p = t_start + (pos_dev ? *pos_dev : 0) + t;
+    const int tok = tokens[(int64_t)b * ld_tok + p];
+    const TE* e = emb + (int64_t)tok * D;
+    const float* pe = pos_emb + (int64_t)p * D;
+    float* xr = x + (int64_t)row * D;
+    for (int c = threadIdx.x * 4; c < D; c += 1024) {
+        const f32x4 a = ld4<TE>(e + c);
+        const f32x4 q = *reinterpret_cast<const f32x4*>(pe + c);
+        *reinterpret_cast<f32x4*>(xr + c) = a + q;
+    }
+}
+
+// ------------------------------------------------------------------ block reductions
+struct MaxIdx {
+    float v;
+    int i;
+};
+__device__ __forceinline__ MaxIdx better(MaxIdx a, MaxIdx b) {
+    // larger value wins; on ties the LOWER index (argmax returns the first maximum)
+    if (b.v > a.v || (b.v == a.v && b.i < a.i)) return b;
+    return a;
+}
+__device__ __forceinline__ MaxIdx wave_argmax(MaxIdx m) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        MaxIdx other;
+        other.v = __shfl_xor(m.v, o, 64);
+        other.i = __shfl_xor(m.i, o, 64);
+        m = better(m, other);
+    }
+    return m;
+}
+
+constexpr int GS_THREADS = 1024;
+
+__global__ __launch_bounds__(GS_THREADS) void greedy_step_kernel(const float* __restrict__ logits, int64_t ldl, int V,
+                                                                 const float* __restrict__ mask_first,
+                                                                 const float* __restrict__ mask_always,
+                                                                 int32_t* __restrict__ tokens, int64_t ld_tok,
+                                                                 const int32_t* __restrict__ pos_dev, int n_init, int eot,
+                                                                 float* __restrict__ sum_logprobs,
+                                                                 int32_t* __restrict__ not_done) {
+    __shared__ float s_v[GS_THREADS / 64];
+    __shared__ int s_i[GS_THREADS / 64];
+    __shared__ float s_sum[GS_THREADS / 64];
+    const int b = blockIdx.x;
+    const int p = *pos_dev;
+    if (p + 1 < n_init) return;  // prompt token already in place
+    const float* mask = (p + 1 == n_init) ? mask_first : mask_always;
+    const float* row = logits + (int64_t)b * ldl;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    MaxIdx m{-INFINITY, 0x7fffffff};
+    for (int i = tid; i < V; i += GS_THREADS) {
+        const float v = row[i] + mask[i];
+        m = better(m, MaxIdx{v, i});
+    }
+    m = wave_argmax(m);
+    if (lane == 0) {
+        s_v[wave] = m.v;
+        s_i[wave] = m.i;
+    }
+    __syncthreads();
+    MaxIdx bm{s_v[0], s_i[0]};
+#pragma unroll
+    for (int w = 1; w < GS_THREADS / 64; ++w) bm = better(bm, MaxIdx{s_v[w], s_i[w]});
+    float se = 0.f;
+    for (int i = tid; i < V; i += GS_THREADS) se += __expf(row[i] + mask[i] - bm.v);
+    se = wave_reduce_sum(se);
+    if (lane == 0) s_sum[wave] = se;
+    __syncthreads();
+    if (tid == 0) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < GS_THREADS / 64; ++w) tot += s_sum[w];
+        const int prev = tokens[(int64_t)b * ld_tok + p];
+        int next = bm.i;
+        if (prev == eot) {
+            next = eot;
+        } else {
+            sum_logprobs[b] += -logf(tot);  // log_softmax at the argmax = -(log sum exp(x - max))
+        }
+        tokens[(int64_t)b * ld_tok + p + 1] = next;
+        if (next != eot) atomicAdd(not_done, 1);
+    }
+}
+
+__global__ void add_i32_kernel(int32_t* p, int32_t v) { *p += v; }
+
+// ------------------------------------------------------------------ masked cross entropy
+constexpr int CE_THREADS = 512;
+__global__ __launch_bounds__(CE_THREADS) void masked_ce_rows_kernel(const float* __restrict__ logits, int64_t ldl,
+                                                                    const int32_t* __restrict__ tokens, int64_t ld_tok,
+                                                                    int T, int V, int eot, float* __restrict__ row_buf,
+                                                                    int rows) {
+    __shared__ float s_red[CE_THREADS / 64];
+    const int r = blockIdx.x;
+    const int b = r / T, t = r - b * T;
+    const int32_t* tk = tokens + (int64_t)b * ld_tok;
+    const int tgt = tk[t + 1];
+    const float* row = logits + (int64_t)r * ldl;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float mx = -INFINITY;
+    for (int i = tid; i < V; i += CE_THREADS) mx = fmaxf(mx, row[i]);
+    mx = wave_reduce_max(mx);
+    if (lane == 0) s_red[wave] = mx;
+    __syncthreads();
+    mx = s_red[0];
+#pragma unroll
+    for (int w = 1; w < CE_THREADS / 64; ++w) mx = fmaxf(mx, s_red[w]);
+    __syncthreads();
+    float se = 0.f;
+    for (int i = tid; i < V; i += CE_THREADS) se += __expf(row[i] - mx);
+    se = wave_reduce_sum(se);
+    if (lane == 0) s_red[wave] = se;
+    __syncthreads();
+    if (tid == 0) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < CE_THREADS / 64; ++w) tot += s_red[w];
+        const float ce = logf(tot) + mx - row[tgt];
+        // mask = (tgt != eot) | (cumsum(tgt == eot) == 1)      (train_whisper_ipa.py:242-247)
+        bool keep = true;
+        if (tgt == eot) {
+            int c = 0;
+            for (int u = 0; u <= t; ++u) c += (tk[u + 1] == eot);
+            keep = (c == 1);
+        }
+        row_buf[r] = keep ? ce : 0.f;
+        row_buf[rows + r] = keep ? 1.f : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void sum2_kernel(const float* __restrict__ row_buf, int rows, float* __restrict__ out2) {
+    // deterministic: fixed-order tree over a single workgroup
+    __shared__ float s_a[256], s_b[256];
+    float a = 0.f, c = 0.f;
+    for (int i = threadIdx.x; i < rows; i += 256) {
+        a += row_buf[i];
+        c += row_buf[rows + i];
+    }
+    s_a[threadIdx.x] = a;
+    s_b[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            s_a[threadIdx.x] += s_a[threadIdx.x + o];
+            s_b[threadIdx.x] += s_b[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out2[0] = s_a[0];
+        out2[1] = s_b[0];
+    }
+}
+
+// ------------------------------------------------------------------ mel pad + cast
+template <typename TO>
+__global__ __launch_bounds__(256) void mel_pad_cast_kernel(const float* __restrict__ mel, int n_mels, TO* __restrict__ out,
+                                                           int64_t total) {
+    // out [B, 3002, n_mels]; row 0 and 3001 zero, row t+1 = mel[b][t]
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int64_t per = (int64_t)(WIPA_N_FRAMES + 2) * n_mels;
+    const int64_t b = i / per;
+    const int64_t r = i - b * per;
+    const int row = (int)(r / n_mels);
+    float v = 0.f;
+    if (row >= 1 && row <= WIPA_N_FRAMES) v = mel[b * (int64_t)WIPA_N_FRAMES * n_mels + (r - n_mels)];
+    out[i] = from_f32<TO>(v);
+}
+
+}  // namespace
+
+extern "C" int wipa_layernorm(const void* x, int x_dtype, int64_t ldx, void* y, int y_dtype, int64_t ldy, const float* w,
+                              const float* b, int rows, int D, float eps, wipa_stream_t stream) {
+    WIPA_REQUIRE(x && y && w && b, "wipa_layernorm: null pointer");
+    WIPA_REQUIRE(D % 4 == 0 && D <= LN_MAXV * 256 && D > 0, "wipa_layernorm: D=%d must be a multiple of 4 and <= %d", D,
+                 LN_MAXV * 256);
+    WIPA_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "wipa_layernorm: ldx/ldy must be multiples of 4");
+    if (rows <= 0) return WIPA_OK;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((rows + 3) / 4), block(256);
+#define LN_LAUNCH(TI, TO)                                                                                      \
+    hipLaunchKernelGGL((layernorm_kernel<TI, TO>), grid, block, 0, s, (const TI*)x, ldx, (TO*)y, ldy, w, b, rows, D, eps)
+    if (x_dtype == WIPA_F32 && y_dtype == WIPA_F32) LN_LAUNCH(float, float);
+    else if (x_dtype == WIPA_F32 && y_dtype == WIPA_BF16) LN_LAUNCH(float, __bf16);
+    else if (x_dtype == WIPA_BF16 && y_dtype == WIPA_BF16) LN_LAUNCH(__bf16, __bf16);
+    else if (x_dtype == WIPA_BF16 && y_dtype == WIPA_F32) LN_LAUNCH(__bf16, float);
+    else WIPA_REQUIRE(false, "wipa_layernorm: bad dtypes %d %d", x_dtype, y_dtype);
+#undef LN_LAUNCH
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+extern "C" int wipa_embed_tokens(const int32_t* tokens, int64_t ld_tok, int B, int T, int t_start, const int32_t* pos_dev,
+                                 const void* tok_emb, int emb_dtype, const float* pos_emb, float* x, int D,
+                                 wipa_stream_t stream) {
+    WIPA_REQUIRE(tokens && tok_emb && pos_emb && x, "wipa_embed_tokens: null pointer");
+    WIPA_REQUIRE(D % 4 == 0, "wipa_embed_tokens: D must be a multiple of 4");
+    if (B * T <= 0) return WIPA_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (emb_dtype == WIPA_F32)
+        hipLaunchKernelGGL((embed_kernel<float>), dim3(B * T), dim3(256), 0, s, tokens, ld_tok, T, t_start, pos_dev,
+                           (const float*)tok_emb, pos_emb, x, D);
+    else if (emb_dtype == WIPA_BF16)
+        hipLaunchKernelGGL((embed_kernel<__bf16>), dim3(B * T), dim3(256), 0, s, tokens, ld_tok, T, t_start, pos_dev,
+                           (const __bf16*)tok_emb, pos_emb, x, D);
+    else
+        WIPA_REQUIRE(false, "wipa_embed_tokens: bad dtype %d", emb_dtype);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+extern "C" int wipa_greedy_step(const float* logits, int64_t ldl, int B, int V, const float* mask_first,
+                                const float* mask_always, int32_t* tokens, int64_t ld_tok, const int32_t* pos_dev,
+                                int n_init, int eot, float* sum_logprobs, int32_t* not_done, wipa_stream_t stream) {
+    WIPA_REQUIRE(logits && mask_first && mask_always && tokens && pos_dev && sum_logprobs && not_done,
+                 "wipa_greedy_step: null pointer");
+    hipLaunchKernelGGL(greedy_step_kernel, dim3(B), dim3(GS_THREADS), 0, (hipStream_t)stream, logits, ldl, V, mask_first,
+                       mask_always, tokens, ld_tok, pos_dev, n_init, eot, sum_logprobs, not_done);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+extern "C" int wipa_add_i32(int32_t* p, int32_t v, wipa_stream_t stream) {
+    WIPA_REQUIRE(p, "wipa_add_i32: null pointer");
+    hipLaunchKernelGGL(add_i32_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, p, v);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+extern "C" int wipa_masked_ce(const float* logits, int64_t ldl, const int32_t* tokens, int64_t ld_tok, int B, int T, int V,
+                              int eot, float* row_buf, float* out2, wipa_stream_t stream) {
+    WIPA_REQUIRE(logits && tokens && row_buf && out2, "wipa_masked_ce: null pointer");
+    const int rows = B * T;
+    if (rows <= 0) return WIPA_OK;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(masked_ce_rows_kernel, dim3(rows), dim3(CE_THREADS), 0, s, logits, ldl, tokens, ld_tok, T, V, eot,
+                       row_buf, rows);
+    hipLaunchKernelGGL(sum2_kernel, dim3(1), dim3(256), 0, s, row_buf, rows, out2);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+extern "C" int wipa_mel_pad_cast(const float* mel, int batch, int n_mels, void* mel_padded, int dtype,
+                                 wipa_stream_t stream) {
+    WIPA_REQUIRE(mel && mel_padded, "wipa_mel_pad_cast: null pointer");
+    const int64_t total = (int64_t)batch * (WIPA_N_FRAMES + 2) * n_mels;
+    if (total <= 0) return WIPA_OK;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == WIPA_F32)
+        hipLaunchKernelGGL((mel_pad_cast_kernel<float>), grid, dim3(256), 0, s, mel, n_mels, (float*)mel_padded, total);
+    else if (dtype == WIPA_BF16)
+        hipLaunchKernelGGL((mel_pad_cast_kernel<__bf16>), grid, dim3(256), 0, s, mel, n_mels, (__bf16*)mel_padded, total);
+    else
+        WIPA_REQUIRE(false, "wipa_mel_pad_cast: bad dtype %d", dtype);
+    WIPA_LAUNCH_CHECK();
+    const size_t esz = wipa_dtype_size(dtype);
+    WIPA_CHECK_HIP(hipMemsetAsync((char*)mel_padded + (size_t)total * esz, 0, 4 * (size_t)n_mels * esz, s));
+    return WIPA_OK;
+}

@@ -1,0 +1,330 @@
+// K4: C = epilogue(A * W^T) on the MFMA units of gfx950.
+//
+// Replaces every nn.Linear / Conv1d of mlx_whisper.whisper on the path
+// (call sites: scripts/train_whisper_ipa.py:223,232; scripts/transcribe_single.py:54-55).
+//
+// Tiling (v1): 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per
+// wave = 4x4 MFMA 16x16 tiles), K-step = 128 BYTES per row (64 bf16 / 32 f32) so both
+// dtypes share one LDS image: [rows][8 x 16-byte chunks], chunk index XOR ((row>>1)&7)
+// -> every ds_read_b128 lane group hits 16 distinct 16-byte slots (conflict free).
+// Operand roles are swapped w.r.t. the textbook (W feeds the MFMA "A" side) so each lane
+// ends up with 4 CONSECUTIVE output columns of one row -> 8/16-byte epilogue stores.
+// f32 inputs use v_mfma_f32_16x16x4_f32 (exact f32 fma chain); a 16-byte fragment feeds
+// four K=4 steps with a consistent K permutation on both operands.
+// Global->register->LDS staging, double buffered, one barrier per K-step; loads for
+// step k+1 are issued before the MFMAs of step k (async-STAGE split).
+#include <mutex>
+
+#include "wipa_common.h"
+
+namespace {
+
+struct GemmParams {
+    const char* A;
+    const char* W;
+    char* C;
+    const float* bias;
+    const char* residual;
+    const float* pos;
+    const int64_t* c_offset_dev;
+    int64_t lda_b, ldw_b;  // bytes
+    int64_t ldc, ldpos;    // elements
+    int64_t rg_stride, cg_stride, c_offset;
+    int M, N, K;
+    int rg_in, rg_valid, cg_in;
+    int zero_invalid, bias_along_m, act, col_scale_n;
+    float col_scale;
+    int tiles_m, tiles_n;
+    int vec_ok;
+};
+
+template <typename T>
+struct Mma;
+template <>
+struct Mma<__bf16> {
+    typedef bf16x8 Frag;
+    static __device__ __forceinline__ void run(const Frag& w, const Frag& x, f32x4& acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, acc, 0, 0, 0);
+    }
+};
+template <>
+struct Mma<float> {
+    typedef f32x4 Frag;
+    static __device__ __forceinline__ void run(const Frag& w, const Frag& x, f32x4& acc) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[e], x[e], acc, 0, 0, 0);
+    }
+};
+
+template <typename OutT>
+__device__ __forceinline__ void store4(char* C, int64_t off, const float (&v)[4], int nvalid, bool vec) {
+    OutT* p = reinterpret_cast<OutT*>(C) + off;
+    if (vec && nvalid == 4) {
+        if constexpr (sizeof(OutT) == 4) {
+            f32x4 o = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(p) = o;
+        } else {
+            bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+            *reinterpret_cast<bf16x4*>(p) = o;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r < nvalid) p[r] = from_f32<OutT>(v[r]);
+    }
+}
+
+template <typename OutT>
+__device__ __forceinline__ void load4(const char* R, int64_t off, float (&v)[4], int nvalid, bool vec) {
+    const OutT* p = reinterpret_cast<const OutT*>(R) + off;
+    if (vec && nvalid == 4) {
+        if constexpr (sizeof(OutT) == 4) {
+            f32x4 o = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = o[r];
+        } else {
+            bf16x4 o = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (float)o[r];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (r < nvalid) ? to_f32<OutT>(p[r]) : 0.f;
+    }
+}
+
+constexpr int BM = 128, BN = 128, ROWB = 128;  // ROWB: bytes of K per LDS row
+constexpr int TILE_BYTES = BM * ROWB;          // 16 KiB per operand tile
+constexpr int GROUP_M = 8;
+
+template <typename T, typename OutT>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][W tile | A tile]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wn = wave >> 1, wm = wave & 1;
+
+    // ---- workgroup -> tile: XCD-contiguous chunks (bijective), then GROUP_M super-rows
+    const int nblocks = p.tiles_m * p.tiles_n;
+    int id;
+    {
+        const int bid = blockIdx.x;
+        const int q = nblocks >> 3, r = nblocks & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int group_size = GROUP_M * p.tiles_n;
+    const int group = id / group_size;
+    const int first_m = group * GROUP_M;
+    const int gm = min(p.tiles_m - first_m, GROUP_M);
+    const int in_group = id - group * group_size;
+    const int tile_m = first_m + in_group % gm;
+    const int tile_n = in_group / gm;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- staging assignment: 4 rows of each operand per thread, one 16-byte chunk each
+    const int srow = tid >> 3, schunk = tid & 7;
+    const char* gA[4];
+    const char* gW[4];
+    int lds_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = srow + 32 * i;
+        const int m = min(m0 + row, p.M - 1);
+        const int n = min(n0 + row, p.N - 1);
+        gA[i] = p.A + (int64_t)m * p.lda_b + schunk * 16;
+        gW[i] = p.W + (int64_t)n * p.ldw_b + schunk * 16;
+        lds_off[i] = row * ROWB + ((schunk ^ ((row >> 1) & 7)) << 4);
+    }
+    f32x4 ra[4], rw[4];
+    auto gload = [&](int kt) {
+        const int64_t kb = (int64_t)kt * ROWB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            rw[i] = *reinterpret_cast<const f32x4*>(gW[i] + kb);
+            ra[i] = *reinterpret_cast<const f32x4*>(gA[i] + kb);
+        }
+    };
+    auto swrite = [&](int buf) {
+        char* base = smem + buf * (2 * TILE_BYTES);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(base + lds_off[i]) = rw[i];
+            *reinterpret_cast<f32x4*>(base + TILE_BYTES + lds_off[i]) = ra[i];
+        }
+    };
+
+    f32x4 acc[4][4];  // [n tile i][m tile j]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15;
+    const int fsw = (lane >> 1) & 7;  // == ((row >> 1) & 7) for row = 16*x + (lane & 15)
+    const int fq = lane >> 4;
+    const int nk = p.K * (int)sizeof(T) / ROWB;
+
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload(kt + 1);
+        const char* wb = smem + (kt & 1) * (2 * TILE_BYTES) + (wn * 64 + frow) * ROWB;
+        const char* ab = smem + (kt & 1) * (2 * TILE_BYTES) + TILE_BYTES + (wm * 64 + frow) * ROWB;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int coff = ((fq + 4 * kk) ^ fsw) << 4;
+            typename Mma<T>::Frag fw[4], fx[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fw[i] = *reinterpret_cast<const typename Mma<T>::Frag*>(wb + i * 16 * ROWB + coff);
+                fx[i] = *reinterpret_cast<const typename Mma<T>::Frag*>(ab + i * 16 * ROWB + coff);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Mma<T>::run(fw[i], fx[j], acc[i][j]);
+        }
+        if (kt + 1 < nk) swrite((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue
+    const bool vec = p.vec_ok != 0;
+    int64_t coff_dev = p.c_offset;
+    if (p.c_offset_dev) coff_dev += *p.c_offset_dev;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 64 + 16 * j + frow;
+        if (m >= p.M) continue;
+        const int gi = m / p.rg_in;
+        const int gr = m - gi * p.rg_in;
+        const bool valid = gr < p.rg_valid;
+        if (!valid && !p.zero_invalid) continue;
+        const int64_t roff = coff_dev + (int64_t)gi * p.rg_stride + (int64_t)gr * p.ldc;
+        const float bm = (p.bias && p.bias_along_m) ? p.bias[m] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + 16 * i + 4 * fq;
+            if (n >= p.N) continue;
+            const int nvalid = min(4, p.N - n);
+            const int cgi = n / p.cg_in;
+            const int cgr = n - cgi * p.cg_in;
+            const int64_t off = roff + (int64_t)cgi * p.cg_stride + cgr;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+            if (p.bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += p.bias_along_m ? bm : (r < nvalid ? p.bias[n + r] : 0.f);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n + r < p.col_scale_n) v[r] *= p.col_scale;
+            if (p.act == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            }
+            if (p.pos) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < nvalid) v[r] += p.pos[(int64_t)gr * p.ldpos + n + r];
+            }
+            if (p.residual) {
+                float rr[4];
+                load4<OutT>(p.residual, off, rr, nvalid, vec);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += rr[r];
+            }
+            if (!valid) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = 0.f;
+            }
+            store4<OutT>(p.C, off, v, nvalid, vec);
+        }
+    }
+}
+
+constexpr int SMEM_BYTES = 4 * TILE_BYTES;  // 64 KiB
+
+// Raise the dynamic-LDS limit of every instantiation once, outside any stream capture.
+int init_attrs() {
+    static std::once_flag once;
+    static hipError_t err = hipSuccess;
+    std::call_once(once, [] {
+        const void* fns[4] = {reinterpret_cast<const void*>(&gemm_nt_kernel<__bf16, __bf16>),
+                              reinterpret_cast<const void*>(&gemm_nt_kernel<__bf16, float>),
+                              reinterpret_cast<const void*>(&gemm_nt_kernel<float, __bf16>),
+                              reinterpret_cast<const void*>(&gemm_nt_kernel<float, float>)};
+        for (const void* f : fns) {
+            const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+            if (e != hipSuccess) err = e;
+        }
+    });
+    WIPA_CHECK_HIP(err);
+    return WIPA_OK;
+}
+
+template <typename T, typename OutT>
+int launch(const GemmParams& p, hipStream_t s) {
+    hipLaunchKernelGGL((gemm_nt_kernel<T, OutT>), dim3(p.tiles_m * p.tiles_n), dim3(256), SMEM_BYTES, s, p);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+}  // namespace
+
+extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
+    WIPA_REQUIRE(d && d->A && d->W && d->C, "wipa_gemm: null operand");
+    WIPA_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "wipa_gemm: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
+    WIPA_REQUIRE(d->in_dtype == WIPA_F32 || d->in_dtype == WIPA_BF16, "wipa_gemm: bad in_dtype %d", d->in_dtype);
+    WIPA_REQUIRE(d->out_dtype == WIPA_F32 || d->out_dtype == WIPA_BF16, "wipa_gemm: bad out_dtype %d", d->out_dtype);
+    const int64_t esz = (int64_t)wipa_dtype_size(d->in_dtype);
+    WIPA_REQUIRE((d->K * esz) % ROWB == 0, "wipa_gemm: K=%d must be a multiple of %d elements", d->K, (int)(ROWB / esz));
+    WIPA_REQUIRE((d->lda * esz) % 16 == 0 && (d->ldw * esz) % 16 == 0, "wipa_gemm: lda/ldw rows must be 16-byte aligned");
+    WIPA_REQUIRE(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->W % 16) == 0, "wipa_gemm: A/W must be 16-byte aligned");
+    GemmParams p;
+    p.A = (const char*)d->A;
+    p.W = (const char*)d->W;
+    p.C = (char*)d->C;
+    p.bias = d->bias;
+    p.residual = (const char*)d->residual;
+    p.pos = d->pos;
+    p.c_offset_dev = d->c_offset_dev;
+    p.lda_b = d->lda * esz;
+    p.ldw_b = d->ldw * esz;
+    p.ldc = d->ldc;
+    p.ldpos = d->ldpos;
+    p.M = d->M;
+    p.N = d->N;
+    p.K = d->K;
+    p.rg_in = d->rg_in > 0 ? d->rg_in : d->M;
+    p.rg_valid = d->rg_in > 0 ? d->rg_valid : d->M;
+    p.rg_stride = d->rg_in > 0 ? d->rg_stride : 0;
+    p.cg_in = d->cg_in > 0 ? d->cg_in : d->N;
+    p.cg_stride = d->cg_in > 0 ? d->cg_stride : 0;
+    p.c_offset = d->c_offset;
+    p.zero_invalid = d->zero_invalid_rows;
+    p.bias_along_m = d->bias_along_m;
+    p.act = d->act;
+    p.col_scale_n = d->col_scale_n;
+    p.col_scale = d->col_scale;
+    p.tiles_m = (d->M + BM - 1) / BM;
+    p.tiles_n = (d->N + BN - 1) / BN;
+    const int64_t osz = (int64_t)wipa_dtype_size(d->out_dtype);
+    const int64_t valign = 16 / osz == 4 ? 4 : 4;  // 4 consecutive outputs per store
+    p.vec_ok = (p.ldc % valign == 0) && (p.rg_stride % valign == 0) && (p.cg_stride % valign == 0) &&
+               (p.cg_in % 4 == 0) && (p.c_offset % valign == 0) && (((uintptr_t)d->C) % 16 == 0) &&
+               (!d->residual || ((uintptr_t)d->residual) % 16 == 0);
+    hipStream_t s = (hipStream_t)stream;
+    {
+        const int rc = init_attrs();
+        if (rc != WIPA_OK) return rc;
+    }
+    if (d->in_dtype == WIPA_BF16) {
+        return d->out_dtype == WIPA_BF16 ? launch<__bf16, __bf16>(p, s) : launch<__bf16, float>(p, s);
+    }
+    return d->out_dtype == WIPA_BF16 ? launch<float, __bf16>(p, s) : launch<float, float>(p, s);
+}

@@ -1,0 +1,502 @@
+// Model runtime: sequences the kernels of libwipa for a whole encoder pass, the cross-KV
+// projection, the KV-cached greedy decode loop (replayed from a hipGraph: every per-step
+// quantity -- token position, KV write offset, visible keys -- lives in device memory, so
+// one captured step is valid for all steps) and the teacher-forced decoder.
+//
+// Replaces mlx_whisper.whisper.{AudioEncoder,TextDecoder}.__call__ and
+// mlx_whisper.decoding.DecodingTask._main_loop (call sites scripts/train_whisper_ipa.py:223,232,356;
+// scripts/transcribe_single.py:54-55; scripts/evaluate_model.py:197-200).
+#include <cstdarg>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <tuple>
+
+#include "wipa_common.h"
+
+// ------------------------------------------------------------------ errors / version
+static thread_local char g_err[512] = "";
+void wipa_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* wipa_last_error(void) { return g_err; }
+extern "C" int wipa_version(void) { return 100; }
+
+namespace {
+
+constexpr float QK_SCALE = 0.35355339059327379f;  // 64 ** -0.25
+constexpr int T_ENC_PAD = 1536;                     // V^T row length (>= ceil64(1500))
+constexpr int ROWS_IN = WIPA_N_FRAMES + 2;          // 3002 padded frames per clip
+
+inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+inline int k_multiple(int dtype) { return dtype == WIPA_BF16 ? 64 : 32; }
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+#define RT_CALL(expr)                 \
+    do {                              \
+        int _rc = (expr);             \
+        if (_rc != WIPA_OK) return _rc; \
+    } while (0)
+
+int cfg_check(const wipa_model_cfg* c) {
+    WIPA_REQUIRE(c, "null cfg");
+    WIPA_REQUIRE(c->dtype == WIPA_F32 || c->dtype == WIPA_BF16, "cfg.dtype %d", c->dtype);
+    WIPA_REQUIRE(c->n_audio_state == c->n_audio_head * WIPA_HEAD_DIM && c->n_text_state == c->n_text_head * WIPA_HEAD_DIM,
+                 "head_dim must be 64 (state %d heads %d)", c->n_audio_state, c->n_audio_head);
+    WIPA_REQUIRE(c->n_audio_ctx == WIPA_N_FRAMES / 2, "n_audio_ctx must be 1500");
+    WIPA_REQUIRE(c->n_audio_state % 64 == 0 && c->n_text_state % 64 == 0, "state must be a multiple of 64");
+    return WIPA_OK;
+}
+
+int gemm(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int M, int N, int K, int in_dt,
+         int out_dt, const float* bias, int act, const void* residual, wipa_stream_t s, wipa_gemm_desc* extra = nullptr) {
+    wipa_gemm_desc g;
+    if (extra) g = *extra; else memset(&g, 0, sizeof(g));
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc;
+    g.M = M; g.N = N; g.K = K; g.in_dtype = in_dt; g.out_dtype = out_dt;
+    g.bias = bias; g.act = act; g.residual = residual;
+    return wipa_gemm(&g, s);
+}
+
+// ------------------------------------------------------------------ encoder
+struct EncWs {
+    size_t c1, x, ln, qk, v, ao, h, total;
+};
+EncWs enc_ws(const wipa_model_cfg* c, int B) {
+    const size_t e = wipa_dtype_size(c->dtype), d = c->n_audio_state, M = (size_t)B * c->n_audio_ctx;
+    EncWs w;
+    size_t o = 0;
+    w.c1 = o; o += align256(((size_t)B * ROWS_IN + 4) * d * e);
+    w.x = o;  o += align256(M * d * 4);
+    w.ln = o; o += align256(M * d * e);
+    w.qk = o; o += align256(M * 2 * d * e);
+    w.v = o;  o += align256(c->dtype == WIPA_BF16 ? (size_t)B * d * T_ENC_PAD * e + 256 : M * d * e);
+    w.ao = o; o += align256(M * d * e);
+    w.h = o;  o += align256(M * 4 * d * e);
+    w.total = o;
+    return w;
+}
+
+}  // namespace
+
+extern "C" size_t wipa_encoder_workspace_bytes(const wipa_model_cfg* cfg, int B) {
+    if (!cfg || B <= 0) return 0;
+    return enc_ws(cfg, B).total;
+}
+
+extern "C" int wipa_encoder_forward(const wipa_model_cfg* cfg, const void* const* w, const void* mel_padded, void* out,
+                                    void* workspace, size_t workspace_bytes, int B, wipa_stream_t stream) {
+    RT_CALL(cfg_check(cfg));
+    WIPA_REQUIRE(w && mel_padded && out && workspace && B > 0, "wipa_encoder_forward: null pointer / bad batch");
+    const EncWs L = enc_ws(cfg, B);
+    WIPA_REQUIRE(workspace_bytes >= L.total, "wipa_encoder_forward: workspace too small (%zu < %zu)", workspace_bytes, L.total);
+    hipStream_t s = (hipStream_t)stream;
+    const int dt = cfg->dtype;
+    const size_t e = wipa_dtype_size(dt);
+    const int d = cfg->n_audio_state, H = cfg->n_audio_head, T = cfg->n_audio_ctx, M = B * T;
+    char* ws = (char*)workspace;
+    void* c1 = ws + L.c1;
+    float* x = (float*)(ws + L.x);
+    void* ln = ws + L.ln;
+    void* qk = ws + L.qk;
+    void* vb = ws + L.v;
+    void* ao = ws + L.ao;
+    void* hb = ws + L.h;
+    const int K1 = round_up(3 * cfg->n_mels, k_multiple(dt));
+
+    // conv1 (k3,p1) + GELU as a GEMM with overlapping rows; output row g lands at c1 row g+1,
+    // dead rows (t >= 3000) write the zero halos of conv2.
+    WIPA_CHECK_HIP(hipMemsetAsync(c1, 0, (size_t)d * e, s));
+    {
+        wipa_gemm_desc g;
+        memset(&g, 0, sizeof(g));
+        g.rg_in = ROWS_IN; g.rg_valid = WIPA_N_FRAMES; g.rg_stride = (int64_t)ROWS_IN * d; g.zero_invalid_rows = 1;
+        g.c_offset = d;
+        RT_CALL(gemm(mel_padded, cfg->n_mels, w[0], K1, c1, d, B * ROWS_IN, d, K1, dt, dt, (const float*)w[1], 1, nullptr,
+                     stream, &g));
+    }
+    // conv2 (k3,s2,p1) + GELU + positional embedding -> residual stream x (f32)
+    {
+        wipa_gemm_desc g;
+        memset(&g, 0, sizeof(g));
+        g.rg_in = T + 1; g.rg_valid = T; g.rg_stride = (int64_t)T * d;
+        g.pos = (const float*)w[4]; g.ldpos = d;
+        RT_CALL(gemm(c1, 2 * d, w[2], 3 * d, x, d, B * (T + 1), d, 3 * d, dt, WIPA_F32, (const float*)w[3], 1, nullptr,
+                     stream, &g));
+    }
+    if (dt == WIPA_BF16) WIPA_CHECK_HIP(hipMemsetAsync(vb, 0, (size_t)B * d * T_ENC_PAD * e, s));
+    for (int l = 0; l < cfg->n_audio_layer; ++l) {
+        const void* const* lw = w + WIPA_ENC_GLOBAL + WIPA_ENC_PER_LAYER * l;
+        RT_CALL(wipa_layernorm(x, WIPA_F32, d, ln, dt, d, (const float*)lw[0], (const float*)lw[1], M, d, 1e-5f, stream));
+        {
+            wipa_gemm_desc g;
+            memset(&g, 0, sizeof(g));
+            g.col_scale_n = 2 * d; g.col_scale = QK_SCALE;
+            RT_CALL(gemm(ln, d, lw[2], d, qk, 2 * d, M, 2 * d, d, dt, dt, (const float*)lw[3], 0, nullptr, stream, &g));
+        }
+        if (dt == WIPA_BF16) {
+            // V^T per clip: swap the operand roles so the GEMM writes [d][t] directly
+            wipa_gemm_desc g;
+            memset(&g, 0, sizeof(g));
+            g.bias_along_m = 1; g.cg_in = T; g.cg_stride = (int64_t)d * T_ENC_PAD;
+            RT_CALL(gemm(lw[4], d, ln, d, vb, T_ENC_PAD, d, M, d, dt, dt, (const float*)lw[5], 0, nullptr, stream, &g));
+            RT_CALL(wipa_flash_attn_enc_bf16(qk, 2 * d, vb, T_ENC_PAD, ao, d, B, H, T, stream));
+        } else {
+            RT_CALL(gemm(ln, d, lw[4], d, vb, d, M, d, d, dt, dt, (const float*)lw[5], 0, nullptr, stream));
+            wipa_attn_desc a;
+            memset(&a, 0, sizeof(a));
+            a.q = qk; a.k = (const char*)qk + (size_t)d * e; a.v = vb; a.out = ao;
+            a.q_bs = (int64_t)T * 2 * d; a.q_rs = 2 * d; a.q_hs = 64;
+            a.k_bs = a.q_bs; a.k_rs = 2 * d; a.k_hs = 64;
+            a.v_bs = (int64_t)T * d; a.v_rs = d; a.v_hs = 64;
+            a.o_bs = (int64_t)T * d; a.o_rs = d; a.o_hs = 64;
+            a.B = B; a.H = H; a.Tq = T; a.Tk = T; a.causal = 0; a.dtype = dt;
+            RT_CALL(wipa_attention(&a, stream));
+        }
+        RT_CALL(gemm(ao, d, lw[6], d, x, d, M, d, d, dt, WIPA_F32, (const float*)lw[7], 0, x, stream));
+        RT_CALL(wipa_layernorm(x, WIPA_F32, d, ln, dt, d, (const float*)lw[8], (const float*)lw[9], M, d, 1e-5f, stream));
+        RT_CALL(gemm(ln, d, lw[10], d, hb, 4 * d, M, 4 * d, d, dt, dt, (const float*)lw[11], 1, nullptr, stream));
+        RT_CALL(gemm(hb, 4 * d, lw[12], 4 * d, x, d, M, d, 4 * d, dt, WIPA_F32, (const float*)lw[13], 0, x, stream));
+    }
+    RT_CALL(wipa_layernorm(x, WIPA_F32, d, out, dt, d, (const float*)w[5], (const float*)w[6], M, d, 1e-5f, stream));
+    return WIPA_OK;
+}
+
+// ------------------------------------------------------------------ decoder state
+namespace {
+
+struct DecScratch {
+    size_t x, ln, q, ao, h, posd, total;
+};
+DecScratch dec_scratch(const wipa_model_cfg* c, int B) {
+    const size_t e = wipa_dtype_size(c->dtype), d = c->n_text_state;
+    DecScratch s;
+    size_t o = 0;
+    s.x = o;    o += align256((size_t)B * d * 4);
+    s.ln = o;   o += align256((size_t)B * d * e);
+    s.q = o;    o += align256((size_t)B * d * e);
+    s.ao = o;   o += align256((size_t)B * d * e);
+    s.h = o;    o += align256((size_t)B * 4 * d * e);
+    s.posd = o; o += 256;
+    s.total = o;
+    return s;
+}
+
+wipa_dec_layout dec_layout(const wipa_model_cfg* c, int B) {
+    const size_t e = wipa_dtype_size(c->dtype);
+    const size_t d = c->n_text_state, H = c->n_text_head;
+    wipa_dec_layout L;
+    size_t o = 0;
+    L.ld_tok = c->n_text_ctx + 8;
+    L.tokens = o; o += align256((size_t)B * L.ld_tok * 4);
+    L.pos = o; o += 256;
+    L.not_done = o; o += 256;
+    L.sum_logprobs = o; o += align256((size_t)B * 4);
+    L.ld_logits = round_up(c->n_vocab, 8);
+    L.logits = o; o += align256((size_t)B * L.ld_logits * 4);
+    L.cross_kv = o; o += align256((size_t)c->n_text_layer * B * 2 * H * c->n_audio_ctx * 64 * e);
+    L.self_kv = o; o += align256((size_t)c->n_text_layer * 3 * B * c->n_text_ctx * d * e);
+    L.scratch = o; o += dec_scratch(c, B).total;
+    L.total_bytes = o;
+    return L;
+}
+
+__global__ void advance_pos_kernel(int32_t* pos, int64_t* posd, int d) {
+    const int p = *pos + 1;
+    *pos = p;
+    *posd = (int64_t)p * d;
+}
+
+__global__ void fill_tokens_kernel(int32_t* tokens, int64_t ld_tok, int B, int n_init, int i0, int i1, int i2, int i3,
+                                   const int32_t* extra) {
+    // rows get the prompt; prompts longer than 4 come through `extra` (device copy)
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int first4[4] = {i0, i1, i2, i3};
+    for (int t = 0; t < n_init; ++t) tokens[(int64_t)b * ld_tok + t] = (t < 4 || !extra) ? first4[t & 3] : extra[t];
+}
+
+// one decoder step (all layers + logits + greedy update + position advance)
+int enqueue_step(const wipa_model_cfg* cfg, const void* const* w, char* st, const wipa_dec_layout& L, int B, int n_init,
+                 int eot, const float* mask_first, const float* mask_always, wipa_stream_t stream) {
+    const int dt = cfg->dtype;
+    const size_t e = wipa_dtype_size(dt);
+    const int d = cfg->n_text_state, H = cfg->n_text_head, nctx = cfg->n_text_ctx, Ta = cfg->n_audio_ctx;
+    const DecScratch S = dec_scratch(cfg, B);
+    char* sc = st + L.scratch;
+    float* x = (float*)(sc + S.x);
+    void* ln = sc + S.ln;
+    void* q = sc + S.q;
+    void* ao = sc + S.ao;
+    void* hb = sc + S.h;
+    int64_t* posd = (int64_t*)(sc + S.posd);
+    int32_t* tokens = (int32_t*)(st + L.tokens);
+    int32_t* pos = (int32_t*)(st + L.pos);
+    RT_CALL(wipa_embed_tokens(tokens, L.ld_tok, B, 1, 0, pos, w[0], dt, (const float*)w[1], x, d, stream));
+    for (int l = 0; l < cfg->n_text_layer; ++l) {
+        const void* const* lw = w + WIPA_DEC_GLOBAL + WIPA_DEC_PER_LAYER * l;
+        char* skv = st + L.self_kv + (size_t)l * 3 * B * nctx * d * e;  // [3][B][nctx][d]
+        char* ckv = st + L.cross_kv + (size_t)l * B * 2 * H * Ta * 64 * e;
+        RT_CALL(wipa_layernorm(x, WIPA_F32, d, ln, dt, d, (const float*)lw[0], (const float*)lw[1], B, d, 1e-5f, stream));
+        {
+            // q|k|v of this position -> slot[n / d][b][pos][n % d]
+            wipa_gemm_desc g;
+            memset(&g, 0, sizeof(g));
+            g.col_scale_n = 2 * d; g.col_scale = QK_SCALE;
+            g.rg_in = 1; g.rg_valid = 1; g.rg_stride = (int64_t)nctx * d;
+            g.cg_in = d; g.cg_stride = (int64_t)B * nctx * d;
+            g.c_offset_dev = posd;
+            RT_CALL(gemm(ln, d, lw[2], d, skv, d, B, 3 * d, d, dt, dt, (const float*)lw[3], 0, nullptr, stream, &g));
+        }
+        {
+            wipa_attn_desc a;
+            memset(&a, 0, sizeof(a));
+            const size_t slot = (size_t)B * nctx * d * e;
+            a.q = skv; a.k = skv + slot; a.v = skv + 2 * slot; a.out = ao;
+            a.q_row_dev = pos; a.tk_dev = pos;
+            a.q_bs = (int64_t)nctx * d; a.q_rs = d; a.q_hs = 64;
+            a.k_bs = a.q_bs; a.k_rs = d; a.k_hs = 64;
+            a.v_bs = a.q_bs; a.v_rs = d; a.v_hs = 64;
+            a.o_bs = d; a.o_rs = d; a.o_hs = 64;
+            a.B = B; a.H = H; a.Tq = 1; a.Tk = 1; a.causal = 0; a.dtype = dt;
+            RT_CALL(wipa_attention(&a, stream));
+        }
+        RT_CALL(gemm(ao, d, lw[4], d, x, d, B, d, d, dt, WIPA_F32, (const float*)lw[5], 0, x, stream));
+        RT_CALL(wipa_layernorm(x, WIPA_F32, d, ln, dt, d, (const float*)lw[6], (const float*)lw[7], B, d, 1e-5f, stream));
+        {
+            wipa_gemm_desc g;
+            memset(&g, 0, sizeof(g));
+            g.col_scale_n = d; g.col_scale = QK_SCALE;
+            RT_CALL(gemm(ln, d, lw[8], d, q, d, B, d, d, dt, dt, (const float*)lw[9], 0, nullptr, stream, &g));
+        }
+        RT_CALL(wipa_decode_cross_attn(q, ckv, ao, B, H, Ta, dt, stream));
+        RT_CALL(gemm(ao, d, lw[12], d, x, d, B, d, d, dt, WIPA_F32, (const float*)lw[13], 0, x, stream));
+        RT_CALL(wipa_layernorm(x, WIPA_F32, d, ln, dt, d, (const float*)lw[14], (const float*)lw[15], B, d, 1e-5f, stream));
+        RT_CALL(gemm(ln, d, lw[16], d, hb, 4 * d, B, 4 * d, d, dt, dt, (const float*)lw[17], 1, nullptr, stream));
+        RT_CALL(gemm(hb, 4 * d, lw[18], 4 * d, x, d, B, d, 4 * d, dt, WIPA_F32, (const float*)lw[19], 0, x, stream));
+    }
+    RT_CALL(wipa_layernorm(x, WIPA_F32, d, ln, dt, d, (const float*)w[2], (const float*)w[3], B, d, 1e-5f, stream));
+    float* logits = (float*)(st + L.logits);
+    RT_CALL(gemm(ln, d, w[0], d, logits, L.ld_logits, B, cfg->n_vocab, d, dt, WIPA_F32, nullptr, 0, nullptr, stream));
+    RT_CALL(wipa_greedy_step(logits, L.ld_logits, B, cfg->n_vocab, mask_first, mask_always, tokens, L.ld_tok, pos, n_init,
+                             eot, (float*)(st + L.sum_logprobs), (int32_t*)(st + L.not_done), stream));
+    hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, pos, posd, d);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+// graph cache: one captured step per (state blob, weights, masks, shape)
+typedef std::tuple<const void*, const void*, const void*, const void*, int, int, int, int> GraphKey;
+std::mutex g_graph_mu;
+std::map<GraphKey, hipGraphExec_t> g_graphs;
+
+}  // namespace
+
+extern "C" int wipa_decoder_layout(const wipa_model_cfg* cfg, int B, wipa_dec_layout* out) {
+    RT_CALL(cfg_check(cfg));
+    WIPA_REQUIRE(out && B > 0, "wipa_decoder_layout: bad arguments");
+    *out = dec_layout(cfg, B);
+    return WIPA_OK;
+}
+
+extern "C" int wipa_decoder_set_audio(const wipa_model_cfg* cfg, const void* const* w, const void* features, void* state,
+                                      int B, wipa_stream_t stream) {
+    RT_CALL(cfg_check(cfg));
+    WIPA_REQUIRE(w && features && state && B > 0, "wipa_decoder_set_audio: null pointer / bad batch");
+    const wipa_dec_layout L = dec_layout(cfg, B);
+    const int dt = cfg->dtype;
+    const size_t e = wipa_dtype_size(dt);
+    const int d = cfg->n_text_state, H = cfg->n_text_head, Ta = cfg->n_audio_ctx;
+    WIPA_REQUIRE(cfg->n_audio_state == d, "encoder/decoder widths differ");
+    for (int l = 0; l < cfg->n_text_layer; ++l) {
+        const void* const* lw = w + WIPA_DEC_GLOBAL + WIPA_DEC_PER_LAYER * l;
+        char* ckv = (char*)state + L.cross_kv + (size_t)l * B * 2 * H * Ta * 64 * e;
+        wipa_gemm_desc g;
+        memset(&g, 0, sizeof(g));
+        g.col_scale_n = d; g.col_scale = QK_SCALE;  // the key half; values stay unscaled
+        g.rg_in = Ta; g.rg_valid = Ta; g.rg_stride = (int64_t)2 * H * Ta * 64;
+        g.cg_in = 64; g.cg_stride = (int64_t)Ta * 64;
+        RT_CALL(gemm(features, d, lw[10], d, ckv, 64, B * Ta, 2 * d, d, dt, dt, (const float*)lw[11], 0, nullptr, stream, &g));
+    }
+    return WIPA_OK;
+}
+
+extern "C" int wipa_decoder_begin(const wipa_model_cfg* cfg, void* state, int B, const int32_t* initial_tokens_host,
+                                  int n_init, wipa_stream_t stream) {
+    RT_CALL(cfg_check(cfg));
+    WIPA_REQUIRE(state && initial_tokens_host && n_init >= 1 && n_init <= 4 && B > 0,
+                 "wipa_decoder_begin: need 1..4 prompt tokens (got %d)", n_init);
+    const wipa_dec_layout L = dec_layout(cfg, B);
+    hipStream_t s = (hipStream_t)stream;
+    char* st = (char*)state;
+    const DecScratch S = dec_scratch(cfg, B);
+    WIPA_CHECK_HIP(hipMemsetAsync(st + L.tokens, 0, (size_t)B * L.ld_tok * 4, s));
+    WIPA_CHECK_HIP(hipMemsetAsync(st + L.pos, 0, 512, s));  // pos and not_done
+    WIPA_CHECK_HIP(hipMemsetAsync(st + L.sum_logprobs, 0, (size_t)B * 4, s));
+    WIPA_CHECK_HIP(hipMemsetAsync(st + L.scratch + S.posd, 0, 8, s));
+    int t4[4] = {0, 0, 0, 0};
+    for (int i = 0; i < n_init; ++i) t4[i] = initial_tokens_host[i];
+    hipLaunchKernelGGL(fill_tokens_kernel, dim3((B + 63) / 64), dim3(64), 0, s, (int32_t*)(st + L.tokens), L.ld_tok, B, n_init,
+                       t4[0], t4[1], t4[2], t4[3], (const int32_t*)nullptr);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+extern "C" int wipa_decoder_run(const wipa_model_cfg* cfg, const void* const* w, void* state, int B, int n_init, int eot,
+                                const float* mask_first, const float* mask_always, int n_steps, int use_graph,
+                                wipa_stream_t stream) {
+    RT_CALL(cfg_check(cfg));
+    WIPA_REQUIRE(w && state && mask_first && mask_always && B > 0 && n_steps >= 0, "wipa_decoder_run: bad arguments");
+    const wipa_dec_layout L = dec_layout(cfg, B);
+    char* st = (char*)state;
+    hipStream_t s = (hipStream_t)stream;
+    if (!use_graph) {
+        for (int i = 0; i < n_steps; ++i)
+            RT_CALL(enqueue_step(cfg, w, st, L, B, n_init, eot, mask_first, mask_always, stream));
+        return WIPA_OK;
+    }
+    WIPA_REQUIRE(s != nullptr, "wipa_decoder_run: graph capture needs a non-default stream");
+    hipGraphExec_t exec = nullptr;
+    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype);
+    {
+        std::lock_guard<std::mutex> lk(g_graph_mu);
+        auto it = g_graphs.find(key);
+        if (it != g_graphs.end()) exec = it->second;
+    }
+    if (!exec) {
+        hipGraph_t graph = nullptr;
+        WIPA_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+        const int rc = enqueue_step(cfg, w, st, L, B, n_init, eot, mask_first, mask_always, stream);
+        const hipError_t ee = hipStreamEndCapture(s, &graph);
+        if (rc != WIPA_OK) {
+            if (graph) hipGraphDestroy(graph);
+            return rc;
+        }
+        WIPA_CHECK_HIP(ee);
+        WIPA_CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        WIPA_CHECK_HIP(hipGraphDestroy(graph));
+        std::lock_guard<std::mutex> lk(g_graph_mu);
+        g_graphs[key] = exec;
+    }
+    for (int i = 0; i < n_steps; ++i) WIPA_CHECK_HIP(hipGraphLaunch(exec, s));
+    return WIPA_OK;
+}
+
+extern "C" int wipa_decoder_release(void* state) {
+    std::lock_guard<std::mutex> lk(g_graph_mu);
+    for (auto it = g_graphs.begin(); it != g_graphs.end();) {
+        if (std::get<0>(it->first) == state) {
+            hipGraphExecDestroy(it->second);
+            it = g_graphs.erase(it);
+        } else {
+            ++it;
+        }
+    }
+    return WIPA_OK;
+}
+
+// ------------------------------------------------------------------ teacher-forced decoder
+namespace {
+struct TfWs {
+    size_t x, ln, qkv, q, ao, h, ckv, total;
+};
+TfWs tf_ws(const wipa_model_cfg* c, int B, int T) {
+    const size_t e = wipa_dtype_size(c->dtype), d = c->n_text_state, M = (size_t)B * T;
+    TfWs w;
+    size_t o = 0;
+    w.x = o;   o += align256(M * d * 4);
+    w.ln = o;  o += align256(M * d * e);
+    w.qkv = o; o += align256(M * 3 * d * e);
+    w.q = o;   o += align256(M * d * e);
+    w.ao = o;  o += align256(M * d * e);
+    w.h = o;   o += align256(M * 4 * d * e);
+    w.ckv = o; o += align256((size_t)B * 2 * c->n_text_head * c->n_audio_ctx * 64 * e);
+    w.total = o;
+    return w;
+}
+}  // namespace
+
+extern "C" size_t wipa_decoder_logits_workspace_bytes(const wipa_model_cfg* cfg, int B, int T) {
+    if (!cfg || B <= 0 || T <= 0) return 0;
+    return tf_ws(cfg, B, T).total;
+}
+
+extern "C" int wipa_decoder_logits(const wipa_model_cfg* cfg, const void* const* w, const int32_t* tokens, const void* features,
+                                   float* logits, int64_t ld_logits, void* workspace, size_t workspace_bytes, int B, int T,
+                                   wipa_stream_t stream) {
+    RT_CALL(cfg_check(cfg));
+    WIPA_REQUIRE(w && tokens && features && logits && workspace && B > 0 && T > 0, "wipa_decoder_logits: bad arguments");
+    WIPA_REQUIRE(T <= cfg->n_text_ctx, "wipa_decoder_logits: T=%d exceeds n_text_ctx=%d", T, cfg->n_text_ctx);
+    const TfWs L = tf_ws(cfg, B, T);
+    WIPA_REQUIRE(workspace_bytes >= L.total, "wipa_decoder_logits: workspace too small (%zu < %zu)", workspace_bytes, L.total);
+    const int dt = cfg->dtype;
+    const size_t e = wipa_dtype_size(dt);
+    const int d = cfg->n_text_state, H = cfg->n_text_head, Ta = cfg->n_audio_ctx, M = B * T;
+    char* ws = (char*)workspace;
+    float* x = (float*)(ws + L.x);
+    void* ln = ws + L.ln;
+    char* qkv = ws + L.qkv;
+    void* q = ws + L.q;
+    void* ao = ws + L.ao;
+    void* hb = ws + L.h;
+    char* ckv = ws + L.ckv;
+    RT_CALL(wipa_embed_tokens(tokens, T, B, T, 0, nullptr, w[0], dt, (const float*)w[1], x, d, stream));
+    for (int l = 0; l < cfg->n_text_layer; ++l) {
+        const void* const* lw = w + WIPA_DEC_GLOBAL + WIPA_DEC_PER_LAYER * l;
+        RT_CALL(wipa_layernorm(x, WIPA_F32, d, ln, dt, d, (const float*)lw[0], (const float*)lw[1], M, d, 1e-5f, stream));
+        {
+            wipa_gemm_desc g;
+            memset(&g, 0, sizeof(g));
+            g.col_scale_n = 2 * d; g.col_scale = QK_SCALE;
+            RT_CALL(gemm(ln, d, lw[2], d, qkv, 3 * d, M, 3 * d, d, dt, dt, (const float*)lw[3], 0, nullptr, stream, &g));
+        }
+        {
+            wipa_attn_desc a;
+            memset(&a, 0, sizeof(a));
+            a.q = qkv; a.k = qkv + (size_t)d * e; a.v = qkv + 2 * (size_t)d * e; a.out = ao;
+            a.q_bs = (int64_t)T * 3 * d; a.q_rs = 3 * d; a.q_hs = 64;
+            a.k_bs = a.q_bs; a.k_rs = 3 * d; a.k_hs = 64;
+            a.v_bs = a.q_bs; a.v_rs = 3 * d; a.v_hs = 64;
+            a.o_bs = (int64_t)T * d; a.o_rs = d; a.o_hs = 64;
+            a.B = B; a.H = H; a.Tq = T; a.Tk = T; a.causal = 1; a.dtype = dt;
+            RT_CALL(wipa_attention(&a, stream));
+        }
+        RT_CALL(gemm(ao, d, lw[4], d, x, d, M, d, d, dt, WIPA_F32, (const float*)lw[5], 0, x, stream));
+        RT_CALL(wipa_layernorm(x, WIPA_F32, d, ln, dt, d, (const float*)lw[6], (const float*)lw[7], M, d, 1e-5f, stream));
+        {
+            wipa_gemm_desc g;
+            memset(&g, 0, sizeof(g));
+            g.col_scale_n = d; g.col_scale = QK_SCALE;
+            RT_CALL(gemm(ln, d, lw[8], d, q, d, M, d, d, dt, dt, (const float*)lw[9], 0, nullptr, stream, &g));
+        }
+        {
+            wipa_gemm_desc g;
+            memset(&g, 0, sizeof(g));
+            g.col_scale_n = d; g.col_scale = QK_SCALE;
+            g.rg_in = Ta; g.rg_valid = Ta; g.rg_stride = (int64_t)2 * H * Ta * 64;
+            g.cg_in = 64; g.cg_stride = (int64_t)Ta * 64;
+            RT_CALL(gemm(features, d, lw[10], d, ckv, 64, B * Ta, 2 * d, d, dt, dt, (const float*)lw[11], 0, nullptr, stream, &g));
+        }
+        {
+            wipa_attn_desc a;
+            memset(&a, 0, sizeof(a));
+            a.q = q; a.k = ckv; a.v = ckv + (size_t)H * Ta * 64 * e; a.out = ao;
+            a.q_bs = (int64_t)T * d; a.q_rs = d; a.q_hs = 64;
+            a.k_bs = (int64_t)2 * H * Ta * 64; a.k_rs = 64; a.k_hs = (int64_t)Ta * 64;
+            a.v_bs = a.k_bs; a.v_rs = 64; a.v_hs = a.k_hs;
+            a.o_bs = (int64_t)T * d; a.o_rs = d; a.o_hs = 64;
+            a.B = B; a.H = H; a.Tq = T; a.Tk = Ta; a.causal = 0; a.dtype = dt;
+            RT_CALL(wipa_attention(&a, stream));
+        }
+        RT_CALL(gemm(ao, d, lw[12], d, x, d, M, d, d, dt, WIPA_F32, (const float*)lw[13], 0, x, stream));
+        RT_CALL(wipa_layernorm(x, WIPA_F32, d, ln, dt, d, (const float*)lw[14], (const float*)lw[15], M, d, 1e-5f, stream));
+        RT_CALL(gemm(ln, d, lw[16], d, hb, 4 * d, M, 4 * d, d, dt, dt, (const float*)lw[17], 1, nullptr, stream));
+        RT_CALL(gemm(hb, 4 * d, lw[18], 4 * d, x, d, M, d, 4 * d, dt, WIPA_F32, (const float*)lw[19], 0, x, stream));
+    }
+    RT_CALL(wipa_layernorm(x, WIPA_F32, d, ln, dt, d, (const float*)w[2], (const float*)w[3], M, d, 1e-5f, stream));
+    RT_CALL(gemm(ln, d, w[0], d, logits, ld_logits, M, cfg->n_vocab, d, dt, WIPA_F32, nullptr, 0, nullptr, stream));
+    return WIPA_OK;
+}

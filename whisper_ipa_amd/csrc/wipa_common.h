@@ -1,0 +1,95 @@
+// Shared device/host helpers for libwipa (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "wipa.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define WIPA_WAVE 64
+
+// ---- error plumbing (never throw across the C ABI) -------------------------
+void wipa_set_error(const char* fmt, ...);
+
+#define WIPA_CHECK_HIP(expr)                                                        \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess) {                                                     \
+            wipa_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return WIPA_ERR_HIP;                                                    \
+        }                                                                           \
+    } while (0)
+
+#define WIPA_REQUIRE(cond, ...)                \
+    do {                                       \
+        if (!(cond)) {                         \
+            wipa_set_error(__VA_ARGS__);       \
+            return WIPA_ERR_ARG;               \
+        }                                      \
+    } while (0)
+
+#define WIPA_LAUNCH_CHECK()                                                          \
+    do {                                                                             \
+        hipError_t _e = hipGetLastError();                                           \
+        if (_e != hipSuccess) {                                                      \
+            wipa_set_error("%s:%d launch -> %s", __FILE__, __LINE__, hipGetErrorString(_e)); \
+            return WIPA_ERR_HIP;                                                     \
+        }                                                                            \
+    } while (0)
+
+static inline size_t wipa_dtype_size(int dt) { return dt == WIPA_BF16 ? 2 : 4; }
+
+// ---- device helpers --------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ float wipa_bf16_to_f32(unsigned short h) {
+    return __uint_as_float(((unsigned int)h) << 16);
+}
+
+template <typename T>
+__device__ __forceinline__ float to_f32(T v);
+template <>
+__device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ float to_f32<__bf16>(__bf16 v) { return (float)v; }
+
+template <typename T>
+__device__ __forceinline__ T from_f32(float v);
+template <>
+__device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
+
+// 16-byte vector of T, unpacked to floats.  EPL = elements per 16-byte lane load.
+template <typename T>
+struct Vec16;
+template <>
+struct Vec16<float> {
+    static constexpr int EPL = 4;
+    f32x4 v;
+    __device__ __forceinline__ float get(int i) const { return v[i]; }
+};
+template <>
+struct Vec16<__bf16> {
+    static constexpr int EPL = 8;
+    bf16x8 v;
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+};
+
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_reduce_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+#endif

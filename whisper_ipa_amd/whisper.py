@@ -1,0 +1,316 @@
+"""``Whisper`` with the call surface of ``mlx_whisper.whisper.Whisper`` that the reference's
+scripts rely on: ``.dims``, ``.encoder(mel)`` / ``embed_audio``,
+``.logits(tokens, features)``, ``.decode``, ``set_dtype``, ``parameters`` / ``update`` in
+mlx_whisper's flat dotted key names (train_whisper_ipa.py:43-57,421; transcribe_single.py:18-33).
+
+All arithmetic runs in libwipa.so; this class owns the weight tensors, packs them into the
+tables the C++ runtime expects (fused query|key, key|value ... matrices) and owns workspaces.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, asdict
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+from .audio import N_FRAMES, PADDED_FRAMES, padded_mel_rows
+from .runtime import device, dt_code, on_stream, ptr, ptr_table, sptr
+
+
+@dataclass
+class ModelDimensions:
+    n_mels: int
+    n_audio_ctx: int
+    n_audio_state: int
+    n_audio_head: int
+    n_audio_layer: int
+    n_vocab: int
+    n_text_ctx: int
+    n_text_state: int
+    n_text_head: int
+    n_text_layer: int
+
+
+def sinusoids(length: int, channels: int, max_timescale: float = 10000.0) -> torch.Tensor:
+    """Positional table of AudioEncoder (computed on the host once, f32)."""
+    log_inc = math.log(max_timescale) / (channels // 2 - 1)
+    inv = torch.exp(-log_inc * torch.arange(channels // 2, dtype=torch.float32))
+    t = torch.arange(length, dtype=torch.float32)[:, None] * inv[None, :]
+    return torch.cat([torch.sin(t), torch.cos(t)], dim=1)
+
+
+def _is_matrix(name: str, t: torch.Tensor) -> bool:
+    return t.dim() >= 2 and not name.endswith("positional_embedding")
+
+
+def parameter_names(dims: ModelDimensions) -> List[str]:
+    names = ["encoder.conv1.weight", "encoder.conv1.bias", "encoder.conv2.weight", "encoder.conv2.bias"]
+
+    def block(p, cross):
+        out = []
+        for a in ["attn"] + (["cross_attn"] if cross else []):
+            out += [f"{p}.{a}.query.weight", f"{p}.{a}.query.bias", f"{p}.{a}.key.weight", f"{p}.{a}.value.weight",
+                    f"{p}.{a}.value.bias", f"{p}.{a}.out.weight", f"{p}.{a}.out.bias", f"{p}.{a}_ln.weight", f"{p}.{a}_ln.bias"]
+        out += [f"{p}.mlp1.weight", f"{p}.mlp1.bias", f"{p}.mlp2.weight", f"{p}.mlp2.bias", f"{p}.mlp_ln.weight", f"{p}.mlp_ln.bias"]
+        return out
+
+    for i in range(dims.n_audio_layer):
+        names += block(f"encoder.blocks.{i}", False)
+    names += ["encoder.ln_post.weight", "encoder.ln_post.bias", "decoder.token_embedding.weight", "decoder.positional_embedding"]
+    for i in range(dims.n_text_layer):
+        names += block(f"decoder.blocks.{i}", True)
+    names += ["decoder.ln.weight", "decoder.ln.bias"]
+    return names
+
+
+class _Part:
+    """``model.encoder`` / ``model.decoder``: callable + freeze()/unfreeze() like mlx.nn.Module."""
+
+    def __init__(self, model: "Whisper", prefix: str):
+        self._model, self._prefix = model, prefix
+
+    def freeze(self):
+        self._model._frozen.add(self._prefix)
+        return self
+
+    def unfreeze(self):
+        self._model._frozen.discard(self._prefix)
+        return self
+
+    def __call__(self, *args, **kw):
+        if self._prefix == "encoder":
+            return self._model.embed_audio(*args, **kw)
+        return self._model.logits(*args, **kw)
+
+
+class Whisper:
+    def __init__(self, dims: ModelDimensions, dtype: torch.dtype = torch.float32):
+        self.dims = dims
+        self.dtype = dtype
+        self.device = device()
+        _lib.lib()  # fail now if the extension is missing
+        self._params: Dict[str, torch.Tensor] = {}
+        self._frozen = set()
+        self._packed = None
+        self._enc_ws: Dict[int, torch.Tensor] = {}
+        self._tf_ws = None
+        self.encoder = _Part(self, "encoder")
+        self.decoder = _Part(self, "decoder")
+        self.training = False
+        with on_stream():
+            self._enc_pos = sinusoids(dims.n_audio_ctx, dims.n_audio_state).to(self.device)
+
+    # ---- mlx.nn.Module-like surface ------------------------------------------------
+    @property
+    def is_multilingual(self) -> bool:
+        return self.dims.n_vocab >= 51865
+
+    @property
+    def num_languages(self) -> int:
+        return self.dims.n_vocab - 51765 - int(self.is_multilingual)
+
+    def train(self, mode: bool = True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def set_dtype(self, dtype: torch.dtype):
+        """Matrices (and activations / KV caches) switch to ``dtype``; biases, LayerNorm and
+        positional tables stay f32 (train_whisper_ipa.py:505, transcribe_single.py:13)."""
+        dt_code(dtype)
+        self.dtype = dtype
+        with on_stream():
+            for k, v in list(self._params.items()):
+                if _is_matrix(k, v):
+                    self._params[k] = v.to(dtype)
+        self._invalidate()
+        return self
+
+    def load_weights(self, flat: Dict[str, torch.Tensor], strict: bool = True):
+        """``flat``: mlx_whisper key names (App. A.5 of SURVEY.md).  Conv weights [d,3,c_in]."""
+        names = parameter_names(self.dims)
+        missing = [n for n in names if n not in flat and n not in self._params]
+        if strict and missing:
+            raise KeyError(f"missing weights: {missing[:5]} ... ({len(missing)})")
+        with on_stream():
+            for n in names:
+                if n in flat:
+                    t = torch.as_tensor(flat[n]).detach()
+                    want = self.dtype if _is_matrix(n, t) else torch.float32
+                    self._params[n] = t.to(device=self.device, dtype=want).contiguous()
+        self._invalidate()
+        return self
+
+    def parameters(self) -> Dict:
+        return _unflatten(self._params)
+
+    def trainable_parameters(self) -> Dict:
+        keep = {k: v for k, v in self._params.items() if k.split(".")[0] not in self._frozen}
+        return _unflatten(keep)
+
+    def flat_parameters(self) -> Dict[str, torch.Tensor]:
+        return dict(self._params)
+
+    def update(self, tree: Dict):
+        self.load_weights(_flatten(tree), strict=False)
+        return self
+
+    def _invalidate(self):
+        self._packed = None
+
+    # ---- packing -------------------------------------------------------------------
+    def _cfg(self) -> _lib.ModelCfg:
+        d = self.dims
+        return _lib.ModelCfg(d.n_mels, d.n_audio_ctx, d.n_audio_state, d.n_audio_head, d.n_audio_layer, d.n_vocab,
+                             d.n_text_ctx, d.n_text_state, d.n_text_head, d.n_text_layer, dt_code(self.dtype), 0)
+
+    def packed(self):
+        """(cfg, encoder table, decoder table); fused matrices are rebuilt after any update."""
+        if self._packed is not None:
+            return self._packed
+        P, T, d = self._params, self.dtype, self.dims
+        kmul = 64 if T == torch.bfloat16 else 32
+        f32 = torch.float32
+        with on_stream():
+            def mat(x):
+                return x.to(T).contiguous()
+
+            def vec(x):
+                return x.to(f32).contiguous()
+
+            de = d.n_audio_state
+            K1 = (3 * d.n_mels + kmul - 1) // kmul * kmul
+            c1 = torch.zeros(de, K1, dtype=T, device=self.device)
+            c1[:, : 3 * d.n_mels] = P["encoder.conv1.weight"].reshape(de, 3 * d.n_mels).to(T)
+            enc = [c1, vec(P["encoder.conv1.bias"]), mat(P["encoder.conv2.weight"].reshape(de, 3 * de)),
+                   vec(P["encoder.conv2.bias"]), vec(self._enc_pos), vec(P["encoder.ln_post.weight"]),
+                   vec(P["encoder.ln_post.bias"])]
+            for i in range(d.n_audio_layer):
+                p = f"encoder.blocks.{i}"
+                qb = P[f"{p}.attn.query.bias"]
+                enc += [vec(P[f"{p}.attn_ln.weight"]), vec(P[f"{p}.attn_ln.bias"]),
+                        mat(torch.cat([P[f"{p}.attn.query.weight"], P[f"{p}.attn.key.weight"]], 0)),
+                        vec(torch.cat([qb.float(), torch.zeros_like(qb, dtype=f32)], 0)),
+                        mat(P[f"{p}.attn.value.weight"]), vec(P[f"{p}.attn.value.bias"]),
+                        mat(P[f"{p}.attn.out.weight"]), vec(P[f"{p}.attn.out.bias"]),
+                        vec(P[f"{p}.mlp_ln.weight"]), vec(P[f"{p}.mlp_ln.bias"]),
+                        mat(P[f"{p}.mlp1.weight"]), vec(P[f"{p}.mlp1.bias"]),
+                        mat(P[f"{p}.mlp2.weight"]), vec(P[f"{p}.mlp2.bias"])]
+            dec = [mat(P["decoder.token_embedding.weight"]), vec(P["decoder.positional_embedding"]),
+                   vec(P["decoder.ln.weight"]), vec(P["decoder.ln.bias"])]
+            for i in range(d.n_text_layer):
+                p = f"decoder.blocks.{i}"
+                qb, vb = P[f"{p}.attn.query.bias"].float(), P[f"{p}.attn.value.bias"].float()
+                cvb = P[f"{p}.cross_attn.value.bias"].float()
+                z = torch.zeros_like(qb)
+                dec += [vec(P[f"{p}.attn_ln.weight"]), vec(P[f"{p}.attn_ln.bias"]),
+                        mat(torch.cat([P[f"{p}.attn.query.weight"], P[f"{p}.attn.key.weight"], P[f"{p}.attn.value.weight"]], 0)),
+                        vec(torch.cat([qb, z, vb], 0)),
+                        mat(P[f"{p}.attn.out.weight"]), vec(P[f"{p}.attn.out.bias"]),
+                        vec(P[f"{p}.cross_attn_ln.weight"]), vec(P[f"{p}.cross_attn_ln.bias"]),
+                        mat(P[f"{p}.cross_attn.query.weight"]), vec(P[f"{p}.cross_attn.query.bias"]),
+                        mat(torch.cat([P[f"{p}.cross_attn.key.weight"], P[f"{p}.cross_attn.value.weight"]], 0)),
+                        vec(torch.cat([z, cvb], 0)),
+                        mat(P[f"{p}.cross_attn.out.weight"]), vec(P[f"{p}.cross_attn.out.bias"]),
+                        vec(P[f"{p}.mlp_ln.weight"]), vec(P[f"{p}.mlp_ln.bias"]),
+                        mat(P[f"{p}.mlp1.weight"]), vec(P[f"{p}.mlp1.bias"]),
+                        mat(P[f"{p}.mlp2.weight"]), vec(P[f"{p}.mlp2.bias"])]
+        assert len(enc) == _lib.ENC_GLOBAL + _lib.ENC_PER_LAYER * d.n_audio_layer
+        assert len(dec) == _lib.DEC_GLOBAL + _lib.DEC_PER_LAYER * d.n_text_layer
+        self._packed = dict(cfg=self._cfg(), enc=enc, dec=dec, enc_tab=ptr_table(enc), dec_tab=ptr_table(dec))
+        return self._packed
+
+    # ---- encoder -------------------------------------------------------------------
+    def encode_padded(self, mel_padded: torch.Tensor, B: int) -> torch.Tensor:
+        """padded mel [B*3002+4, n_mels] in the model dtype -> features [B, 1500, d]."""
+        L = _lib.lib()
+        pk = self.packed()
+        assert mel_padded.dtype == self.dtype and mel_padded.shape[0] >= padded_mel_rows(B)
+        with on_stream() as s:
+            ws = self._enc_ws.get(B)
+            if ws is None:
+                self._enc_ws.clear()
+                ws = torch.empty(L.wipa_encoder_workspace_bytes(C.byref(pk["cfg"]), B), dtype=torch.uint8, device=self.device)
+                self._enc_ws[B] = ws
+            out = torch.empty(B, self.dims.n_audio_ctx, self.dims.n_audio_state, dtype=self.dtype, device=self.device)
+            _lib.check(L.wipa_encoder_forward(C.byref(pk["cfg"]), pk["enc_tab"], ptr(mel_padded), ptr(out), ptr(ws), ws.numel(),
+                                              B, sptr(s)), "wipa_encoder_forward")
+        return out
+
+    def embed_audio(self, mel: torch.Tensor) -> torch.Tensor:
+        """mel [B, 3000, n_mels] (or [3000, n_mels]) -> [B, 1500, d]  (train_whisper_ipa.py:223)."""
+        L = _lib.lib()
+        if mel.dim() == 2:
+            mel = mel[None]
+        B = mel.shape[0]
+        assert mel.shape[1] == N_FRAMES and mel.shape[2] == self.dims.n_mels, mel.shape
+        with on_stream() as s:
+            mel32 = mel.to(device=self.device, dtype=torch.float32).contiguous()
+            padded = torch.empty(padded_mel_rows(B), self.dims.n_mels, dtype=self.dtype, device=self.device)
+            _lib.check(L.wipa_mel_pad_cast(ptr(mel32), B, self.dims.n_mels, ptr(padded), dt_code(self.dtype), sptr(s)),
+                       "wipa_mel_pad_cast")
+        return self.encode_padded(padded, B)
+
+    # ---- teacher-forced decoder ----------------------------------------------------
+    def logits(self, tokens: torch.Tensor, audio_features: torch.Tensor) -> torch.Tensor:
+        """tokens [B,T] int, features [B,1500,d] -> logits [B,T,V] f32 (train_whisper_ipa.py:232)."""
+        L = _lib.lib()
+        pk = self.packed()
+        B, T = tokens.shape
+        V = self.dims.n_vocab
+        ldl = (V + 7) // 8 * 8
+        with on_stream() as s:
+            tok = tokens.to(device=self.device, dtype=torch.int32).contiguous()
+            feats = audio_features.to(device=self.device, dtype=self.dtype).contiguous()
+            need = L.wipa_decoder_logits_workspace_bytes(C.byref(pk["cfg"]), B, T)
+            if self._tf_ws is None or self._tf_ws.numel() < need:
+                self._tf_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            out = torch.empty(B * T, ldl, dtype=torch.float32, device=self.device)
+            _lib.check(L.wipa_decoder_logits(C.byref(pk["cfg"]), pk["dec_tab"], ptr(tok), ptr(feats), ptr(out), ldl,
+                                             ptr(self._tf_ws), self._tf_ws.numel(), B, T, sptr(s)), "wipa_decoder_logits")
+        return out.view(B, T, ldl)[:, :, :V]
+
+    def __call__(self, mel: torch.Tensor, tokens: torch.Tensor) -> torch.Tensor:
+        return self.logits(tokens, self.embed_audio(mel))
+
+    def decode(self, mel_or_features: torch.Tensor, options=None):
+        from .decoding import DecodingOptions, decode
+
+        return decode(self, mel_or_features, options or DecodingOptions())
+
+
+def _flatten(tree, prefix=""):
+    out = {}
+    if isinstance(tree, dict):
+        for k, v in tree.items():
+            out.update(_flatten(v, f"{prefix}{k}."))
+    elif isinstance(tree, (list, tuple)):
+        for i, v in enumerate(tree):
+            out.update(_flatten(v, f"{prefix}{i}."))
+    else:
+        out[prefix[:-1]] = tree
+    return out
+
+
+def _unflatten(flat: Dict[str, torch.Tensor]) -> Dict:
+    root: Dict = {}
+    for key, v in flat.items():
+        parts = key.split(".")
+        node = root
+        for p in parts[:-1]:
+            node = node.setdefault(p, {})
+        node[parts[-1]] = v
+
+    def listify(node):
+        if isinstance(node, dict):
+            node = {k: listify(v) for k, v in node.items()}
+            if node and all(k.isdigit() for k in node):
+                return [node[str(i)] for i in range(len(node))]
+        return node
+
+    return listify(root)
