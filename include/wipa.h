@@ -133,8 +133,13 @@ int wipa_attention(const wipa_attn_desc* d, wipa_stream_t s);
 int wipa_flash_attn_enc_bf16(const void* qk, int64_t ldqk, const void* vt, int64_t ldvt, void* out, int64_t ldo,
                              int B, int H, int T, wipa_stream_t s);
 
-/* K11 decode-step cross-attention (HBM-bound): one query row per (b,h) against the
- * cached cross K/V.  q [B, H*64] T; kv [B][2H][Tk][64] T (K heads then V heads);
+/* K11/K12 decode-step attention (HBM-bound): ONE query row per (b,h) (Tq must be 1) against
+ * cached K/V with the strides of wipa_attn_desc; 8 (bf16) / 16 (f32) lanes stream one 64-dim key
+ * row with 16-byte loads, online softmax per lane group, merged across 4 waves.  Used for the
+ * growing self-attention cache (tk_dev / q_row_dev = position) and, via the wrapper below,
+ * for cross-attention. */
+int wipa_decode_attn(const wipa_attn_desc* d, wipa_stream_t s);
+/* cross-attention wrapper: q [B, H*64] T; kv [B][2H][Tk][64] T (K heads then V heads);
  * out [B, H*64] T. */
 int wipa_decode_cross_attn(const void* q, const void* kv, void* out, int B, int H, int Tk, int dtype,
                            wipa_stream_t s);

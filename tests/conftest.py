@@ -10,8 +10,27 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def host_cores() -> int:
+    """cores really available (affinity, cgroup quota), capped at 16: os.cpu_count() reports the
+    whole host on the GPU box and oversubscribes torch's CPU thread pool."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    try:
+        import torch
+
+        torch.set_num_threads(host_cores())
+    except Exception:
+        pass
 
 
 def _has_gpu():

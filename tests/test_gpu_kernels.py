@@ -180,6 +180,47 @@ def test_decode_cross_attention(ops, dtype, Tk):
     assert _rel(out, ref) < (1e-2 if dtype == torch.bfloat16 else 1e-5)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_decode_self_attention_cache_layout(ops, dtype):
+    """self-attention cache [B, n_ctx, H*64] with the position in device memory."""
+    g = torch.Generator().manual_seed(9)
+    B, H, nctx, pos = 3, 2, 448, 70
+    qbuf = (torch.randn(B, nctx, H, 64, generator=g) * 0.5).to(dtype)
+    kbuf = (torch.randn(B, nctx, H, 64, generator=g) * 0.5).to(dtype)
+    vbuf = torch.randn(B, nctx, H, 64, generator=g).to(dtype)
+    pos_dev = torch.tensor([pos], dtype=torch.int32).cuda()
+    out = ops.decode_attn(qbuf.cuda(), kbuf.cuda(), vbuf.cuda(), Tk=1, tk_dev=pos_dev, q_row_dev=pos_dev)
+    torch.cuda.synchronize()
+    qf = qbuf[:, pos].float()
+    K, V = kbuf[:, : pos + 1].float(), vbuf[:, : pos + 1].float()
+    s = torch.einsum("bhd,bthd->bht", qf, K)
+    ref = torch.einsum("bht,bthd->bhd", torch.softmax(s, -1), V)
+    assert _rel(out, ref) < (1e-2 if dtype == torch.bfloat16 else 1e-5)
+
+
+@pytest.mark.parametrize("dtype,out_dtype", [(torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32), (torch.float32, torch.float32)])
+@pytest.mark.parametrize("M,N,K", [(64, 768, 768), (64, 768, 3072), (64, 2304, 768), (1, 768, 768), (17, 100, 128), (33, 51865, 768), (28, 384, 1536)])
+def test_gemm_skinny(ops, dtype, out_dtype, M, N, K):
+    """decode-step GEMMs (M <= 64) take the weight-streaming kernel: all epilogue features."""
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    A = (torch.randn(M, K, generator=g)).to(dtype)
+    W = (torch.randn(N, K, generator=g) * 0.05).to(dtype)
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g).to(out_dtype)
+    ldc = (N + 7) // 8 * 8
+    out = torch.zeros(M, ldc, dtype=out_dtype)
+    out[:, :N] = res
+    out = out.cuda()
+    ops.gemm(A.cuda(), W.cuda(), out, M=M, N=N, K=K, lda=K, ldw=K, ldc=ldc, bias=bias.cuda(), act=1, residual=out,
+             col_scale_n=N // 2, col_scale=0.25)
+    torch.cuda.synchronize()
+    y = A.double() @ W.double().T + bias.double()
+    y[:, : N // 2] *= 0.25
+    ref = torch.nn.functional.gelu(y) + res.double()
+    tol = 1e-2 if out_dtype == torch.bfloat16 else (3e-5 if dtype == torch.float32 else 1e-5)
+    assert _rel(out[:, :N], ref) < tol
+
+
 def test_embed_tokens(ops):
     g = torch.Generator().manual_seed(1)
     V, D, B, T = 1000, 128, 3, 7

@@ -30,7 +30,6 @@ def clips():
 
 @pytest.fixture(scope="module")
 def micro(clips):
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
     W = R.synthetic_weights(MICRO, seed=7)
     mels = np.stack([R.log_mel_spectrogram(a) for a in clips])
     with torch.no_grad():

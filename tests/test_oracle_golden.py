@@ -24,7 +24,6 @@ def gmodel(golden_dir):
 
 @pytest.fixture(scope="module")
 def micro():
-    torch.set_num_threads(8)
     W = R.synthetic_weights(MICRO, seed=7)
     mels = np.stack([R.log_mel_spectrogram(R.synthetic_clip(0, 30.0)), R.log_mel_spectrogram(R.synthetic_clip(1, 5.0))])
     with torch.no_grad():

@@ -78,6 +78,7 @@ SIGNATURES = {
     "wipa_attention": (c_int, [_P(AttnDesc), c_void_p]),
     "wipa_flash_attn_enc_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
                                          c_void_p]),
+    "wipa_decode_attn": (c_int, [_P(AttnDesc), c_void_p]),
     "wipa_decode_cross_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "wipa_greedy_step": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int,
                                  c_int, c_void_p, c_void_p, c_void_p]),

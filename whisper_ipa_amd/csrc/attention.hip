@@ -7,6 +7,8 @@
 //                            HBM-bound streaming with 16-byte coalesced loads.
 // Replaces MultiHeadAttention.qkv_attention of mlx_whisper.whisper
 // (call sites scripts/train_whisper_ipa.py:223,232; scripts/transcribe_single.py:54-55).
+#include <cstring>
+
 #include "wipa_common.h"
 
 namespace {
@@ -159,8 +161,7 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(AttnParams p) {
 // K11 decode-step cross-attention
 // =============================================================================
 template <typename T>
-__global__ __launch_bounds__(256) void decode_cross_attn_kernel(const T* __restrict__ q, const T* __restrict__ kv,
-                                                                T* __restrict__ out, int H, int Tk) {
+__global__ __launch_bounds__(256) void decode_attn_kernel(AttnParams p) {
     constexpr int EPL = Vec16<T>::EPL;  // elements per 16-byte load
     constexpr int LPK = 64 / EPL;       // lanes per key row (64 dims)
     constexpr int G = 64 / LPK;         // keys per wave instruction
@@ -170,15 +171,18 @@ __global__ __launch_bounds__(256) void decode_cross_attn_kernel(const T* __restr
     const int h = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane / LPK, c = lane % LPK;
-    const int D = H * 64;
+    const int Tk = p.Tk + (p.tk_dev ? *p.tk_dev : 0);
+    const int q_row0 = p.q_row_dev ? *p.q_row_dev : 0;
     float qf[EPL];
     {
-        Vec16<T> qv = *reinterpret_cast<const Vec16<T>*>(q + (int64_t)b * D + h * 64 + c * EPL);
+        const T* qp = reinterpret_cast<const T*>(p.q) + b * p.q_bs + (int64_t)q_row0 * p.q_rs + h * p.q_hs + c * EPL;
+        Vec16<T> qv = *reinterpret_cast<const Vec16<T>*>(qp);
 #pragma unroll
         for (int e = 0; e < EPL; ++e) qf[e] = qv.get(e);
     }
-    const T* Kb = kv + ((int64_t)(b * 2 * H + h) * Tk) * 64 + c * EPL;
-    const T* Vb = kv + ((int64_t)(b * 2 * H + H + h) * Tk) * 64 + c * EPL;
+    const T* Kb = reinterpret_cast<const T*>(p.k) + b * p.k_bs + h * p.k_hs + c * EPL;
+    const T* Vb = reinterpret_cast<const T*>(p.v) + b * p.v_bs + h * p.v_hs + c * EPL;
+    const int64_t k_rs = p.k_rs, v_rs = p.v_rs;
     float m = NEG_BIG, l = 0.f;
     float acc[EPL];
 #pragma unroll
@@ -188,8 +192,8 @@ __global__ __launch_bounds__(256) void decode_cross_attn_kernel(const T* __restr
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int t = min(t0 + u * G + g, Tk - 1);
-            kvec[u] = *reinterpret_cast<const Vec16<T>*>(Kb + (int64_t)t * 64);
-            vvec[u] = *reinterpret_cast<const Vec16<T>*>(Vb + (int64_t)t * 64);
+            kvec[u] = *reinterpret_cast<const Vec16<T>*>(Kb + (int64_t)t * k_rs);
+            vvec[u] = *reinterpret_cast<const Vec16<T>*>(Vb + (int64_t)t * v_rs);
         }
         float s[U];
 #pragma unroll
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(256) void decode_cross_attn_kernel(const T* __restr
             num += s_acc[w][tid] * sc;
             den += s_l[w] * sc;
         }
-        out[(int64_t)b * D + h * 64 + tid] = from_f32<T>(num / den);
+        reinterpret_cast<T*>(p.out)[b * p.o_bs + h * p.o_hs + tid] = from_f32<T>(num / den);
     }
 }
 
@@ -450,19 +454,55 @@ extern "C" int wipa_flash_attn_enc_bf16(const void* qk, int64_t ldqk, const void
     return WIPA_OK;
 }
 
+static int fill_attn_params(const wipa_attn_desc* d, AttnParams& p) {
+    p.q = (const char*)d->q;
+    p.k = (const char*)d->k;
+    p.v = (const char*)d->v;
+    p.out = (char*)d->out;
+    p.tk_dev = d->tk_dev;
+    p.q_row_dev = d->q_row_dev;
+    p.q_bs = d->q_bs; p.q_rs = d->q_rs; p.q_hs = d->q_hs;
+    p.k_bs = d->k_bs; p.k_rs = d->k_rs; p.k_hs = d->k_hs;
+    p.v_bs = d->v_bs; p.v_rs = d->v_rs; p.v_hs = d->v_hs;
+    p.o_bs = d->o_bs; p.o_rs = d->o_rs; p.o_hs = d->o_hs;
+    p.Tq = d->Tq;
+    p.Tk = d->Tk;
+    p.causal = d->causal;
+    return WIPA_OK;
+}
+
+extern "C" int wipa_decode_attn(const wipa_attn_desc* d, wipa_stream_t stream) {
+    WIPA_REQUIRE(d && d->q && d->k && d->v && d->out, "wipa_decode_attn: null pointer");
+    WIPA_REQUIRE(d->B > 0 && d->H > 0 && d->Tq == 1, "wipa_decode_attn: one query row per (b,h) (Tq=%d)", d->Tq);
+    WIPA_REQUIRE(d->dtype == WIPA_F32 || d->dtype == WIPA_BF16, "wipa_decode_attn: bad dtype %d", d->dtype);
+    const int64_t al = d->dtype == WIPA_BF16 ? 8 : 4;
+    WIPA_REQUIRE(d->q_rs % al == 0 && d->k_rs % al == 0 && d->v_rs % al == 0 && d->q_hs % al == 0 && d->k_hs % al == 0 &&
+                     d->v_hs % al == 0 && d->q_bs % al == 0 && d->k_bs % al == 0 && d->v_bs % al == 0,
+                 "wipa_decode_attn: strides must keep 16-byte alignment");
+    AttnParams p;
+    fill_attn_params(d, p);
+    dim3 grid(d->H, d->B);
+    if (d->dtype == WIPA_F32)
+        hipLaunchKernelGGL((decode_attn_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL((decode_attn_kernel<__bf16>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
 extern "C" int wipa_decode_cross_attn(const void* q, const void* kv, void* out, int B, int H, int Tk, int dtype,
                                       wipa_stream_t stream) {
     WIPA_REQUIRE(q && kv && out, "wipa_decode_cross_attn: null pointer");
     WIPA_REQUIRE(B > 0 && H > 0 && Tk > 0, "wipa_decode_cross_attn: bad shape");
-    dim3 grid(H, B);
-    if (dtype == WIPA_F32)
-        hipLaunchKernelGGL((decode_cross_attn_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)q,
-                           (const float*)kv, (float*)out, H, Tk);
-    else if (dtype == WIPA_BF16)
-        hipLaunchKernelGGL((decode_cross_attn_kernel<__bf16>), grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)q,
-                           (const __bf16*)kv, (__bf16*)out, H, Tk);
-    else
-        WIPA_REQUIRE(false, "wipa_decode_cross_attn: bad dtype %d", dtype);
-    WIPA_LAUNCH_CHECK();
-    return WIPA_OK;
+    WIPA_REQUIRE(dtype == WIPA_F32 || dtype == WIPA_BF16, "wipa_decode_cross_attn: bad dtype %d", dtype);
+    wipa_attn_desc d;
+    memset(&d, 0, sizeof(d));
+    const size_t e = wipa_dtype_size(dtype);
+    d.q = q; d.k = kv; d.v = (const char*)kv + (size_t)H * Tk * 64 * e; d.out = out;
+    d.q_bs = (int64_t)H * 64; d.q_rs = (int64_t)H * 64; d.q_hs = 64;
+    d.k_bs = (int64_t)2 * H * Tk * 64; d.k_rs = 64; d.k_hs = (int64_t)Tk * 64;
+    d.v_bs = d.k_bs; d.v_rs = 64; d.v_hs = d.k_hs;
+    d.o_bs = (int64_t)H * 64; d.o_rs = (int64_t)H * 64; d.o_hs = 64;
+    d.B = B; d.H = H; d.Tq = 1; d.Tk = Tk; d.causal = 0; d.dtype = dtype;
+    return wipa_decode_attn(&d, stream);
 }

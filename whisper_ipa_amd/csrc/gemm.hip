@@ -93,6 +93,56 @@ __device__ __forceinline__ void load4(const char* R, int64_t off, float (&v)[4],
     }
 }
 
+// Shared epilogue: 4 consecutive output columns n..n+3 of row m (see wipa_gemm in wipa.h).
+template <typename OutT>
+__device__ __forceinline__ void epilogue4(const GemmParams& p, const f32x4& a, int m, int n, int64_t coff_dev, bool vec) {
+    if (m >= p.M || n >= p.N) return;
+    const int gi = m / p.rg_in;
+    const int gr = m - gi * p.rg_in;
+    const bool valid = gr < p.rg_valid;
+    if (!valid && !p.zero_invalid) return;
+    const int nvalid = min(4, p.N - n);
+    const int cgi = n / p.cg_in;
+    const int cgr = n - cgi * p.cg_in;
+    const int64_t off = coff_dev + (int64_t)gi * p.rg_stride + (int64_t)gr * p.ldc + (int64_t)cgi * p.cg_stride + cgr;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = a[r];
+    if (p.bias) {
+        if (p.bias_along_m) {
+            const float bm = p.bias[m];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += bm;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (r < nvalid ? p.bias[n + r] : 0.f);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (n + r < p.col_scale_n) v[r] *= p.col_scale;
+    if (p.act == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+    }
+    if (p.pos) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r < nvalid) v[r] += p.pos[(int64_t)gr * p.ldpos + n + r];
+    }
+    if (p.residual) {
+        float rr[4];
+        load4<OutT>(p.residual, off, rr, nvalid, vec);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += rr[r];
+    }
+    if (!valid) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = 0.f;
+    }
+    store4<OutT>(p.C, off, v, nvalid, vec);
+}
+
 constexpr int BM = 128, BN = 128, ROWB = 128;  // ROWB: bytes of K per LDS row
 constexpr int TILE_BYTES = BM * ROWB;          // 16 KiB per operand tile
 constexpr int GROUP_M = 8;
@@ -198,54 +248,112 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int m = m0 + wm * 64 + 16 * j + frow;
-        if (m >= p.M) continue;
-        const int gi = m / p.rg_in;
-        const int gr = m - gi * p.rg_in;
-        const bool valid = gr < p.rg_valid;
-        if (!valid && !p.zero_invalid) continue;
-        const int64_t roff = coff_dev + (int64_t)gi * p.rg_stride + (int64_t)gr * p.ldc;
-        const float bm = (p.bias && p.bias_along_m) ? p.bias[m] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = n0 + wn * 64 + 16 * i + 4 * fq;
-            if (n >= p.N) continue;
-            const int nvalid = min(4, p.N - n);
-            const int cgi = n / p.cg_in;
-            const int cgr = n - cgi * p.cg_in;
-            const int64_t off = roff + (int64_t)cgi * p.cg_stride + cgr;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
-            if (p.bias) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += p.bias_along_m ? bm : (r < nvalid ? p.bias[n + r] : 0.f);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (n + r < p.col_scale_n) v[r] *= p.col_scale;
-            if (p.act == 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-            }
-            if (p.pos) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (r < nvalid) v[r] += p.pos[(int64_t)gr * p.ldpos + n + r];
-            }
-            if (p.residual) {
-                float rr[4];
-                load4<OutT>(p.residual, off, rr, nvalid, vec);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += rr[r];
-            }
-            if (!valid) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = 0.f;
-            }
-            store4<OutT>(p.C, off, v, nvalid, vec);
-        }
+        for (int i = 0; i < 4; ++i) epilogue4<OutT>(p, acc[i][j], m, n0 + wn * 64 + 16 * i + 4 * fq, coff_dev, vec);
     }
 }
+
+// ---------------------------------------------------------------------------------------
+// Skinny GEMM (decode step, M <= 64 rows per workgroup): weight-streaming bound.
+// One workgroup owns 16*NT output columns for 16*MT rows; its NW waves split K, every wave
+// streams its weight slice ONCE straight from HBM into MFMA fragments (16-byte loads, no LDS
+// round trip: nothing is shared between waves), reads the small activation matrix from L2,
+// and the partial tiles are summed through LDS.  Grid = N / (16*NT) workgroups, so even a
+// 768x768 projection spreads over 48 CUs x 4 waves instead of the 6 workgroups a 128x128
+// tiling gives.
+template <typename T, typename OutT, int MT, int NT, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p) {
+    __shared__ f32x4 red[NW][MT * NT][64];
+    typedef typename Mma<T>::Frag Frag;
+    constexpr int UB = (NT == 1) ? 6 : 4;  // k-steps whose loads are in flight together
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int n0 = blockIdx.x * (16 * NT);
+    const int m0 = blockIdx.y * (16 * MT);
+    const int ksteps = p.K * (int)sizeof(T) / 64;  // 64 bytes of K per MFMA fragment step
+    const int per = ksteps / NW, rem = ksteps % NW;
+    const int kb = wave * per + min(wave, rem);
+    const int ke = kb + per + (wave < rem ? 1 : 0);
+    const char* wp[NT];
+    const char* xp[MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) wp[i] = p.W + (int64_t)min(n0 + 16 * i + frow, p.N - 1) * p.ldw_b + fq * 16;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) xp[j] = p.A + (int64_t)min(m0 + 16 * j + frow, p.M - 1) * p.lda_b + fq * 16;
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int ks = kb;
+    for (; ks + UB <= ke; ks += UB) {
+        Frag fw[UB][NT], fx[UB][MT];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int64_t off = (int64_t)(ks + u) * 64;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) fw[u][i] = *reinterpret_cast<const Frag*>(wp[i] + off);
+#pragma unroll
+            for (int j = 0; j < MT; ++j) fx[u][j] = *reinterpret_cast<const Frag*>(xp[j] + off);
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j) Mma<T>::run(fw[u][i], fx[u][j], acc[i][j]);
+    }
+    for (; ks < ke; ++ks) {
+        const int64_t off = (int64_t)ks * 64;
+        Frag fw[NT], fx[MT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) fw[i] = *reinterpret_cast<const Frag*>(wp[i] + off);
+#pragma unroll
+        for (int j = 0; j < MT; ++j) fx[j] = *reinterpret_cast<const Frag*>(xp[j] + off);
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) Mma<T>::run(fw[i], fx[j], acc[i][j]);
+    }
+#pragma unroll
+    for (int t = 0; t < NT * MT; ++t) red[wave][t][lane] = acc[t / MT][t % MT];
+    __syncthreads();
+    const bool vec = p.vec_ok != 0;
+    int64_t coff_dev = p.c_offset;
+    if (p.c_offset_dev) coff_dev += *p.c_offset_dev;
+    for (int t = wave; t < NT * MT; t += NW) {
+        f32x4 s = red[0][t][lane];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) s += red[w][t][lane];
+        const int i = t / MT, j = t - i * MT;
+        epilogue4<OutT>(p, s, m0 + 16 * j + frow, n0 + 16 * i + 4 * fq, coff_dev, vec);
+    }
+}
+
+template <typename T, typename OutT, int MT, int NT, int NW>
+int launch_skinny_cfg(const GemmParams& p, hipStream_t s) {
+    dim3 grid((p.N + 16 * NT - 1) / (16 * NT), (p.M + 16 * MT - 1) / (16 * MT));
+    hipLaunchKernelGGL((gemm_skinny_kernel<T, OutT, MT, NT, NW>), grid, dim3(NW * 64), 0, s, p);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+template <typename T, typename OutT, int MT>
+int launch_skinny_mt(const GemmParams& p, hipStream_t s) {
+    const int ksteps = p.K * (int)sizeof(T) / 64;
+    if (p.N >= 8192) return launch_skinny_cfg<T, OutT, MT, 2, 4>(p, s);
+    if (ksteps >= 64) return launch_skinny_cfg<T, OutT, MT, 1, 8>(p, s);
+    return launch_skinny_cfg<T, OutT, MT, 1, 4>(p, s);
+}
+
+template <typename T, typename OutT>
+int launch_skinny(const GemmParams& p, hipStream_t s) {
+    if (p.M <= 16) return launch_skinny_mt<T, OutT, 1>(p, s);
+    if (p.M <= 32) return launch_skinny_mt<T, OutT, 2>(p, s);
+    return launch_skinny_mt<T, OutT, 4>(p, s);
+}
+
+constexpr int SKINNY_MAX_M = 64;
 
 constexpr int SMEM_BYTES = 4 * TILE_BYTES;  // 64 KiB
 
@@ -322,6 +430,11 @@ extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
     {
         const int rc = init_attrs();
         if (rc != WIPA_OK) return rc;
+    }
+    if (d->M <= SKINNY_MAX_M && !(d->in_dtype == WIPA_F32 && d->out_dtype == WIPA_BF16)) {
+        if (d->in_dtype == WIPA_BF16)
+            return d->out_dtype == WIPA_BF16 ? launch_skinny<__bf16, __bf16>(p, s) : launch_skinny<__bf16, float>(p, s);
+        return launch_skinny<float, float>(p, s);
     }
     if (d->in_dtype == WIPA_BF16) {
         return d->out_dtype == WIPA_BF16 ? launch<__bf16, __bf16>(p, s) : launch<__bf16, float>(p, s);

@@ -262,7 +262,7 @@ int enqueue_step(const wipa_model_cfg* cfg, const void* const* w, char* st, cons
             a.v_bs = a.q_bs; a.v_rs = d; a.v_hs = 64;
             a.o_bs = d; a.o_rs = d; a.o_hs = 64;
             a.B = B; a.H = H; a.Tq = 1; a.Tk = 1; a.causal = 0; a.dtype = dt;
-            RT_CALL(wipa_attention(&a, stream));
+            RT_CALL(wipa_decode_attn(&a, stream));
         }
         RT_CALL(gemm(ao, d, lw[4], d, x, d, B, d, d, dt, WIPA_F32, (const float*)lw[5], 0, x, stream));
         RT_CALL(wipa_layernorm(x, WIPA_F32, d, ln, dt, d, (const float*)lw[6], (const float*)lw[7], B, d, 1e-5f, stream));

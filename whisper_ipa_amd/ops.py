@@ -75,6 +75,27 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = 
     return out
 
 
+def decode_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, Tk: Optional[int] = None,
+                tk_dev: Optional[torch.Tensor] = None, q_row_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One query row per (b,h): q [B,Tq_buf,H,64] (row ``*q_row_dev`` or 0 is used), k/v [B,Tk_buf,H,64]
+    with any strides (last dim contiguous); keys [0, Tk + *tk_dev) -> [B,H,64]."""
+    L = _lib.lib()
+    B, _, H, hd = q.shape
+    assert hd == 64
+    with on_stream() as s:
+        out = torch.empty(B, H, 64, dtype=q.dtype, device=q.device)
+        d = _lib.AttnDesc()
+        d.q, d.k, d.v, d.out = ptr(q), ptr(k), ptr(v), ptr(out)
+        d.tk_dev, d.q_row_dev = ptr(tk_dev), ptr(q_row_dev)
+        d.q_bs, d.q_rs, d.q_hs = q.stride(0), q.stride(1), q.stride(2)
+        d.k_bs, d.k_rs, d.k_hs = k.stride(0), k.stride(1), k.stride(2)
+        d.v_bs, d.v_rs, d.v_hs = v.stride(0), v.stride(1), v.stride(2)
+        d.o_bs, d.o_rs, d.o_hs = out.stride(0), out.stride(0), out.stride(1)
+        d.B, d.H, d.Tq, d.Tk, d.causal, d.dtype = B, H, 1, (k.shape[1] if Tk is None else Tk), 0, dt_code(q.dtype)
+        _lib.check(L.wipa_decode_attn(C.byref(d), sptr(s)), "wipa_decode_attn")
+    return out
+
+
 def flash_attn_enc(qk: torch.Tensor, vt: torch.Tensor, B: int, H: int, T: int) -> torch.Tensor:
     """qk [B*T, 2D] bf16 (q|k, pre-scaled), vt [B, D, ldvt] bf16 (zero beyond T) -> [B*T, D] bf16."""
     L = _lib.lib()
