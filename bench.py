@@ -49,6 +49,7 @@ def host_cores() -> int:
 
 
 BATCH = 64          # clips per GPU
+N_STREAMS = 4       # sub-batches of the 64 clips, one HIP stream each
 NEW_TOKENS = 64     # decode positions per clip (SURVEY.md section 8d primary setting)
 HBM_PEAK_GBS = 8000.0
 MFMA_BF16_PEAK_TFLOPS = 2500.0
@@ -129,16 +130,23 @@ def decode_setup():
     return list(tok.sot_sequence_including_notimestamps), always, first, tok.eot
 
 
-def one_pass(model, audio_dev, setup):
+def one_pass(model, audio_chunks, setup):
+    """One pass over the batch.  The clips are split into sub-batches, each on its own HIP stream:
+    log-mel -> encoder -> cross-KV -> decode loop are enqueued asynchronously per sub-batch, so the
+    MFMA-bound encoder of one sub-batch overlaps the HBM/latency-bound decode loop of another.
+    Returns the token matrix of the whole batch (host), i.e. the pass ends when all ids are on the host."""
     from whisper_ipa_amd import audio as A
-    from whisper_ipa_amd.decoding import greedy_decode_tokens
+    from whisper_ipa_amd.decoding import greedy_collect, greedy_launch
+    from whisper_ipa_amd.runtime import use_stream
 
     init, always, first, eot = setup
-    B = audio_dev.shape[0]
-    mel = A.log_mel_padded(audio_dev, model.dims.n_mels, model.dtype)
-    feats = model.encode_padded(mel, B)
-    res = greedy_decode_tokens(model, feats, init, always, first, eot, max_new_tokens=NEW_TOKENS, stop_on_eot=False)
-    return res
+    handles = []
+    for sid, a in enumerate(audio_chunks):
+        with use_stream(sid):
+            mel = A.log_mel_padded(a, model.dims.n_mels, model.dtype)
+            feats = model.encode_padded(mel, a.shape[0])
+            handles.append(greedy_launch(model, feats, init, always, first, eot, max_new_tokens=NEW_TOKENS))
+    return np.concatenate([greedy_collect(h).tokens for h in handles], axis=0)
 
 
 def roofline_cross_attn(model, B: int, iters: int = 48):
@@ -151,7 +159,7 @@ def roofline_cross_attn(model, B: int, iters: int = 48):
 
     d = model.dims
     H, Ta = d.n_text_head, d.n_audio_ctx
-    st = model._dec_state
+    st = model._dec_states[0]
     lay = st.layout
     e = 2 if model.dtype == torch.bfloat16 else 4
     per_layer = B * 2 * H * Ta * 64
@@ -205,6 +213,7 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--streams", type=int, default=N_STREAMS, help="clip sub-batches run on this many HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -230,13 +239,14 @@ def main():
     model.load_weights(W)
     del W
     audio_dev = torch.from_numpy(synthetic_audio(rank * B, B)).cuda()
+    audio_chunks = [c.contiguous() for c in audio_dev.chunk(args.streams)]
     setup = decode_setup()
     model.packed()
     torch.cuda.synchronize()
     log("model + audio resident on the GPU")
 
     for i in range(args.warmup):
-        one_pass(model, audio_dev, setup)
+        one_pass(model, audio_chunks, setup)
         torch.cuda.synchronize()
         log(f"warmup pass {i} done")
     torch.cuda.synchronize()
@@ -245,7 +255,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = one_pass(model, audio_dev, setup)
+        tokens = one_pass(model, audio_chunks, setup)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -274,11 +284,12 @@ def main():
             "data": "synthetic (seeded noise clips, random-init whisper-small weights)",
             "config": {"workload": f"whisper-small bf16 batched inference, batch={B}x30s synthetic clips per GPU, "
                                    f"log-mel + encoder + cross-KV + {NEW_TOKENS} greedy KV-cached decode steps",
-                       "clips_per_gpu": B, "new_tokens": NEW_TOKENS, "parallelism": f"dp{world} (clip sharding, no collective)"},
-            "tokens_checksum": int(res.tokens.sum() % 1000003),
+                       "clips_per_gpu": B, "new_tokens": NEW_TOKENS, "streams_per_gpu": args.streams,
+                       "parallelism": f"dp{world} (clip sharding, no collective)"},
+            "tokens_checksum": int(tokens.sum() % 1000003),
         }
         log(f"timed region done: {elapsed:.3f} s for {args.steps} passes")
-        out["roofline"] = roofline_cross_attn(model, B)
+        out["roofline"] = roofline_cross_attn(model, audio_chunks[0].shape[0])
         log("roofline microbench done")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(1)

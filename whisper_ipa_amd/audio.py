@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .runtime import device, dt_code, on_stream, ptr, sptr
+from .runtime import device, dt_code, on_stream, ptr, sptr, stream_id
 
 SAMPLE_RATE = 16000
 N_FFT = 400
@@ -116,11 +116,11 @@ def log_mel_padded(audio: torch.Tensor, n_mels: int = 80, dtype: torch.dtype = t
     B = audio.shape[0]
     tables = _get_tables(n_mels)
     with on_stream() as s:
-        key = (audio.device.index, B, n_mels)
+        key = (audio.device.index, stream_id())
         ws = _workspaces.get(key)
-        if ws is None:
-            ws = torch.empty(L.wipa_logmel_workspace_bytes(B, n_mels), dtype=torch.uint8, device=audio.device)
-            _workspaces.clear()  # keep one workspace alive (they are large)
+        need = L.wipa_logmel_workspace_bytes(B, n_mels)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=audio.device)  # one per library stream
             _workspaces[key] = ws
         mel = torch.empty(padded_mel_rows(B), n_mels, dtype=dtype, device=audio.device)
         _lib.check(L.wipa_logmel(ptr(audio), B, n_mels, ptr(tables), ptr(mel), dt_code(dtype), ptr(ws), ws.numel(), sptr(s)),

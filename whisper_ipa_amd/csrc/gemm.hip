@@ -13,6 +13,7 @@
 // four K=4 steps with a consistent K permutation on both operands.
 // Global->register->LDS staging, double buffered, one barrier per K-step; loads for
 // step k+1 are issued before the MFMAs of step k (async-STAGE split).
+#include <cstdlib>
 #include <mutex>
 
 #include "wipa_common.h"
@@ -93,34 +94,61 @@ __device__ __forceinline__ void load4(const char* R, int64_t off, float (&v)[4],
     }
 }
 
-// Shared epilogue: 4 consecutive output columns n..n+3 of row m (see wipa_gemm in wipa.h).
+// Shared epilogue (see wipa_gemm in wipa.h).  Row- and column-dependent address parts, the
+// remap divisions and the bias loads are hoisted: once per output row / per 4-column group
+// of a lane, not once per accumulator tile.
+struct EpiRow {
+    int64_t roff;
+    int gr;
+    float bm;
+    bool store, valid;
+};
+struct EpiCol {
+    int64_t coff;
+    int n, nvalid;
+    float b[4], sc[4];
+    bool ok;
+};
+__device__ __forceinline__ EpiRow epi_row(const GemmParams& p, int m, int64_t coff_dev) {
+    EpiRow r;
+    r.store = m < p.M;
+    int gi = 0, gr = m;
+    if (p.rg_in < p.M) {  // uniform: remapped rows (conv halo layouts, KV caches)
+        gi = m / p.rg_in;
+        gr = m - gi * p.rg_in;
+    }
+    r.gr = gr;
+    r.valid = gr < p.rg_valid;
+    if (!r.valid && !p.zero_invalid) r.store = false;
+    r.roff = coff_dev + (int64_t)gi * p.rg_stride + (int64_t)gr * p.ldc;
+    r.bm = (p.bias && p.bias_along_m && m < p.M) ? p.bias[m] : 0.f;
+    return r;
+}
+__device__ __forceinline__ EpiCol epi_col(const GemmParams& p, int n) {
+    EpiCol c;
+    c.n = n;
+    c.ok = n < p.N;
+    c.nvalid = min(4, p.N - n);
+    int cgi = 0, cgr = n;
+    if (p.cg_in < p.N) {
+        cgi = n / p.cg_in;
+        cgr = n - cgi * p.cg_in;
+    }
+    c.coff = (int64_t)cgi * p.cg_stride + cgr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        c.b[r] = (p.bias && !p.bias_along_m && c.ok && r < c.nvalid) ? p.bias[n + r] : 0.f;
+        c.sc[r] = (n + r < p.col_scale_n) ? p.col_scale : 1.0f;
+    }
+    return c;
+}
 template <typename OutT>
-__device__ __forceinline__ void epilogue4(const GemmParams& p, const f32x4& a, int m, int n, int64_t coff_dev, bool vec) {
-    if (m >= p.M || n >= p.N) return;
-    const int gi = m / p.rg_in;
-    const int gr = m - gi * p.rg_in;
-    const bool valid = gr < p.rg_valid;
-    if (!valid && !p.zero_invalid) return;
-    const int nvalid = min(4, p.N - n);
-    const int cgi = n / p.cg_in;
-    const int cgr = n - cgi * p.cg_in;
-    const int64_t off = coff_dev + (int64_t)gi * p.rg_stride + (int64_t)gr * p.ldc + (int64_t)cgi * p.cg_stride + cgr;
+__device__ __forceinline__ void epilogue4(const GemmParams& p, const f32x4& a, const EpiRow& R, const EpiCol& Cc, bool vec) {
+    if (!R.store || !Cc.ok) return;
+    const int64_t off = R.roff + Cc.coff;
     float v[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = a[r];
-    if (p.bias) {
-        if (p.bias_along_m) {
-            const float bm = p.bias[m];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += bm;
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += (r < nvalid ? p.bias[n + r] : 0.f);
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-        if (n + r < p.col_scale_n) v[r] *= p.col_scale;
+    for (int r = 0; r < 4; ++r) v[r] = (a[r] + Cc.b[r] + R.bm) * Cc.sc[r];
     if (p.act == 1) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
@@ -128,19 +156,19 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, const f32x4& a, i
     if (p.pos) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (r < nvalid) v[r] += p.pos[(int64_t)gr * p.ldpos + n + r];
+            if (r < Cc.nvalid) v[r] += p.pos[(int64_t)R.gr * p.ldpos + Cc.n + r];
     }
     if (p.residual) {
         float rr[4];
-        load4<OutT>(p.residual, off, rr, nvalid, vec);
+        load4<OutT>(p.residual, off, rr, Cc.nvalid, vec);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += rr[r];
     }
-    if (!valid) {
+    if (!R.valid) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = 0.f;
     }
-    store4<OutT>(p.C, off, v, nvalid, vec);
+    store4<OutT>(p.C, off, v, Cc.nvalid, vec);
 }
 
 constexpr int BM = 128, BN = 128, ROWB = 128;  // ROWB: bytes of K per LDS row
@@ -245,11 +273,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
     const bool vec = p.vec_ok != 0;
     int64_t coff_dev = p.c_offset;
     if (p.c_offset_dev) coff_dev += *p.c_offset_dev;
+    EpiCol cols[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cols[i] = epi_col(p, n0 + wn * 64 + 16 * i + 4 * fq);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int m = m0 + wm * 64 + 16 * j + frow;
+        const EpiRow row = epi_row(p, m0 + wm * 64 + 16 * j + frow, coff_dev);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) epilogue4<OutT>(p, acc[i][j], m, n0 + wn * 64 + 16 * i + 4 * fq, coff_dev, vec);
+        for (int i = 0; i < 4; ++i) epilogue4<OutT>(p, acc[i][j], row, cols[i], vec);
     }
 }
 
@@ -326,7 +357,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p) {
 #pragma unroll
         for (int w = 1; w < NW; ++w) s += red[w][t][lane];
         const int i = t / MT, j = t - i * MT;
-        epilogue4<OutT>(p, s, m0 + 16 * j + frow, n0 + 16 * i + 4 * fq, coff_dev, vec);
+        epilogue4<OutT>(p, s, epi_row(p, m0 + 16 * j + frow, coff_dev), epi_col(p, n0 + 16 * i + 4 * fq), vec);
     }
 }
 
@@ -355,6 +386,123 @@ int launch_skinny(const GemmParams& p, hipStream_t s) {
 
 constexpr int SKINNY_MAX_M = 64;
 
+// ---------------------------------------------------------------------------------------
+// Large-tile GEMM: 256x256 output tile, 8 waves (2 along M x 4 along N, 128x64 per wave =
+// 8x4 MFMA tiles), K-step 128 bytes, LDS 2 x 64 KiB, one workgroup per CU.  Tiles are staged
+// with LDS-DMA (global_load_lds, 16 bytes per lane, no VGPR round trip and no ds_write):
+// the LDS image is lane-linear per 1-KiB piece (8 rows x 128 B), so the bank swizzle
+// (chunk ^ ((row>>1)&7)) is applied to the per-lane SOURCE address and again on the read.
+// Per K-step a wave issues 24 ds_read_b128 for 64 MFMAs (the 128x128 kernel: 16 for 32).
+constexpr int LBM = 256, LBN = 256;
+constexpr int LTILE = LBM * ROWB;  // 32 KiB per operand tile
+constexpr int LSMEM = 4 * LTILE;   // 128 KiB
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+template <typename T, typename OutT>
+__global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][W tile | A tile]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int nblocks = p.tiles_m * p.tiles_n;
+    int id;
+    {
+        const int bid = blockIdx.x;
+        const int q = nblocks >> 3, r = nblocks & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int group_size = GROUP_M * p.tiles_n;
+    const int group = id / group_size;
+    const int first_m = group * GROUP_M;
+    const int gm = min(p.tiles_m - first_m, GROUP_M);
+    const int in_group = id - group * group_size;
+    const int tile_m = first_m + in_group % gm;
+    const int tile_n = in_group / gm;
+    const int m0 = tile_m * LBM, n0 = tile_n * LBN;
+
+    // staging: pass i covers rows 64*i + 8*wave + (lane>>3); lane's physical chunk is lane&7
+    const char* gW[4];
+    const char* gA[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 64 * i + 8 * wave + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        gW[i] = p.W + (int64_t)min(n0 + row, p.N - 1) * p.ldw_b + c * 16;
+        gA[i] = p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda_b + c * 16;
+    }
+    auto stage = [&](int kt, int buf) {
+        const int64_t kb = (int64_t)kt * ROWB;
+        char* base = smem + buf * (2 * LTILE) + wave * (8 * ROWB);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gW[i] + kb), (lds_ptr_t)(base + i * 64 * ROWB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gA[i] + kb), (lds_ptr_t)(base + LTILE + i * 64 * ROWB), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][8];  // [n tile i][m tile j]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15;
+    const int fsw = (lane >> 1) & 7;
+    const int fq = lane >> 4;
+    const int nk = p.K * (int)sizeof(T) / ROWB;
+
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        const char* wb = smem + (kt & 1) * (2 * LTILE) + (wn * 64 + frow) * ROWB;
+        const char* ab = smem + (kt & 1) * (2 * LTILE) + LTILE + (wm * 128 + frow) * ROWB;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int coff = ((fq + 4 * kk) ^ fsw) << 4;
+            typename Mma<T>::Frag fw[4], fx[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fw[i] = *reinterpret_cast<const typename Mma<T>::Frag*>(wb + i * 16 * ROWB + coff);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fx[j] = *reinterpret_cast<const typename Mma<T>::Frag*>(ab + j * 16 * ROWB + coff);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) Mma<T>::run(fw[i], fx[j], acc[i][j]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    const bool vec = p.vec_ok != 0;
+    int64_t coff_dev = p.c_offset;
+    if (p.c_offset_dev) coff_dev += *p.c_offset_dev;
+    EpiCol cols[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cols[i] = epi_col(p, n0 + wn * 64 + 16 * i + 4 * fq);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const EpiRow row = epi_row(p, m0 + wm * 128 + 16 * j + frow, coff_dev);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) epilogue4<OutT>(p, acc[i][j], row, cols[i], vec);
+    }
+}
+
+template <typename T, typename OutT>
+int launch256(GemmParams p, hipStream_t s) {
+    p.tiles_m = (p.M + LBM - 1) / LBM;
+    p.tiles_n = (p.N + LBN - 1) / LBN;
+    hipLaunchKernelGGL((gemm_nt256_kernel<T, OutT>), dim3(p.tiles_m * p.tiles_n), dim3(512), LSMEM, s, p);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
 constexpr int SMEM_BYTES = 4 * TILE_BYTES;  // 64 KiB
 
 // Raise the dynamic-LDS limit of every instantiation once, outside any stream capture.
@@ -368,6 +516,14 @@ int init_attrs() {
                               reinterpret_cast<const void*>(&gemm_nt_kernel<float, float>)};
         for (const void* f : fns) {
             const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+            if (e != hipSuccess) err = e;
+        }
+        const void* big[4] = {reinterpret_cast<const void*>(&gemm_nt256_kernel<__bf16, __bf16>),
+                              reinterpret_cast<const void*>(&gemm_nt256_kernel<__bf16, float>),
+                              reinterpret_cast<const void*>(&gemm_nt256_kernel<float, __bf16>),
+                              reinterpret_cast<const void*>(&gemm_nt256_kernel<float, float>)};
+        for (const void* f : big) {
+            const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LSMEM);
             if (e != hipSuccess) err = e;
         }
     });
@@ -435,6 +591,16 @@ extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
         if (d->in_dtype == WIPA_BF16)
             return d->out_dtype == WIPA_BF16 ? launch_skinny<__bf16, __bf16>(p, s) : launch_skinny<__bf16, float>(p, s);
         return launch_skinny<float, float>(p, s);
+    }
+    static const int force_tile = [] {
+        const char* e = getenv("WIPA_GEMM_TILE");  // debugging / A-B timing: 128 or 256
+        return e ? atoi(e) : 0;
+    }();
+    const bool big = force_tile == 256 || (force_tile != 128 && d->M >= 1024 && d->N >= 256);
+    if (big) {
+        if (d->in_dtype == WIPA_BF16)
+            return d->out_dtype == WIPA_BF16 ? launch256<__bf16, __bf16>(p, s) : launch256<__bf16, float>(p, s);
+        return d->out_dtype == WIPA_BF16 ? launch256<float, __bf16>(p, s) : launch256<float, float>(p, s);
     }
     if (d->in_dtype == WIPA_BF16) {
         return d->out_dtype == WIPA_BF16 ? launch<__bf16, __bf16>(p, s) : launch<__bf16, float>(p, s);

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .runtime import on_stream, ptr, sptr
+from .runtime import on_stream, ptr, sptr, stream, stream_id
 from .tokenizer import Tokenizer, get_tokenizer
 
 
@@ -106,13 +106,17 @@ class DecoderState:
 
 
 def _state_for(model, B: int) -> DecoderState:
-    st = getattr(model, "_dec_state", None)
+    """one decode blob per (model, library stream); re-made when the batch or dtype changes"""
+    states = model.__dict__.setdefault("_dec_states", {})
+    sid = stream_id()
+    st = states.get(sid)
     if st is None or st.B != B or st.blob.device != model.device or st.cfg_dtype != model.dtype:
         if st is not None:
+            stream().synchronize()
             st.release()
         st = DecoderState(model, B)
         st.cfg_dtype = model.dtype
-        model._dec_state = st
+        states[sid] = st
     return st
 
 
@@ -124,10 +128,54 @@ def _mask(model, ids: Sequence[int]) -> torch.Tensor:
         host = torch.zeros(model.dims.n_vocab, dtype=torch.float32)
         if key:
             host[list(key)] = float("-inf")
-        with on_stream():
+        with on_stream() as s:
             m = host.to(model.device)
+        s.synchronize()  # masks are shared by every library stream
         cache[key] = m
     return m
+
+
+@dataclass
+class GreedyHandle:
+    state: "DecoderState"
+    stream: torch.cuda.Stream
+    n_init: int
+    steps: int  # decoder steps enqueued (prompt positions included)
+    keep: tuple = ()  # tensors that must outlive the enqueued work
+
+
+def greedy_launch(model, audio_features: torch.Tensor, initial_tokens: Sequence[int], suppress_always: Sequence[int],
+                  suppress_first: Sequence[int], eot: int, max_new_tokens: int, use_graph: bool = True) -> GreedyHandle:
+    """Enqueue cross-KV projection + a FIXED number of decoder steps on the current library
+    stream and return without synchronising (EOT rows are latched on the device, so running
+    past the end of a row is harmless).  Pair with greedy_collect()."""
+    L = _lib.lib()
+    pk = model.packed()
+    B = audio_features.shape[0]
+    n_init = len(initial_tokens)
+    max_new_tokens = min(max_new_tokens, model.dims.n_text_ctx - n_init)
+    m_always = _mask(model, suppress_always)
+    m_first = _mask(model, list(suppress_always) + list(suppress_first))
+    init = (C.c_int32 * n_init)(*[int(t) for t in initial_tokens])
+    total = (n_init - 1) + max_new_tokens
+    with on_stream() as s:
+        st = _state_for(model, B)
+        feats = audio_features.to(device=model.device, dtype=model.dtype).contiguous()
+        _lib.check(L.wipa_decoder_set_audio(C.byref(pk["cfg"]), pk["dec_tab"], ptr(feats), ptr(st.blob), B, sptr(s)),
+                   "wipa_decoder_set_audio")
+        _lib.check(L.wipa_decoder_begin(C.byref(pk["cfg"]), ptr(st.blob), B, init, n_init, sptr(s)), "wipa_decoder_begin")
+        _lib.check(L.wipa_decoder_run(C.byref(pk["cfg"]), pk["dec_tab"], ptr(st.blob), B, n_init, eot, ptr(m_first),
+                                      ptr(m_always), total, int(use_graph), sptr(s)), "wipa_decoder_run")
+    return GreedyHandle(st, s, n_init, total, (feats, m_always, m_first))
+
+
+def greedy_collect(h: GreedyHandle) -> GreedyTokens:
+    """Wait for a greedy_launch() and bring the token ids to the host."""
+    with torch.cuda.stream(h.stream):
+        toks = h.state.tokens[:, : h.steps + 1].cpu().numpy().astype(np.int64)
+        slp = h.state.sum_logprobs.cpu().numpy().copy()
+    h.stream.synchronize()
+    return GreedyTokens(toks, h.steps - (h.n_init - 1), slp, h.state.logits)
 
 
 def greedy_decode_tokens(model, audio_features: torch.Tensor, initial_tokens: Sequence[int], suppress_always: Sequence[int],

@@ -1,12 +1,18 @@
-"""Plumbing shared by the Python host side: the library stream, dtype codes, pointers.
+"""Plumbing shared by the Python host side: library streams, dtype codes, pointers.
 
 torch is used for device memory, streams and (later) autograd glue only; every
 computation on the path goes through libwipa.so.
+
+Streams: all libwipa work runs on dedicated non-default HIP streams (graph capture needs
+one).  Stream 0 is the default library stream; ``use_stream(i)`` selects another one for a
+block of code so independent clip sub-batches can run concurrently (the compute-bound
+encoder of one sub-batch overlaps the HBM/latency-bound decode loop of another).
 """
 from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import threading
 from typing import Optional
 
 import torch
@@ -14,6 +20,7 @@ import torch
 from . import _lib
 
 _streams = {}
+_tls = threading.local()
 
 
 def device() -> torch.device:
@@ -22,27 +29,53 @@ def device() -> torch.device:
     return torch.device("cuda", torch.cuda.current_device())
 
 
-def stream(dev: Optional[torch.device] = None) -> torch.cuda.Stream:
-    """One dedicated (non-default, capturable) HIP stream per device for all libwipa work."""
-    dev = dev or device()
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
+def stream_id() -> int:
+    return getattr(_tls, "sid", 0)
+
+
+def stream(sid: Optional[int] = None) -> torch.cuda.Stream:
+    """The library stream ``sid`` (default: the one selected by use_stream, else 0) of the
+    current device."""
+    sid = stream_id() if sid is None else sid
+    key = (torch.cuda.current_device(), sid)
     s = _streams.get(key)
     if s is None:
-        s = torch.cuda.Stream(device=key)
+        s = torch.cuda.Stream(device=key[0])
         _streams[key] = s
     return s
 
 
 @contextlib.contextmanager
+def use_stream(sid: int):
+    """Run the enclosed libwipa calls on library stream ``sid`` WITHOUT ordering them against
+    the caller's stream or other library streams (the caller synchronises, e.g. through
+    decoding.greedy_collect)."""
+    prev = (getattr(_tls, "sid", 0), getattr(_tls, "detached", False))
+    _tls.sid, _tls.detached = sid, True
+    try:
+        with torch.cuda.stream(stream(sid)):
+            yield stream(sid)
+    finally:
+        _tls.sid, _tls.detached = prev
+
+
+@contextlib.contextmanager
 def on_stream():
-    """Run torch allocations/copies and libwipa launches on the library stream, ordered
-    after the caller's stream on entry and before it on exit."""
+    """Run torch allocations/copies and libwipa launches on the current library stream.
+    Outside use_stream() the work is ordered after the caller's stream on entry and the
+    caller's stream waits for it on exit."""
     s = stream()
+    if getattr(_tls, "detached", False):
+        with torch.cuda.stream(s):
+            yield s
+        return
     cur = torch.cuda.current_stream()
-    s.wait_stream(cur)
+    if cur != s:
+        s.wait_stream(cur)
     with torch.cuda.stream(s):
         yield s
-    cur.wait_stream(s)
+    if cur != s:
+        cur.wait_stream(s)
 
 
 def dt_code(dtype: torch.dtype) -> int:

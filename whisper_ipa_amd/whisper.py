@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 from .audio import N_FRAMES, PADDED_FRAMES, padded_mel_rows
-from .runtime import device, dt_code, on_stream, ptr, ptr_table, sptr
+from .runtime import device, dt_code, on_stream, ptr, ptr_table, sptr, stream, stream_id
 
 
 @dataclass
@@ -95,8 +95,8 @@ class Whisper:
         self._params: Dict[str, torch.Tensor] = {}
         self._frozen = set()
         self._packed = None
-        self._enc_ws: Dict[int, torch.Tensor] = {}
-        self._tf_ws = None
+        self._enc_ws: Dict[int, torch.Tensor] = {}  # per library stream
+        self._tf_ws: Dict[int, torch.Tensor] = {}
         self.encoder = _Part(self, "encoder")
         self.decoder = _Part(self, "decoder")
         self.training = False
@@ -222,6 +222,7 @@ class Whisper:
                         mat(P[f"{p}.mlp2.weight"]), vec(P[f"{p}.mlp2.bias"])]
         assert len(enc) == _lib.ENC_GLOBAL + _lib.ENC_PER_LAYER * d.n_audio_layer
         assert len(dec) == _lib.DEC_GLOBAL + _lib.DEC_PER_LAYER * d.n_text_layer
+        stream().synchronize()  # the tables are read from every library stream
         self._packed = dict(cfg=self._cfg(), enc=enc, dec=dec, enc_tab=ptr_table(enc), dec_tab=ptr_table(dec))
         return self._packed
 
@@ -232,11 +233,11 @@ class Whisper:
         pk = self.packed()
         assert mel_padded.dtype == self.dtype and mel_padded.shape[0] >= padded_mel_rows(B)
         with on_stream() as s:
-            ws = self._enc_ws.get(B)
-            if ws is None:
-                self._enc_ws.clear()
-                ws = torch.empty(L.wipa_encoder_workspace_bytes(C.byref(pk["cfg"]), B), dtype=torch.uint8, device=self.device)
-                self._enc_ws[B] = ws
+            need = L.wipa_encoder_workspace_bytes(C.byref(pk["cfg"]), B)
+            ws = self._enc_ws.get(stream_id())
+            if ws is None or ws.numel() < need:
+                ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                self._enc_ws[stream_id()] = ws
             out = torch.empty(B, self.dims.n_audio_ctx, self.dims.n_audio_state, dtype=self.dtype, device=self.device)
             _lib.check(L.wipa_encoder_forward(C.byref(pk["cfg"]), pk["enc_tab"], ptr(mel_padded), ptr(out), ptr(ws), ws.numel(),
                                               B, sptr(s)), "wipa_encoder_forward")
@@ -268,11 +269,13 @@ class Whisper:
             tok = tokens.to(device=self.device, dtype=torch.int32).contiguous()
             feats = audio_features.to(device=self.device, dtype=self.dtype).contiguous()
             need = L.wipa_decoder_logits_workspace_bytes(C.byref(pk["cfg"]), B, T)
-            if self._tf_ws is None or self._tf_ws.numel() < need:
-                self._tf_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            tf_ws = self._tf_ws.get(stream_id())
+            if tf_ws is None or tf_ws.numel() < need:
+                tf_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                self._tf_ws[stream_id()] = tf_ws
             out = torch.empty(B * T, ldl, dtype=torch.float32, device=self.device)
             _lib.check(L.wipa_decoder_logits(C.byref(pk["cfg"]), pk["dec_tab"], ptr(tok), ptr(feats), ptr(out), ldl,
-                                             ptr(self._tf_ws), self._tf_ws.numel(), B, T, sptr(s)), "wipa_decoder_logits")
+                                             ptr(tf_ws), tf_ws.numel(), B, T, sptr(s)), "wipa_decoder_logits")
         return out.view(B, T, ldl)[:, :, :V]
 
     def __call__(self, mel: torch.Tensor, tokens: torch.Tensor) -> torch.Tensor:
