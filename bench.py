@@ -49,7 +49,9 @@ def host_cores() -> int:
 
 
 BATCH = 64          # clips per GPU
-N_STREAMS = 4       # sub-batches of the 64 clips, one HIP stream each
+N_STREAMS = 1       # sub-batches of the 64 clips, one HIP stream each (measured r01: 1 -> 162 ms,
+                    # 2 -> 156 ms, 4 -> 200 ms, 8 -> 266 ms per pass: the per-step cost of the decode
+                    # loop is launch/latency bound and does not shrink with the sub-batch)
 NEW_TOKENS = 64     # decode positions per clip (SURVEY.md section 8d primary setting)
 HBM_PEAK_GBS = 8000.0
 MFMA_BF16_PEAK_TFLOPS = 2500.0
@@ -165,15 +167,28 @@ def roofline_cross_attn(model, B: int, iters: int = 48):
     per_layer = B * 2 * H * Ta * 64
     kv_all = st.blob[lay.cross_kv: lay.cross_kv + d.n_text_layer * per_layer * e].view(model.dtype).view(
         d.n_text_layer, B, 2 * H, Ta, 64)
+    from whisper_ipa_amd import _lib
+    from whisper_ipa_amd.runtime import dt_code, ptr, sptr
+
+    L = _lib.lib()
     with on_stream():
         q = torch.randn(B, H * 64, device=model.device).to(model.dtype)
+        out = torch.empty_like(q)
         for l in range(d.n_text_layer):
             ops.decode_cross_attn(q, kv_all[l])
         s = stream()
+        s.synchronize()
+        # the launches are captured into a graph so the event pair times the kernels, not the
+        # Python/ctypes launch path (which costs more than the 50 us kernel)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            for i in range(iters):
+                _lib.check(L.wipa_decode_cross_attn(ptr(q), ptr(kv_all[i % d.n_text_layer]), ptr(out), B, H, Ta,
+                                                    dt_code(model.dtype), sptr(s)))
+        graph.replay()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record(s)
-        for i in range(iters):
-            ops.decode_cross_attn(q, kv_all[i % d.n_text_layer])
+        graph.replay()
         ev1.record(s)
         ev1.synchronize()
     ms = ev0.elapsed_time(ev1) / iters

@@ -78,6 +78,7 @@ typedef struct wipa_gemm_desc {
     const int64_t* c_offset_dev;
     int64_t lda, ldw, ldc, ldpos;
     int64_t rg_stride, cg_stride, c_offset;
+    int64_t slab_stride; /* elements between the k_slices partial outputs */
     int32_t M, N, K;
     int32_t in_dtype, out_dtype;
     int32_t rg_in, rg_valid, cg_in;
@@ -86,7 +87,10 @@ typedef struct wipa_gemm_desc {
     int32_t act; /* 0 none, 1 gelu(erf) */
     int32_t col_scale_n;
     float col_scale;
-    int32_t reserved;
+    int32_t k_slices; /* 0/1: whole K.  >1 (M <= 64 only): K is cut into k_slices contiguous slices
+                       * computed by different workgroups; slice z writes its PARTIAL sums (bias in
+                       * slice 0 only, no act/pos/residual) to C + z*slab_stride -- to be summed in a
+                       * fixed order by wipa_add_slabs_layernorm (deterministic split-K). */
 } wipa_gemm_desc;
 int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t s);
 
@@ -94,6 +98,12 @@ int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t s);
  * nn.LayerNorm(eps=1e-5) rows of width D (attn_ln, cross_attn_ln, mlp_ln, ln_post, ln). */
 int wipa_layernorm(const void* x, int x_dtype, int64_t ldx, void* y, int y_dtype, int64_t ldy, const float* w,
                    const float* b, int rows, int D, float eps, wipa_stream_t s);
+
+/* Decode-step fusion: x[r,:] += sum_s slabs[s][r,:] (fixed order s = 0..n_slabs-1; x f32, in place),
+ * then y = LayerNorm(x).  slabs are the k_slices partial outputs of the preceding residual GEMM. */
+int wipa_add_slabs_layernorm(float* x, int64_t ldx, const float* slabs, int n_slabs, int64_t slab_stride, void* y,
+                             int y_dtype, int64_t ldy, const float* w, const float* b, int rows, int D, float eps,
+                             wipa_stream_t s);
 
 /* ------------------------------------------------------------------ K8 embedding
  * TextDecoder: token_embedding[tokens] + positional_embedding[offset : offset+T].

@@ -221,6 +221,36 @@ def test_gemm_skinny(ops, dtype, out_dtype, M, N, K):
     assert _rel(out[:, :N], ref) < tol
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N,K,S", [(64, 768, 768, 2), (64, 768, 3072, 4), (7, 128, 256, 3), (64, 768, 768, 1)])
+def test_gemm_split_k_slabs_and_fused_layernorm(ops, dtype, M, N, K, S):
+    """deterministic split-K: slice z writes a partial slab (bias in slab 0); the fused kernel adds the
+    slabs to the residual stream in order and applies LayerNorm."""
+    g = torch.Generator().manual_seed(M + N + K + S)
+    A = torch.randn(M, K, generator=g).to(dtype)
+    W = (torch.randn(N, K, generator=g) * 0.05).to(dtype)
+    bias = torch.randn(N, generator=g)
+    x0 = torch.randn(M, N, generator=g)
+    lw, lb = torch.randn(N, generator=g), torch.randn(N, generator=g)
+    slabs = torch.full((S, M, N), float("nan")).cuda()
+    ops.gemm(A.cuda(), W.cuda(), slabs, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, bias=bias.cuda(), k_slices=S, slab_stride=M * N)
+    x = x0.clone().cuda()
+    y = ops.add_slabs_layernorm(x, slabs, lw.cuda(), lb.cuda(), out_dtype=torch.float32)
+    y2 = ops.add_slabs_layernorm(x.clone(), None, lw.cuda(), lb.cuda(), out_dtype=torch.bfloat16)
+    torch.cuda.synchronize()
+    ref_x = x0.double() + A.double() @ W.double().T + bias.double()
+    assert _rel(slabs.sum(0), ref_x - x0.double()) < 2e-5
+    assert _rel(x, ref_x) < 2e-5
+    ref_y = torch.nn.functional.layer_norm(ref_x.float(), (N,), lw, lb, 1e-5)
+    assert _rel(y, ref_y) < 5e-5
+    assert _rel(y2, ref_y) < 1e-2
+    # run-to-run determinism (no atomics)
+    slabs2 = torch.zeros_like(slabs)
+    ops.gemm(A.cuda(), W.cuda(), slabs2, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, bias=bias.cuda(), k_slices=S, slab_stride=M * N)
+    torch.cuda.synchronize()
+    assert torch.equal(slabs, slabs2)
+
+
 def test_embed_tokens(ops):
     g = torch.Generator().manual_seed(1)
     V, D, B, T = 1000, 128, 3, 7

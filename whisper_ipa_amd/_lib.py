@@ -25,12 +25,12 @@ class GemmDesc(C.Structure):
         ("A", c_void_p), ("W", c_void_p), ("C", c_void_p), ("bias", c_void_p), ("residual", c_void_p),
         ("pos", c_void_p), ("c_offset_dev", c_void_p),
         ("lda", c_int64), ("ldw", c_int64), ("ldc", c_int64), ("ldpos", c_int64),
-        ("rg_stride", c_int64), ("cg_stride", c_int64), ("c_offset", c_int64),
+        ("rg_stride", c_int64), ("cg_stride", c_int64), ("c_offset", c_int64), ("slab_stride", c_int64),
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
         ("in_dtype", C.c_int32), ("out_dtype", C.c_int32),
         ("rg_in", C.c_int32), ("rg_valid", C.c_int32), ("cg_in", C.c_int32),
         ("zero_invalid_rows", C.c_int32), ("bias_along_m", C.c_int32), ("act", C.c_int32),
-        ("col_scale_n", C.c_int32), ("col_scale", c_float), ("reserved", C.c_int32),
+        ("col_scale_n", C.c_int32), ("col_scale", c_float), ("k_slices", C.c_int32),
     ]
 
 
@@ -73,6 +73,8 @@ SIGNATURES = {
     "wipa_gemm": (c_int, [_P(GemmDesc), c_void_p]),
     "wipa_layernorm": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_int, c_int,
                                c_float, c_void_p]),
+    "wipa_add_slabs_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_void_p,
+                                         c_void_p, c_int, c_int, c_float, c_void_p]),
     "wipa_embed_tokens": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                   c_int, c_void_p]),
     "wipa_attention": (c_int, [_P(AttnDesc), c_void_p]),

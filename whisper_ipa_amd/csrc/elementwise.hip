@@ -75,6 +75,68 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
     }
 }
 
+// Decode-step variant: ONE workgroup per row (few rows -> spread them over many CUs), fused with
+// the fixed-order sum of the split-K partial slabs of the preceding residual GEMM.
+template <typename TO>
+__global__ __launch_bounds__(256) void add_slabs_layernorm_kernel(float* __restrict__ x, int64_t ldx,
+                                                                   const float* __restrict__ slabs, int n_slabs,
+                                                                   int64_t slab_stride, TO* __restrict__ y, int64_t ldy,
+                                                                   const float* __restrict__ w, const float* __restrict__ b,
+                                                                   int D, float eps) {
+    __shared__ float s_red[4];
+    const int row = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* xr = x + (int64_t)row * ldx;
+    f32x4 v[2];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid * 4 + 1024 * i;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < D) {
+            v[i] = *reinterpret_cast<const f32x4*>(xr + c);
+            for (int s = 0; s < n_slabs; ++s)
+                v[i] += *reinterpret_cast<const f32x4*>(slabs + (int64_t)s * slab_stride + (int64_t)row * ldx + c);
+            if (n_slabs > 0) *reinterpret_cast<f32x4*>(xr + c) = v[i];
+            sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    sum = wave_reduce_sum(sum);
+    if (lane == 0) s_red[wave] = sum;
+    __syncthreads();
+    const float mean = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) / (float)D;
+    __syncthreads();
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid * 4 + 1024 * i;
+        if (c < D) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mean;
+                sq += d * d;
+            }
+        }
+    }
+    sq = wave_reduce_sum(sq);
+    if (lane == 0) s_red[wave] = sq;
+    __syncthreads();
+    const float rstd = rsqrtf(((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) / (float)D + eps);
+    TO* yr = y + (int64_t)row * ldy;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid * 4 + 1024 * i;
+        if (c < D) {
+            const f32x4 ww = *reinterpret_cast<const f32x4*>(w + c);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(b + c);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * ww[e] + bb[e];
+            st4<TO>(yr + c, o);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ embedding
 template <typename TE>
 __global__ __launch_bounds__(256) void embed_kernel(const int32_t* __restrict__ tokens, int64_t ld_tok, int T, int t_start,
@@ -273,6 +335,26 @@ extern "C" int wipa_layernorm(const void* x, int x_dtype, int64_t ldx, void* y, 
     else if (x_dtype == WIPA_BF16 && y_dtype == WIPA_F32) LN_LAUNCH(__bf16, float);
     else WIPA_REQUIRE(false, "wipa_layernorm: bad dtypes %d %d", x_dtype, y_dtype);
 #undef LN_LAUNCH
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+extern "C" int wipa_add_slabs_layernorm(float* x, int64_t ldx, const float* slabs, int n_slabs, int64_t slab_stride, void* y,
+                                        int y_dtype, int64_t ldy, const float* w, const float* b, int rows, int D, float eps,
+                                        wipa_stream_t stream) {
+    WIPA_REQUIRE(x && y && w && b && (slabs || n_slabs == 0), "wipa_add_slabs_layernorm: null pointer");
+    WIPA_REQUIRE(D % 4 == 0 && D > 0 && D <= 2048, "wipa_add_slabs_layernorm: D=%d must be a multiple of 4 and <= 2048", D);
+    WIPA_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && slab_stride % 4 == 0, "wipa_add_slabs_layernorm: strides must be multiples of 4");
+    if (rows <= 0) return WIPA_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (y_dtype == WIPA_F32)
+        hipLaunchKernelGGL((add_slabs_layernorm_kernel<float>), dim3(rows), dim3(256), 0, s, x, ldx, slabs, n_slabs, slab_stride,
+                           (float*)y, ldy, w, b, D, eps);
+    else if (y_dtype == WIPA_BF16)
+        hipLaunchKernelGGL((add_slabs_layernorm_kernel<__bf16>), dim3(rows), dim3(256), 0, s, x, ldx, slabs, n_slabs, slab_stride,
+                           (__bf16*)y, ldy, w, b, D, eps);
+    else
+        WIPA_REQUIRE(false, "wipa_add_slabs_layernorm: bad dtype %d", y_dtype);
     WIPA_LAUNCH_CHECK();
     return WIPA_OK;
 }

@@ -37,6 +37,8 @@ struct GemmParams {
     float col_scale;
     int tiles_m, tiles_n;
     int vec_ok;
+    int k_slices;
+    int64_t slab_stride;
 };
 
 template <typename T>
@@ -301,9 +303,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p) {
     const int frow = lane & 15, fq = lane >> 4;
     const int n0 = blockIdx.x * (16 * NT);
     const int m0 = blockIdx.y * (16 * MT);
-    const int ksteps = p.K * (int)sizeof(T) / 64;  // 64 bytes of K per MFMA fragment step
+    const int ksteps_all = p.K * (int)sizeof(T) / 64;  // 64 bytes of K per MFMA fragment step
+    // split-K: workgroup slice blockIdx.z of k_slices, then the NW waves of the workgroup
+    const int kz = blockIdx.z, S = p.k_slices;
+    const int s_per = ksteps_all / S, s_rem = ksteps_all % S;
+    const int s_beg = kz * s_per + min(kz, s_rem);
+    const int ksteps = s_per + (kz < s_rem ? 1 : 0);
     const int per = ksteps / NW, rem = ksteps % NW;
-    const int kb = wave * per + min(wave, rem);
+    const int kb = s_beg + wave * per + min(wave, rem);
     const int ke = kb + per + (wave < rem ? 1 : 0);
     const char* wp[NT];
     const char* xp[MT];
@@ -334,6 +341,24 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p) {
 #pragma unroll
                 for (int j = 0; j < MT; ++j) Mma<T>::run(fw[u][i], fx[u][j], acc[i][j]);
     }
+    constexpr int UB2 = 3;  // mid-size batch so a 3..5-step slice still has all its loads in flight together
+    for (; ks + UB2 <= ke; ks += UB2) {
+        Frag fw[UB2][NT], fx[UB2][MT];
+#pragma unroll
+        for (int u = 0; u < UB2; ++u) {
+            const int64_t off = (int64_t)(ks + u) * 64;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) fw[u][i] = *reinterpret_cast<const Frag*>(wp[i] + off);
+#pragma unroll
+            for (int j = 0; j < MT; ++j) fx[u][j] = *reinterpret_cast<const Frag*>(xp[j] + off);
+        }
+#pragma unroll
+        for (int u = 0; u < UB2; ++u)
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j) Mma<T>::run(fw[u][i], fx[u][j], acc[i][j]);
+    }
     for (; ks < ke; ++ks) {
         const int64_t off = (int64_t)ks * 64;
         Frag fw[NT], fx[MT];
@@ -350,8 +375,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p) {
     for (int t = 0; t < NT * MT; ++t) red[wave][t][lane] = acc[t / MT][t % MT];
     __syncthreads();
     const bool vec = p.vec_ok != 0;
-    int64_t coff_dev = p.c_offset;
+    int64_t coff_dev = p.c_offset + (int64_t)kz * p.slab_stride;
     if (p.c_offset_dev) coff_dev += *p.c_offset_dev;
+    if (kz > 0) p.bias = nullptr;  // partial slabs: the bias rides on slice 0 only
     for (int t = wave; t < NT * MT; t += NW) {
         f32x4 s = red[0][t][lane];
 #pragma unroll
@@ -363,7 +389,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p) {
 
 template <typename T, typename OutT, int MT, int NT, int NW>
 int launch_skinny_cfg(const GemmParams& p, hipStream_t s) {
-    dim3 grid((p.N + 16 * NT - 1) / (16 * NT), (p.M + 16 * MT - 1) / (16 * MT));
+    dim3 grid((p.N + 16 * NT - 1) / (16 * NT), (p.M + 16 * MT - 1) / (16 * MT), p.k_slices);
     hipLaunchKernelGGL((gemm_skinny_kernel<T, OutT, MT, NT, NW>), grid, dim3(NW * 64), 0, s, p);
     WIPA_LAUNCH_CHECK();
     return WIPA_OK;
@@ -371,7 +397,7 @@ int launch_skinny_cfg(const GemmParams& p, hipStream_t s) {
 
 template <typename T, typename OutT, int MT>
 int launch_skinny_mt(const GemmParams& p, hipStream_t s) {
-    const int ksteps = p.K * (int)sizeof(T) / 64;
+    const int ksteps = p.K * (int)sizeof(T) / 64 / p.k_slices;
     if (p.N >= 8192) return launch_skinny_cfg<T, OutT, MT, 2, 4>(p, s);
     if (ksteps >= 64) return launch_skinny_cfg<T, OutT, MT, 1, 8>(p, s);
     return launch_skinny_cfg<T, OutT, MT, 1, 4>(p, s);
@@ -577,6 +603,14 @@ extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
     p.col_scale = d->col_scale;
     p.tiles_m = (d->M + BM - 1) / BM;
     p.tiles_n = (d->N + BN - 1) / BN;
+    p.k_slices = d->k_slices > 1 ? d->k_slices : 1;
+    p.slab_stride = d->slab_stride;
+    if (p.k_slices > 1) {
+        WIPA_REQUIRE(d->M <= SKINNY_MAX_M, "wipa_gemm: k_slices needs M <= %d (M=%d)", SKINNY_MAX_M, d->M);
+        WIPA_REQUIRE(!d->residual && !d->pos && d->act == 0 && d->col_scale_n == 0,
+                     "wipa_gemm: k_slices writes partial sums: no residual/pos/act/col_scale");
+        WIPA_REQUIRE(p.k_slices <= 16 && d->slab_stride % 4 == 0, "wipa_gemm: bad k_slices / slab_stride");
+    }
     const int64_t osz = (int64_t)wipa_dtype_size(d->out_dtype);
     const int64_t valign = 16 / osz == 4 ? 4 : 4;  // 4 consecutive outputs per store
     p.vec_ok = (p.ldc % valign == 0) && (p.rg_stride % valign == 0) && (p.cg_stride % valign == 0) &&
@@ -596,7 +630,8 @@ extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
         const char* e = getenv("WIPA_GEMM_TILE");  // debugging / A-B timing: 128 or 256
         return e ? atoi(e) : 0;
     }();
-    const bool big = force_tile == 256 || (force_tile != 128 && d->M >= 1024 && d->N >= 256);
+    const bool big = force_tile == 256 ||
+                     (force_tile != 128 && d->M >= 512 && d->N >= 256 && (int64_t)d->M * d->N >= (1 << 20));
     if (big) {
         if (d->in_dtype == WIPA_BF16)
             return d->out_dtype == WIPA_BF16 ? launch256<__bf16, __bf16>(p, s) : launch256<__bf16, float>(p, s);

@@ -168,9 +168,16 @@ extern "C" int wipa_encoder_forward(const wipa_model_cfg* cfg, const void* const
 // ------------------------------------------------------------------ decoder state
 namespace {
 
+constexpr int MAX_SLABS = 4;
 struct DecScratch {
-    size_t x, ln, q, ao, h, posd, total;
+    size_t x, ln, q, ao, h, slabs, posd, total;
 };
+// split-K factor of a decode-step residual GEMM: keep >= 3 fragment steps per wave (4 waves)
+inline int k_slices_for(int K, int dtype) {
+    const int ksteps = K * (int)wipa_dtype_size(dtype) / 64;
+    int s = ksteps / 12;
+    return s < 1 ? 1 : (s > MAX_SLABS ? MAX_SLABS : s);
+}
 DecScratch dec_scratch(const wipa_model_cfg* c, int B) {
     const size_t e = wipa_dtype_size(c->dtype), d = c->n_text_state;
     DecScratch s;
@@ -180,6 +187,7 @@ DecScratch dec_scratch(const wipa_model_cfg* c, int B) {
     s.q = o;    o += align256((size_t)B * d * e);
     s.ao = o;   o += align256((size_t)B * d * e);
     s.h = o;    o += align256((size_t)B * 4 * d * e);
+    s.slabs = o; o += align256((size_t)MAX_SLABS * B * d * 4);
     s.posd = o; o += 256;
     s.total = o;
     return s;
@@ -235,12 +243,32 @@ int enqueue_step(const wipa_model_cfg* cfg, const void* const* w, char* st, cons
     int64_t* posd = (int64_t*)(sc + S.posd);
     int32_t* tokens = (int32_t*)(st + L.tokens);
     int32_t* pos = (int32_t*)(st + L.pos);
+    // Residual GEMMs (out, cross.out, mlp2) are split along K over workgroups; each slice writes a
+    // partial slab and the NEXT LayerNorm kernel adds the slabs to x in a fixed order first
+    // (deterministic split-K, no atomics).  `pend` = slabs waiting to be folded into x.
+    float* slabs = (float*)(sc + S.slabs);
+    const int64_t slab_stride = (int64_t)B * d;
+    int pend = 0;
+    auto ln_step = [&](const void* lw_w, const void* lw_b) -> int {
+        const int rc = wipa_add_slabs_layernorm(x, d, slabs, pend, slab_stride, ln, dt, d, (const float*)lw_w, (const float*)lw_b,
+                                                B, d, 1e-5f, stream);
+        pend = 0;
+        return rc;
+    };
+    auto residual_gemm = [&](const void* A, int K, const void* W, const void* bias) -> int {
+        wipa_gemm_desc g;
+        memset(&g, 0, sizeof(g));
+        g.k_slices = B <= 64 ? k_slices_for(K, dt) : 1;  // split-K lives in the skinny (M <= 64) kernel
+        g.slab_stride = slab_stride;
+        pend = g.k_slices;
+        return gemm(A, K, W, K, slabs, d, B, d, K, dt, WIPA_F32, (const float*)bias, 0, nullptr, stream, &g);
+    };
     RT_CALL(wipa_embed_tokens(tokens, L.ld_tok, B, 1, 0, pos, w[0], dt, (const float*)w[1], x, d, stream));
     for (int l = 0; l < cfg->n_text_layer; ++l) {
         const void* const* lw = w + WIPA_DEC_GLOBAL + WIPA_DEC_PER_LAYER * l;
         char* skv = st + L.self_kv + (size_t)l * 3 * B * nctx * d * e;  // [3][B][nctx][d]
         char* ckv = st + L.cross_kv + (size_t)l * B * 2 * H * Ta * 64 * e;
-        RT_CALL(wipa_layernorm(x, WIPA_F32, d, ln, dt, d, (const float*)lw[0], (const float*)lw[1], B, d, 1e-5f, stream));
+        RT_CALL(ln_step(lw[0], lw[1]));
         {
             // q|k|v of this position -> slot[n / d][b][pos][n % d]
             wipa_gemm_desc g;
@@ -264,8 +292,8 @@ int enqueue_step(const wipa_model_cfg* cfg, const void* const* w, char* st, cons
             a.B = B; a.H = H; a.Tq = 1; a.Tk = 1; a.causal = 0; a.dtype = dt;
             RT_CALL(wipa_decode_attn(&a, stream));
         }
-        RT_CALL(gemm(ao, d, lw[4], d, x, d, B, d, d, dt, WIPA_F32, (const float*)lw[5], 0, x, stream));
-        RT_CALL(wipa_layernorm(x, WIPA_F32, d, ln, dt, d, (const float*)lw[6], (const float*)lw[7], B, d, 1e-5f, stream));
+        RT_CALL(residual_gemm(ao, d, lw[4], lw[5]));
+        RT_CALL(ln_step(lw[6], lw[7]));
         {
             wipa_gemm_desc g;
             memset(&g, 0, sizeof(g));
@@ -273,12 +301,12 @@ int enqueue_step(const wipa_model_cfg* cfg, const void* const* w, char* st, cons
             RT_CALL(gemm(ln, d, lw[8], d, q, d, B, d, d, dt, dt, (const float*)lw[9], 0, nullptr, stream, &g));
         }
         RT_CALL(wipa_decode_cross_attn(q, ckv, ao, B, H, Ta, dt, stream));
-        RT_CALL(gemm(ao, d, lw[12], d, x, d, B, d, d, dt, WIPA_F32, (const float*)lw[13], 0, x, stream));
-        RT_CALL(wipa_layernorm(x, WIPA_F32, d, ln, dt, d, (const float*)lw[14], (const float*)lw[15], B, d, 1e-5f, stream));
+        RT_CALL(residual_gemm(ao, d, lw[12], lw[13]));
+        RT_CALL(ln_step(lw[14], lw[15]));
         RT_CALL(gemm(ln, d, lw[16], d, hb, 4 * d, B, 4 * d, d, dt, dt, (const float*)lw[17], 1, nullptr, stream));
-        RT_CALL(gemm(hb, 4 * d, lw[18], 4 * d, x, d, B, d, 4 * d, dt, WIPA_F32, (const float*)lw[19], 0, x, stream));
+        RT_CALL(residual_gemm(hb, 4 * d, lw[18], lw[19]));
     }
-    RT_CALL(wipa_layernorm(x, WIPA_F32, d, ln, dt, d, (const float*)w[2], (const float*)w[3], B, d, 1e-5f, stream));
+    RT_CALL(ln_step(w[2], w[3]));
     float* logits = (float*)(st + L.logits);
     RT_CALL(gemm(ln, d, w[0], d, logits, L.ld_logits, B, cfg->n_vocab, d, dt, WIPA_F32, nullptr, 0, nullptr, stream));
     RT_CALL(wipa_greedy_step(logits, L.ld_logits, B, cfg->n_vocab, mask_first, mask_always, tokens, L.ld_tok, pos, n_init,

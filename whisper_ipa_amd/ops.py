@@ -17,7 +17,7 @@ def gemm(A: torch.Tensor, W: torch.Tensor, C_out: torch.Tensor, *, M: int, N: in
          residual: Optional[torch.Tensor] = None, pos: Optional[torch.Tensor] = None, ldpos: int = 0,
          col_scale_n: int = 0, col_scale: float = 1.0, rg_in: int = 0, rg_valid: int = 0, rg_stride: int = 0,
          cg_in: int = 0, cg_stride: int = 0, c_offset: int = 0, c_offset_dev: Optional[torch.Tensor] = None,
-         zero_invalid_rows: bool = False) -> torch.Tensor:
+         zero_invalid_rows: bool = False, k_slices: int = 0, slab_stride: int = 0) -> torch.Tensor:
     """C = epilogue(A @ W^T); see wipa_gemm in include/wipa.h for the addressing rules."""
     L = _lib.lib()
     d = _lib.GemmDesc()
@@ -31,6 +31,7 @@ def gemm(A: torch.Tensor, W: torch.Tensor, C_out: torch.Tensor, *, M: int, N: in
     d.rg_in, d.rg_valid, d.cg_in = rg_in, rg_valid, cg_in
     d.zero_invalid_rows, d.bias_along_m, d.act = int(zero_invalid_rows), int(bias_along_m), act
     d.col_scale_n, d.col_scale = col_scale_n, col_scale
+    d.k_slices, d.slab_stride = k_slices, slab_stride
     with on_stream() as s:
         _lib.check(L.wipa_gemm(C.byref(d), sptr(s)), "wipa_gemm")
     return C_out
@@ -53,6 +54,20 @@ def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out_dtype: Opti
         y = torch.empty(rows, D, dtype=out_dtype or x.dtype, device=x.device)
         _lib.check(L.wipa_layernorm(ptr(x), dt_code(x.dtype), x.stride(0), ptr(y), dt_code(y.dtype), D, ptr(w), ptr(b),
                                     rows, D, eps, sptr(s)), "wipa_layernorm")
+    return y
+
+
+def add_slabs_layernorm(x: torch.Tensor, slabs: Optional[torch.Tensor], w: torch.Tensor, b: torch.Tensor,
+                        out_dtype: torch.dtype = torch.float32, eps: float = 1e-5) -> torch.Tensor:
+    """x [rows, D] f32 (updated in place: += slabs.sum(0) in slab order), slabs [S, rows, D] f32 -> LN(x)."""
+    L = _lib.lib()
+    rows, D = x.shape
+    S = 0 if slabs is None else slabs.shape[0]
+    with on_stream() as s:
+        y = torch.empty(rows, D, dtype=out_dtype, device=x.device)
+        _lib.check(L.wipa_add_slabs_layernorm(ptr(x), x.stride(0), ptr(slabs), S, (slabs.stride(0) if S else 0), ptr(y),
+                                              dt_code(out_dtype), D, ptr(w), ptr(b), rows, D, eps, sptr(s)),
+                   "wipa_add_slabs_layernorm")
     return y
 
 
