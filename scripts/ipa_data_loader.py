@@ -1,0 +1,82 @@
+"""IPA dataset / batch builder with the surface of the reference's scripts/ipa_data_loader.py
+(``IPADataset`` :17-131, ``create_data_loader`` :134-157), on top of whisper_ipa_amd.
+
+Same JSON schema (``audio_path``, ``ipa_transcription``, ``speaker_id``, ``dataset_source``), same
+batch dict keys (``mel_features [B,3000,n_mels]``, ``tokens [B,T]``, ``ipa_texts``, ``audio_paths``),
+same token framing (SOT sequence incl. <|notimestamps|> + BPE(ipa) + EOT, padded with EOT).
+Differences forced by the platform: audio is read as WAV/PCM (no ffmpeg), the log-mel of the
+whole batch is ONE GPU launch, and the returned arrays are torch tensors on the GPU.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+from pathlib import Path
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from whisper_ipa_amd.audio import N_SAMPLES, load_audio, log_mel_spectrogram, pad_or_trim  # noqa: E402
+
+
+class IPADataset:
+    """audio + IPA transcription pairs (reference :17-131)."""
+
+    def __init__(self, json_path: str, tokenizer, n_mels: int = 80, audio_root: str = ""):
+        self.json_path = Path(json_path)
+        self.tokenizer = tokenizer
+        self.n_mels = n_mels
+        self.audio_root = audio_root
+        with open(self.json_path) as f:
+            self.data = json.load(f)
+        print(f"Loaded {len(self.data)} samples from {self.json_path}")
+
+    def __len__(self) -> int:
+        return len(self.data)
+
+    def __getitem__(self, idx: int) -> Dict:
+        entry = self.data[idx]
+        path = entry["audio_path"]
+        audio = load_audio(os.path.join(self.audio_root, path) if self.audio_root else path)
+        return {
+            "audio": audio,
+            "ipa_text": entry["ipa_transcription"],
+            "audio_path": path,
+            "metadata": {"speaker_id": entry.get("speaker_id", "unknown"),
+                         "dataset_source": entry.get("dataset_source", "unknown")},
+        }
+
+    def tokenize_batch(self, ipa_texts: List[str]) -> torch.Tensor:
+        """<|sot|><|en|><|transcribe|><|notimestamps|> ipa <|eot|>, EOT-padded to the longest row."""
+        tok = self.tokenizer
+        rows = [list(tok.sot_sequence_including_notimestamps) + tok.encode(t) + [tok.eot] for t in ipa_texts]
+        width = max(len(r) for r in rows)
+        return torch.tensor([r + [tok.eot] * (width - len(r)) for r in rows], dtype=torch.int32)
+
+    # reference name (ipa_data_loader.py:102)
+    _tokenize_ipa_batch = tokenize_batch
+
+    def get_batch(self, indices: List[int]) -> Dict:
+        samples = [self[i] for i in indices]
+        audio = np.stack([pad_or_trim(s["audio"], N_SAMPLES) for s in samples])
+        mel = log_mel_spectrogram(audio, n_mels=self.n_mels)  # [B, 3000, n_mels] on the GPU, one launch
+        texts = [s["ipa_text"] for s in samples]
+        return {
+            "mel_features": mel,
+            "tokens": self.tokenize_batch(texts).to(mel.device),
+            "ipa_texts": texts,
+            "audio_paths": [s["audio_path"] for s in samples],
+        }
+
+
+def create_data_loader(json_path: str, multilingual: bool = True, n_mels: int = 80, audio_root: str = "") -> IPADataset:
+    from whisper_ipa_amd import tokenizer as tok
+
+    print(f"Loading Whisper tokenizer (multilingual={multilingual})...")
+    tokenizer = tok.get_tokenizer(multilingual=multilingual)
+    tokenizer.language = "en"  # reference :152 (does not change the frozen sot_sequence)
+    return IPADataset(json_path, tokenizer, n_mels=n_mels, audio_root=audio_root)
