@@ -126,6 +126,7 @@ typedef struct wipa_attn_desc {
     void* out;
     const int32_t* tk_dev;
     const int32_t* q_row_dev; /* optional device int: first query row = *q_row_dev (decode step) */
+    float* lse;               /* optional out (wipa_attention only): f32 [B,H,Tq] log-sum-exp of each score row */
     int64_t q_bs, q_rs, q_hs;
     int64_t k_bs, k_rs, k_hs;
     int64_t v_bs, v_rs, v_hs;
@@ -247,6 +248,44 @@ int wipa_decoder_logits(const wipa_model_cfg* cfg, const void* const* weights, c
  * per-row mask*ce and mask; out2[0] = sum(mask*ce), out2[1] = sum(mask) (fixed-order sum). */
 int wipa_masked_ce(const float* logits, int64_t ldl, const int32_t* tokens, int64_t ld_tok, int B, int T, int V, int eot,
                    float* row_buf, float* out2, wipa_stream_t s);
+
+/* ------------------------------------------------------------------ fine-tune step (f32)
+ * Backward of the teacher-forced decoder + masked CE w.r.t. the decoder parameters, i.e. what
+ * nn.value_and_grad(model, loss_fn) computes at scripts/train_whisper_ipa.py:284 with the encoder
+ * frozen (:187), then the per-tensor clip (:287-303) and optim.AdamW (:306,513).  The dense
+ * contractions are wipa_gemm calls on operands transposed by wipa_transpose; all kernels are
+ * deterministic (no float atomics). */
+/* out[c][r] = in[r][c]; out columns rows..rows_pad-1 are written as zero (K padding for wipa_gemm). */
+int wipa_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int rows, int cols, int rows_pad, int dtype,
+                   wipa_stream_t s);
+/* out[c] (+)= sum_r x[r][c]  (bias gradients). */
+int wipa_colsum(const float* x, int64_t ld, int rows, int cols, float* out, int accumulate, wipa_stream_t s);
+/* LayerNorm backward: dx (+)= ..., dw, db; stats f32 [2*rows] scratch (mean, rstd). x, dy, dx contiguous [rows, D]. */
+int wipa_layernorm_bwd(const float* x, const float* dy, const float* w, float* dx, int accumulate_dx, float* dw, float* db,
+                       float* stats, int rows, int D, float eps, wipa_stream_t s);
+/* exact-erf GELU forward / backward on n (multiple of 4) contiguous f32 values. */
+int wipa_gelu(const float* z, float* u, int64_t n, wipa_stream_t s);
+int wipa_gelu_bwd(const float* z, const float* du, float* dz, int64_t n, wipa_stream_t s);
+/* In place: logits[r][v] <- mask_r * (softmax_r[v] - [v == target_r]) / max(count[0], 1).
+ * row_mask = the second half of wipa_masked_ce's row_buf; count = &out2[1] (or its all-reduced value). */
+int wipa_masked_ce_bwd(float* logits, int64_t ldl, const int32_t* tokens, int64_t ld_tok, int B, int T, int V,
+                       const float* row_mask, const float* count, wipa_stream_t s);
+/* d_tok_emb[tokens[r]] += dx[r] (rows visited in order), d_pos_emb[t] = sum_b dx[b*T+t]. tokens_flat int32 [B*T]. */
+int wipa_embed_bwd(const int32_t* tokens_flat, const float* dx, int B, int T, int D, float* d_tok_emb, float* d_pos_emb,
+                   wipa_stream_t s);
+/* Backward of wipa_attention (f32): d is the forward descriptor (q,k,v pre-scaled); out / d_out share the
+ * o_* strides; dq,dk,dv share the q/k/v strides; dvec f32 [B,H,Tq] scratch. dq and dk are multiplied by qk_scale. */
+int wipa_attention_bwd(const wipa_attn_desc* d, const float* out, const float* d_out, const float* lse, float* dq, float* dk,
+                       float* dv, float* dvec, float qk_scale, wipa_stream_t s);
+/* Flat multi-tensor optimiser step: per-tensor g *= min(1, max_norm/(|g|+1e-6)), then mlx-style AdamW
+ * (no bias correction): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p = p (1 - lr wd) - lr m / (sqrt(v)+eps).
+ * Tensors live in flat f32 buffers; a chunk table (<= 4096 elements per chunk, never crossing tensors)
+ * drives the kernels: chunk_off/len/seg [n_chunks], seg_first_chunk [n_seg+1]; partial [n_chunks],
+ * coef/norms [n_seg] are scratch/outputs. */
+int wipa_clip_adamw(float* params, float* grads, float* m, float* v, const int64_t* chunk_off, const int32_t* chunk_len,
+                    const int32_t* chunk_seg, const int32_t* seg_first_chunk, int n_chunks, int n_seg, float* partial,
+                    float* coef, float* norms, float max_norm, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, wipa_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,319 @@
+"""Fine-tune entry point with the CLI, console line and artefacts of the reference's
+scripts/train_whisper_ipa.py (flags :648-709, console line :557-561, CSV columns :105-112,
+checkpoint-N/{model.safetensors,training_state.json} :410-443, best-checkpoint/ :574-588,
+training_config.json :91-99, training_summary.json :625-636) on top of whisper_ipa_amd.
+
+What differs because of the platform: the base model is a LOCAL directory (no hub access); the
+arithmetic is libwipa (HIP) instead of MLX; one process per GPU when launched with
+``python -m torch.distributed.run --nproc-per-node N scripts/train_whisper_ipa.py ...``: rank r takes
+slice r of one shared ``np.random.choice`` draw, the loss normalisation and the gradients are
+all-reduced over RCCL, the per-tensor clip and AdamW run on the reduced gradients
+(whisper_ipa_amd/training.py), rank 0 logs / validates / saves.
+"""
+from __future__ import annotations
+
+import argparse
+import csv
+import json
+import os
+import platform
+import re
+import resource
+import shutil
+import sys
+import time
+from datetime import datetime
+from pathlib import Path
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from evaluate_ipa import evaluate_batch  # noqa: E402
+from ipa_data_loader import create_data_loader  # noqa: E402
+from whisper_ipa_amd import parallel  # noqa: E402
+from whisper_ipa_amd.decoding import DecodingOptions  # noqa: E402
+from whisper_ipa_amd.load_models import load_model, save_safetensors  # noqa: E402
+from whisper_ipa_amd.training import DecoderTrainer  # noqa: E402
+
+
+def flatten_params(params, prefix: str = "") -> Dict[str, torch.Tensor]:
+    flat = {}
+    if isinstance(params, dict):
+        for k, v in params.items():
+            flat.update(flatten_params(v, f"{prefix}{k}."))
+    elif isinstance(params, (list, tuple)):
+        for i, v in enumerate(params):
+            flat.update(flatten_params(v, f"{prefix}{i}."))
+    else:
+        flat[prefix[:-1]] = params
+    return flat
+
+
+def count_parameters(params) -> int:
+    return sum(int(v.numel()) for v in flatten_params(params).values())
+
+
+def get_hardware_info() -> Dict:
+    info = {"platform": platform.platform(), "python": platform.python_version(), "torch": torch.__version__,
+            "cpu_count": os.cpu_count()}
+    if torch.cuda.is_available():
+        p = torch.cuda.get_device_properties(0)
+        info.update({"gpu": p.name, "gpu_memory_gb": round(p.total_memory / 2**30, 1), "n_gpus": torch.cuda.device_count()})
+    return info
+
+
+def save_training_config(output_dir: Path, config: Dict) -> None:
+    with open(output_dir / "training_config.json", "w") as f:
+        json.dump({"config": config, "hardware": get_hardware_info(), "start_time": datetime.now().isoformat()}, f, indent=2)
+
+
+class TrainingLogger:
+    TRAIN_COLUMNS = ["step", "loss", "lr", "step_time_sec", "samples_per_sec", "wall_clock_sec", "timestamp", "peak_memory_mb"]
+    VAL_COLUMNS = ["step", "per", "pfer", "per_std", "pfer_std", "num_samples", "wall_clock_sec", "timestamp"]
+
+    def __init__(self, output_dir: Path):
+        self.train_log_path = output_dir / "training_log.csv"
+        self.val_log_path = output_dir / "validation_log.csv"
+        self.best_pfer, self.best_pfer_step = float("inf"), 0
+        self.latest_val_per = self.latest_val_pfer = None
+        for path, cols in ((self.train_log_path, self.TRAIN_COLUMNS), (self.val_log_path, self.VAL_COLUMNS)):
+            if not path.exists():
+                with open(path, "w", newline="") as f:
+                    csv.writer(f).writerow(cols)
+
+    @staticmethod
+    def _peak_memory_mb() -> float:
+        rss = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+        return rss / (1024 * 1024) if platform.system() == "Darwin" else rss / 1024
+
+    def log_train_step(self, step, loss, lr, step_time, batch_size, wall_clock_sec):
+        with open(self.train_log_path, "a", newline="") as f:
+            csv.writer(f).writerow([step, f"{loss:.6f}", f"{lr:.2e}", f"{step_time:.4f}", f"{batch_size / step_time:.2f}",
+                                    f"{wall_clock_sec:.2f}", datetime.now().isoformat(), f"{self._peak_memory_mb():.1f}"])
+
+    def log_validation(self, step, metrics, wall_clock_sec) -> bool:
+        per, pfer = metrics["per"], metrics["pfer"]
+        self.latest_val_per, self.latest_val_pfer = per, pfer
+        with open(self.val_log_path, "a", newline="") as f:
+            csv.writer(f).writerow([step, f"{per:.4f}", f"{pfer:.4f}", f"{metrics.get('per_std', 0):.4f}",
+                                    f"{metrics.get('pfer_std', 0):.4f}", metrics.get("num_samples", ""),
+                                    f"{wall_clock_sec:.2f}", datetime.now().isoformat()])
+        if pfer < self.best_pfer:
+            self.best_pfer, self.best_pfer_step = pfer, step
+            return True
+        return False
+
+
+def freeze_encoder(model) -> None:
+    print("\nFreezing encoder parameters...")
+    model.encoder.freeze()
+    print("  ✓ Encoder frozen")
+    model.decoder.unfreeze()
+    print("  ✓ Decoder unfrozen (trainable)")
+    trainable, total = count_parameters(model.trainable_parameters()), count_parameters(model.parameters())
+    print(f"\nTrainable parameters: {trainable:,} / {total:,} ({100 * trainable / total:.1f}%)")
+
+
+def train_step(trainer: DecoderTrainer, batch: Dict, tokenizer):
+    """reference :266-311 -> (loss, clipped grads); the arithmetic is DecoderTrainer.train_step."""
+    return trainer.train_step(batch["mel_features"], batch["tokens"], tokenizer.eot)
+
+
+def validate(model, dataset, tokenizer, num_samples: int = 100) -> Dict:
+    """reference :314-407: batched greedy decode (language=None -> detection, fp16=False), PER / PFER."""
+    print(f"\nValidating on {num_samples} samples...")
+    model.eval()
+    references, hypotheses = [], []
+    val_batch_size = 4
+    options = DecodingOptions(language=None, without_timestamps=True, fp16=False, length_penalty=1.0)
+    for i in range((num_samples + val_batch_size - 1) // val_batch_size):
+        indices = list(range(i * val_batch_size, min((i + 1) * val_batch_size, num_samples)))
+        if not indices:
+            break
+        try:
+            batch = dataset.get_batch(indices)
+            results = model.decode(batch["mel_features"], options)
+            if not isinstance(results, list):
+                results = [results]
+            hyps = [r.text.strip() for r in results]
+            refs = [re.sub(r"<\|.*?\|>", "", tokenizer.decode(batch["tokens"][j].tolist())).strip() for j in range(len(indices))]
+            references.extend(refs)
+            hypotheses.extend(hyps)
+            if i == 0:
+                print("\nSample Predictions:")
+                for k in range(min(3, len(refs))):
+                    print(f"  Ref:  [{refs[k]}]\n  Pred: [{hyps[k]}]\n" + "-" * 30)
+        except Exception as e:  # reference :393-396 keeps going
+            print(f"Error during validation decoding: {e}")
+            import traceback
+            traceback.print_exc()
+    metrics = evaluate_batch(references, hypotheses)
+    model.train()
+    print(f"Validation Results:\n  PER:  {metrics['per']:.2f}%\n  PFER: {metrics['pfer']:.2f}%")
+    return metrics
+
+
+def save_checkpoint(model, optimizer, step: int, loss, output_dir: Path, logger: Optional[TrainingLogger] = None,
+                    start_time: Optional[float] = None, learning_rate: Optional[float] = None) -> None:
+    ckpt = output_dir / f"checkpoint-{step}"
+    ckpt.mkdir(parents=True, exist_ok=True)
+    save_safetensors(str(ckpt / "model.safetensors"), flatten_params(model.parameters()))  # ALL weights (reference :421)
+    state = {"step": step, "loss": float(loss.item()) if hasattr(loss, "item") else float(loss)}
+    if start_time is not None:
+        state["wall_clock_sec"] = time.time() - start_time
+    if learning_rate is not None:
+        state["learning_rate"] = learning_rate
+    if logger is not None:
+        state["best_pfer"] = logger.best_pfer if logger.best_pfer != float("inf") else None
+        state["best_pfer_step"] = logger.best_pfer_step
+        state["latest_val_per"] = logger.latest_val_per
+        state["latest_val_pfer"] = logger.latest_val_pfer
+    state["timestamp"] = datetime.now().isoformat()
+    with open(ckpt / "training_state.json", "w") as f:
+        json.dump(state, f, indent=2)
+    print(f"  ✓ Saved checkpoint to {ckpt}")
+
+
+def _init_distributed():
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # RCCL over xGMI
+    return parallel.world()
+
+
+def train(model_name: str, train_data_path: str, test_data_path: str, output_dir: str, num_steps: int = 1000,
+          batch_size: int = 4, learning_rate: float = 1e-5, validate_every: int = 100, save_every: int = 500,
+          test_run: bool = False, audio_root: str = "", seed: Optional[int] = None):
+    rank, world = _init_distributed()
+    main = rank == 0
+    output_dir = Path(output_dir)
+    if main:
+        output_dir.mkdir(parents=True, exist_ok=True)
+        save_training_config(output_dir, dict(model=model_name, train_data=train_data_path, test_data=test_data_path,
+                                              steps=num_steps, batch_size=batch_size, lr=learning_rate,
+                                              validate_every=validate_every, save_every=save_every, test_run=test_run,
+                                              world_size=world))
+    logger = TrainingLogger(output_dir) if main else None
+    print(f"Loading model: {model_name}")
+    t0 = time.time()
+    model = load_model(model_name)
+    model.set_dtype(torch.float32)
+    print(f"  ✓ Model loaded in {time.time() - t0:.1f}s")
+    freeze_encoder(model)
+    trainer = DecoderTrainer(model, lr=learning_rate)  # mlx AdamW defaults (reference :513)
+    n_mels = 128 if "large" in model_name else 80  # reference :517
+    if model.dims.n_mels != n_mels:
+        n_mels = model.dims.n_mels
+    train_dataset = create_data_loader(train_data_path, multilingual=True, n_mels=n_mels, audio_root=audio_root)
+    test_dataset = create_data_loader(test_data_path, multilingual=True, n_mels=n_mels, audio_root=audio_root)
+    tokenizer = train_dataset.tokenizer
+    if test_run:
+        train_dataset.data = train_dataset.data[:100]
+        num_steps = min(num_steps, 100)
+    rng = np.random.default_rng(seed) if seed is not None else np.random.default_rng(int(time.time()) if world == 1 else 0)
+
+    print("\n" + "=" * 70 + f"\nStarting training for {num_steps} steps\n" + "=" * 70)
+    model.train()
+    start_time = time.time()
+    latest_loss = None
+    for step in range(1, num_steps + 1):
+        try:
+            draw = rng.choice(len(train_dataset), size=batch_size, replace=False)  # one shared draw (reference :548)
+            mine = parallel.shard_indices(draw.tolist(), world, rank)
+            batch = train_dataset.get_batch(mine)
+            # all ranks must use one token width: pad to the global maximum with EOT
+            if world > 1:
+                import torch.distributed as dist
+
+                w = torch.tensor([batch["tokens"].shape[1]], device="cuda")
+                dist.all_reduce(w, op=dist.ReduceOp.MAX)
+                pad = int(w.item()) - batch["tokens"].shape[1]
+                if pad:
+                    batch["tokens"] = torch.nn.functional.pad(batch["tokens"], (0, pad), value=tokenizer.eot)
+            step_start = time.time()
+            loss, _ = train_step(trainer, batch, tokenizer)
+            loss_value = float(loss.item())  # device sync, like mx.eval(loss) (reference :309)
+            latest_loss = loss
+            step_time = time.time() - step_start
+            if main and (step % 10 == 0 or step <= 5):
+                print(f"Step {step}/{num_steps} | Loss: {loss_value:.4f} | Time: {step_time:.3f}s | "
+                      f"Samples/sec: {batch_size / step_time:.1f}")
+                logger.log_train_step(step, loss_value, learning_rate, step_time, batch_size, time.time() - start_time)
+            if main and step % validate_every == 0:
+                metrics = validate(model, test_dataset, tokenizer, num_samples=min(100, len(test_dataset)))
+                if logger.log_validation(step, metrics, time.time() - start_time):
+                    best = output_dir / "best-checkpoint"
+                    if best.exists():
+                        shutil.rmtree(best)
+                    best.mkdir(parents=True, exist_ok=True)
+                    save_safetensors(str(best / "model.safetensors"), flatten_params(model.parameters()))
+                    with open(best / "training_state.json", "w") as f:
+                        json.dump({"step": step, "pfer": metrics["pfer"], "per": metrics["per"],
+                                   "timestamp": datetime.now().isoformat()}, f, indent=2)
+                    print(f"  ✓ New best PFER {metrics['pfer']:.2f}% at step {step}")
+            if main and step % save_every == 0:
+                save_checkpoint(model, trainer, step, loss, output_dir, logger=logger, start_time=start_time,
+                                learning_rate=learning_rate)
+        except Exception as e:  # reference :598-602
+            print(f"\n✗ Error at step {step}: {e}")
+            import traceback
+            traceback.print_exc()
+            break
+
+    if main:
+        print("\n" + "=" * 70 + "\nTraining complete! Running final validation...\n" + "=" * 70)
+        metrics = validate(model, test_dataset, tokenizer, num_samples=min(500, len(test_dataset)))
+        logger.log_validation(num_steps, metrics, time.time() - start_time)
+        if latest_loss is not None:
+            print("\nSaving final model...")
+            save_checkpoint(model, trainer, num_steps, latest_loss, output_dir, logger=logger, start_time=start_time,
+                            learning_rate=learning_rate)
+            total = time.time() - start_time
+            with open(output_dir / "training_summary.json", "w") as f:
+                json.dump({"total_wall_clock_sec": total, "total_wall_clock_min": total / 60,
+                           "final_loss": float(latest_loss.item()), "final_per": metrics["per"], "final_pfer": metrics["pfer"],
+                           "best_pfer": logger.best_pfer if logger.best_pfer != float("inf") else None,
+                           "best_pfer_step": logger.best_pfer_step, "end_time": datetime.now().isoformat()}, f, indent=2)
+            print(f"\n✓ Training complete in {total / 60:.1f} minutes")
+            print(f"  Final loss: {float(latest_loss.item()):.4f}\n  Final PER: {metrics['per']:.2f}%\n"
+                  f"  Final PFER: {metrics['pfer']:.2f}%\n  Model saved to: {output_dir}")
+        else:
+            print("\n✗ Training failed - no loss computed")
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main():
+    p = argparse.ArgumentParser(description="Fine-tune Whisper for IPA transcription")
+    p.add_argument("--model", type=str, default="mlx-community/whisper-small-mlx",
+                   help="base model: a LOCAL directory with config.json + weights.safetensors (hub names cannot resolve offline)")
+    p.add_argument("--train-data", type=str, default="data/processed/english_only_train_ipa.json", help="Path to training JSON file")
+    p.add_argument("--test-data", type=str, default="data/processed/english_only_test_ipa.json", help="Path to test JSON file")
+    p.add_argument("--output-dir", type=str, default="checkpoints/whisper-ipa", help="Directory to save checkpoints")
+    p.add_argument("--steps", type=int, default=10000, help="Number of training steps")
+    p.add_argument("--batch-size", type=int, default=12, help="Batch size (global, split over the GPUs)")
+    p.add_argument("--lr", type=float, default=1e-5, help="Learning rate")
+    p.add_argument("--validate-every", type=int, default=1000, help="Validate every N steps")
+    p.add_argument("--save-every", type=int, default=1000, help="Save checkpoint every N steps")
+    p.add_argument("--test-run", action="store_true", help="Test run with only 100 samples")
+    p.add_argument("--audio-root", type=str, default="", help="prefix for the relative audio_path entries of the JSON")
+    a = p.parse_args()
+    train(model_name=a.model, train_data_path=a.train_data, test_data_path=a.test_data, output_dir=a.output_dir,
+          num_steps=a.steps, batch_size=a.batch_size, learning_rate=a.lr, validate_every=a.validate_every,
+          save_every=a.save_every, test_run=a.test_run, audio_root=a.audio_root)
+
+
+if __name__ == "__main__":
+    main()

@@ -220,3 +220,25 @@ def test_shard_bounds_cover_everything():
     named = {f"t{i}": torch.zeros(1000) for i in range(10)}
     buckets = list(bucketed(named, bucket_bytes=12000))
     assert [n for b in buckets for n in b] == list(named) and max(len(b) for b in buckets) == 3
+
+
+def test_evaluate_ipa_tokenisation_known_answers():
+    """the nine assertions of the reference's scripts/evaluate_ipa.py:449-457 + PER examples."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import evaluate_ipa as ev
+
+    assert ev.tokenize_ipa("n̩æp") == ["n̩", "æ", "p"]
+    assert ev.tokenize_ipa("ɾ̃æ") == ["ɾ̃", "æ"]
+    assert ev.tokenize_ipa("ə̥tʃ") == ["ə̥", "t", "ʃ"]
+    assert ev.tokenize_ipa("tʃ") == ["t", "ʃ"]
+    assert ev.tokenize_ipa("ŋ̍") == ["ŋ̍"]
+    assert ev.tokenize_ipa("kæt") == ["k", "æ", "t"]
+    assert ev.tokenize_ipa("m̩") == ["m̩"] and ev.tokenize_ipa("l̩") == ["l̩"] and ev.tokenize_ipa("") == []
+    assert ev.tokenize_ipa("tʰ a") == ["tʰ", "a"]
+    assert ev.phone_error_rate("kæt", "kæt") == 0.0
+    assert abs(ev.phone_error_rate("kæt", "kat") - 100.0 / 3) < 1e-9
+    assert ev.phone_error_rate("", "") == 0.0 and ev.phone_error_rate("", "a") == 100.0
+    assert ev.edit_distance("kitten", "sitting") == 3
+    assert ev.normalize_ipa_for_comparison("g a") == "ɡa"
+    m = ev.evaluate_batch(["kæt", "dɔɡ"], ["kæt", "dɔ"])
+    assert m["num_samples"] == 2 and abs(m["per"] - (0 + 100.0 / 3) / 2) < 1e-9 and "pfer" in m

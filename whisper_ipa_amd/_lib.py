@@ -37,7 +37,7 @@ class GemmDesc(C.Structure):
 class AttnDesc(C.Structure):
     _fields_ = [
         ("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("out", c_void_p), ("tk_dev", c_void_p),
-        ("q_row_dev", c_void_p),
+        ("q_row_dev", c_void_p), ("lse", c_void_p),
         ("q_bs", c_int64), ("q_rs", c_int64), ("q_hs", c_int64),
         ("k_bs", c_int64), ("k_rs", c_int64), ("k_hs", c_int64),
         ("v_bs", c_int64), ("v_rs", c_int64), ("v_hs", c_int64),
@@ -98,6 +98,18 @@ SIGNATURES = {
                                     c_int, c_int, c_void_p]),
     "wipa_masked_ce": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                c_void_p]),
+    "wipa_transpose": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "wipa_colsum": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "wipa_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                   c_float, c_void_p]),
+    "wipa_gelu": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "wipa_gelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "wipa_masked_ce_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "wipa_embed_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "wipa_attention_bwd": (c_int, [_P(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                   c_void_p]),
+    "wipa_clip_adamw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_float, c_float, c_void_p]),
 }
 
 _lib = None

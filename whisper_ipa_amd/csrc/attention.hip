@@ -26,6 +26,7 @@ struct AttnParams {
     char* out;
     const int32_t* tk_dev;
     const int32_t* q_row_dev;
+    float* lse;  // optional [B, H, Tq]: log-sum-exp of every score row (saved for the backward pass)
     int64_t q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, v_bs, v_rs, v_hs, o_bs, o_rs, o_hs;
     int Tq, Tk, causal;
 };
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(AttnParams p) {
     }
     if (qi < p.Tq) {
         const float inv = 1.f / l;
+        if (p.lse && kl == 0) p.lse[((int64_t)b * gridDim.y + h) * p.Tq + qi] = m + __logf(l);
         T* op = reinterpret_cast<T*>(p.out) + b * p.o_bs + (int64_t)qi * p.o_rs + h * p.o_hs;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -425,6 +427,7 @@ extern "C" int wipa_attention(const wipa_attn_desc* d, wipa_stream_t stream) {
     p.out = (char*)d->out;
     p.tk_dev = d->tk_dev;
     p.q_row_dev = d->q_row_dev;
+    p.lse = d->lse;
     p.q_bs = d->q_bs; p.q_rs = d->q_rs; p.q_hs = d->q_hs;
     p.k_bs = d->k_bs; p.k_rs = d->k_rs; p.k_hs = d->k_hs;
     p.v_bs = d->v_bs; p.v_rs = d->v_rs; p.v_hs = d->v_hs;
@@ -461,6 +464,7 @@ static int fill_attn_params(const wipa_attn_desc* d, AttnParams& p) {
     p.out = (char*)d->out;
     p.tk_dev = d->tk_dev;
     p.q_row_dev = d->q_row_dev;
+    p.lse = d->lse;
     p.q_bs = d->q_bs; p.q_rs = d->q_rs; p.q_hs = d->q_hs;
     p.k_bs = d->k_bs; p.k_rs = d->k_rs; p.k_hs = d->k_hs;
     p.v_bs = d->v_bs; p.v_rs = d->v_rs; p.v_hs = d->v_hs;

@@ -1,0 +1,347 @@
+// Backward / optimiser kernels of the decoder fine-tune step (f32, parity-first versions).
+// Replaces what mlx's nn.value_and_grad / optim.AdamW do for scripts/train_whisper_ipa.py:266-311:
+// gradients of the teacher-forced decoder + masked CE w.r.t. the decoder parameters, the
+// PER-TENSOR clip g *= min(1, 1/(|g|+1e-6)) (:287-303) and mlx-style AdamW without bias
+// correction (:513).  Dense contractions reuse wipa_gemm (A * W^T) on transposed operands
+// produced by transpose_kernel; everything here is deterministic (no float atomics).
+#include "wipa_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ transpose (+ zero pad)
+// out[c][r] = in[r][c] for r < rows, c < cols; out columns rows..rows_pad-1 are written as zero
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in, int64_t ld_in, T* __restrict__ out,
+                                                        int64_t ld_out, int rows, int cols, int rows_pad) {
+    __shared__ T tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? in[(int64_t)r * ld_in + c] : from_f32<T>(0.f);
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < cols && r < rows_pad) out[(int64_t)c * ld_out + r] = tile[tx][i];
+    }
+}
+
+// ------------------------------------------------------------------ column sums (bias grads)
+// out[c] (+)= sum_r x[r][c]; one workgroup per 64 columns, 4 row lanes, fixed order
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ld, int rows, int cols,
+                                                     float* __restrict__ out, int accumulate) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < cols)
+        for (int r = g; r < rows; r += 4) s += x[(int64_t)r * ld + c];
+    part[g][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (g == 0 && c < cols) {
+        const float t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        out[c] = accumulate ? out[c] + t : t;
+    }
+}
+
+// ------------------------------------------------------------------ LayerNorm backward
+// dx (+)= rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w ; stats[r] = (mean, rstd)
+constexpr int LNB_MAXV = 8;
+__global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        const float* __restrict__ w, float* __restrict__ dx,
+                                                        float* __restrict__ stats, int rows, int D, float eps, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (int64_t)row * D;
+    const float* gr = dy + (int64_t)row * D;
+    float* dr = dx + (int64_t)row * D;
+    f32x4 v[LNB_MAXV], g[LNB_MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LNB_MAXV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        v[i] = g[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < D) {
+            v[i] = *reinterpret_cast<const f32x4*>(xr + c);
+            g[i] = *reinterpret_cast<const f32x4*>(gr + c) * *reinterpret_cast<const f32x4*>(w + c);
+            sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    const float mean = wave_reduce_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < LNB_MAXV; ++i)
+        if (lane * 4 + 256 * i < D)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mean;
+                sq += d * d;
+            }
+    const float rstd = rsqrtf(wave_reduce_sum(sq) / (float)D + eps);
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int i = 0; i < LNB_MAXV; ++i)
+        if (lane * 4 + 256 * i < D)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (v[i][e] - mean) * rstd;
+                sg += g[i][e];
+                sgx += g[i][e] * xh;
+            }
+    sg = wave_reduce_sum(sg) / (float)D;
+    sgx = wave_reduce_sum(sgx) / (float)D;
+#pragma unroll
+    for (int i = 0; i < LNB_MAXV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < D) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (v[i][e] - mean) * rstd;
+                o[e] = rstd * (g[i][e] - sg - xh * sgx);
+            }
+            if (accumulate) o += *reinterpret_cast<const f32x4*>(dr + c);
+            *reinterpret_cast<f32x4*>(dr + c) = o;
+        }
+    }
+    if (lane == 0) {
+        stats[2 * row] = mean;
+        stats[2 * row + 1] = rstd;
+    }
+}
+
+// dw[c] = sum_r dy*xhat, db[c] = sum_r dy  (one workgroup per 64 columns, fixed order)
+__global__ __launch_bounds__(256) void ln_bwd_params_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ stats, int rows, int D,
+                                                            float* __restrict__ dw, float* __restrict__ db) {
+    __shared__ float pw[4][64], pb[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    float sw = 0.f, sb = 0.f;
+    if (c < D)
+        for (int r = g; r < rows; r += 4) {
+            const float d = dy[(int64_t)r * D + c];
+            sw += d * (x[(int64_t)r * D + c] - stats[2 * r]) * stats[2 * r + 1];
+            sb += d;
+        }
+    pw[g][threadIdx.x & 63] = sw;
+    pb[g][threadIdx.x & 63] = sb;
+    __syncthreads();
+    if (g == 0 && c < D) {
+        dw[c] = (pw[0][threadIdx.x] + pw[1][threadIdx.x]) + (pw[2][threadIdx.x] + pw[3][threadIdx.x]);
+        db[c] = (pb[0][threadIdx.x] + pb[1][threadIdx.x]) + (pb[2][threadIdx.x] + pb[3][threadIdx.x]);
+    }
+}
+
+// ------------------------------------------------------------------ GELU forward / backward (exact erf form)
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ z, float* __restrict__ u, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(z + i);
+    *reinterpret_cast<f32x4*>(u + i) = f32x4{gelu_erf(a[0]), gelu_erf(a[1]), gelu_erf(a[2]), gelu_erf(a[3])};
+}
+__device__ __forceinline__ float gelu_grad(float z) {
+    const float cdf = 0.5f * (1.0f + erf_fast(z * 0.70710678118654752440f));
+    const float pdf = 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.72134752044448170f * z * z);  // exp(-z^2/2)/sqrt(2 pi)
+    return cdf + z * pdf;
+}
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ z, const float* __restrict__ du,
+                                                       float* __restrict__ dz, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(z + i);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(du + i);
+    *reinterpret_cast<f32x4*>(dz + i) =
+        f32x4{d[0] * gelu_grad(a[0]), d[1] * gelu_grad(a[1]), d[2] * gelu_grad(a[2]), d[3] * gelu_grad(a[3])};
+}
+
+// ------------------------------------------------------------------ masked CE backward (in place over the logits)
+// logits[r][v] <- mask_r * (softmax_r[v] - [v == tgt_r]) / max(count, 1)
+constexpr int CEB_THREADS = 512;
+__global__ __launch_bounds__(CEB_THREADS) void ce_bwd_kernel(float* __restrict__ logits, int64_t ldl,
+                                                             const int32_t* __restrict__ tokens, int64_t ld_tok, int T, int V,
+                                                             const float* __restrict__ row_mask,
+                                                             const float* __restrict__ count) {
+    __shared__ float s_red[CEB_THREADS / 64];
+    const int r = blockIdx.x;
+    const int b = r / T, t = r - b * T;
+    const int tgt = tokens[(int64_t)b * ld_tok + t + 1];
+    float* row = logits + (int64_t)r * ldl;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float keep = row_mask[r];
+    if (keep == 0.f) {
+        for (int i = tid; i < V; i += CEB_THREADS) row[i] = 0.f;
+        return;
+    }
+    float mx = -INFINITY;
+    for (int i = tid; i < V; i += CEB_THREADS) mx = fmaxf(mx, row[i]);
+    mx = wave_reduce_max(mx);
+    if (lane == 0) s_red[wave] = mx;
+    __syncthreads();
+    mx = s_red[0];
+#pragma unroll
+    for (int w = 1; w < CEB_THREADS / 64; ++w) mx = fmaxf(mx, s_red[w]);
+    __syncthreads();
+    float se = 0.f;
+    for (int i = tid; i < V; i += CEB_THREADS) se += __expf(row[i] - mx);
+    se = wave_reduce_sum(se);
+    if (lane == 0) s_red[wave] = se;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < CEB_THREADS / 64; ++w) tot += s_red[w];
+    const float scale = 1.0f / fmaxf(count[0], 1.0f);
+    const float inv = scale / tot;
+    for (int i = tid; i < V; i += CEB_THREADS) row[i] = __expf(row[i] - mx) * inv - (i == tgt ? scale : 0.f);
+}
+
+// ------------------------------------------------------------------ embedding backward
+// dE[tok[r]][c] += dx[r][c] : each thread owns a column and walks the rows in order (deterministic)
+__global__ __launch_bounds__(64) void embed_bwd_tok_kernel(const int32_t* __restrict__ tokens, int rows,
+                                                           const float* __restrict__ dx, float* __restrict__ dE, int D) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= D) return;
+    for (int r = 0; r < rows; ++r) dE[(int64_t)tokens[r] * D + c] += dx[(int64_t)r * D + c];
+}
+// dpos[t][c] = sum_b dx[b*T + t][c]
+__global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const float* __restrict__ dx, int B, int T, int D,
+                                                            float* __restrict__ dpos) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)T * D) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dx[(int64_t)b * T * D + i];
+    dpos[i] = s;
+}
+
+// ------------------------------------------------------------------ per-tensor clip + AdamW (mlx defaults)
+// chunk table: every 4096-element chunk belongs to one tensor (segment)
+constexpr int OPT_CHUNK = 4096;
+__global__ __launch_bounds__(256) void sumsq_chunks_kernel(const float* __restrict__ g, const int64_t* __restrict__ chunk_off,
+                                                           const int32_t* __restrict__ chunk_len, float* __restrict__ partial) {
+    __shared__ float s_red[4];
+    const int ch = blockIdx.x;
+    const float* p = g + chunk_off[ch];
+    const int n = chunk_len[ch];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += p[i] * p[i];
+    s = wave_reduce_sum(s);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[ch] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+// one thread per segment: fixed-order sum of its chunks -> clip coefficient
+__global__ void clip_coef_kernel(const float* __restrict__ partial, const int32_t* __restrict__ seg_first_chunk, int n_seg,
+                                 float max_norm, float* __restrict__ coef, float* __restrict__ norms) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_seg) return;
+    float t = 0.f;
+    for (int c = seg_first_chunk[s]; c < seg_first_chunk[s + 1]; ++c) t += partial[c];
+    const float nrm = sqrtf(t);
+    norms[s] = nrm;
+    coef[s] = fminf(max_norm / (nrm + 1e-6f), 1.0f);  // train_whisper_ipa.py:295-297
+}
+__global__ __launch_bounds__(256) void adamw_chunks_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                           float* __restrict__ v, const int64_t* __restrict__ chunk_off,
+                                                           const int32_t* __restrict__ chunk_len,
+                                                           const int32_t* __restrict__ chunk_seg, const float* __restrict__ coef,
+                                                           float lr, float b1, float b2, float eps, float wd) {
+    const int ch = blockIdx.x;
+    const int64_t off = chunk_off[ch];
+    const int n = chunk_len[ch];
+    const float c = coef[chunk_seg[ch]];
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float gi = g[off + i] * c;
+        const float mi = b1 * m[off + i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[off + i] + (1.0f - b2) * gi * gi;
+        g[off + i] = gi;  // the clipped gradient (train_step returns it)
+        m[off + i] = mi;
+        v[off + i] = vi;
+        p[off + i] = p[off + i] * (1.0f - lr * wd) - lr * mi / (sqrtf(vi) + eps);  // mlx AdamW, no bias correction
+    }
+}
+
+}  // namespace
+
+extern "C" int wipa_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int rows, int cols, int rows_pad,
+                              int dtype, wipa_stream_t stream) {
+    WIPA_REQUIRE(in && out && rows > 0 && cols > 0 && rows_pad >= rows, "wipa_transpose: bad arguments");
+    dim3 grid((cols + 63) / 64, (rows_pad + 63) / 64);
+    if (dtype == WIPA_F32)
+        hipLaunchKernelGGL((transpose_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)in, ld_in,
+                           (float*)out, ld_out, rows, cols, rows_pad);
+    else if (dtype == WIPA_BF16)
+        hipLaunchKernelGGL((transpose_kernel<__bf16>), grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)in, ld_in,
+                           (__bf16*)out, ld_out, rows, cols, rows_pad);
+    else
+        WIPA_REQUIRE(false, "wipa_transpose: bad dtype %d", dtype);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+extern "C" int wipa_colsum(const float* x, int64_t ld, int rows, int cols, float* out, int accumulate, wipa_stream_t stream) {
+    WIPA_REQUIRE(x && out && rows > 0 && cols > 0, "wipa_colsum: bad arguments");
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, ld, rows, cols, out, accumulate);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+extern "C" int wipa_layernorm_bwd(const float* x, const float* dy, const float* w, float* dx, int accumulate_dx, float* dw,
+                                  float* db, float* stats, int rows, int D, float eps, wipa_stream_t stream) {
+    WIPA_REQUIRE(x && dy && w && dx && dw && db && stats, "wipa_layernorm_bwd: null pointer");
+    WIPA_REQUIRE(D % 4 == 0 && D <= LNB_MAXV * 256 && rows > 0, "wipa_layernorm_bwd: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, dy, w, dx, stats, rows, D, eps, accumulate_dx);
+    hipLaunchKernelGGL(ln_bwd_params_kernel, dim3((D + 63) / 64), dim3(256), 0, s, x, dy, stats, rows, D, dw, db);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+extern "C" int wipa_gelu(const float* z, float* u, int64_t n, wipa_stream_t stream) {
+    WIPA_REQUIRE(z && u && n > 0 && n % 4 == 0, "wipa_gelu: bad arguments");
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z, u, n);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+extern "C" int wipa_gelu_bwd(const float* z, const float* du, float* dz, int64_t n, wipa_stream_t stream) {
+    WIPA_REQUIRE(z && du && dz && n > 0 && n % 4 == 0, "wipa_gelu_bwd: bad arguments");
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z, du, dz, n);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+extern "C" int wipa_masked_ce_bwd(float* logits, int64_t ldl, const int32_t* tokens, int64_t ld_tok, int B, int T, int V,
+                                  const float* row_mask, const float* count, wipa_stream_t stream) {
+    WIPA_REQUIRE(logits && tokens && row_mask && count && B * T > 0, "wipa_masked_ce_bwd: bad arguments");
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3(B * T), dim3(CEB_THREADS), 0, (hipStream_t)stream, logits, ldl, tokens, ld_tok, T, V,
+                       row_mask, count);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+extern "C" int wipa_embed_bwd(const int32_t* tokens_flat, const float* dx, int B, int T, int D, float* d_tok_emb, float* d_pos_emb,
+                              wipa_stream_t stream) {
+    WIPA_REQUIRE(tokens_flat && dx && d_tok_emb && d_pos_emb && B * T > 0, "wipa_embed_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(embed_bwd_tok_kernel, dim3((D + 63) / 64), dim3(64), 0, s, tokens_flat, B * T, dx, d_tok_emb, D);
+    hipLaunchKernelGGL(embed_bwd_pos_kernel, dim3((unsigned)(((int64_t)T * D + 255) / 256)), dim3(256), 0, s, dx, B, T, D, d_pos_emb);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+extern "C" int wipa_clip_adamw(float* params, float* grads, float* m, float* v, const int64_t* chunk_off,
+                               const int32_t* chunk_len, const int32_t* chunk_seg, const int32_t* seg_first_chunk, int n_chunks,
+                               int n_seg, float* partial, float* coef, float* norms, float max_norm, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, wipa_stream_t stream) {
+    WIPA_REQUIRE(params && grads && m && v && chunk_off && chunk_len && chunk_seg && seg_first_chunk && partial && coef && norms,
+                 "wipa_clip_adamw: null pointer");
+    WIPA_REQUIRE(n_chunks > 0 && n_seg > 0, "wipa_clip_adamw: empty");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(sumsq_chunks_kernel, dim3(n_chunks), dim3(256), 0, s, grads, chunk_off, chunk_len, partial);
+    hipLaunchKernelGGL(clip_coef_kernel, dim3((n_seg + 63) / 64), dim3(64), 0, s, partial, seg_first_chunk, n_seg, max_norm, coef,
+                       norms);
+    hipLaunchKernelGGL(adamw_chunks_kernel, dim3(n_chunks), dim3(256), 0, s, params, grads, m, v, chunk_off, chunk_len, chunk_seg,
+                       coef, lr, beta1, beta2, eps, weight_decay);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}

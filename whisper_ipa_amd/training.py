@@ -1,0 +1,308 @@
+"""Decoder-only fine-tune step (f32) with the semantics of the reference's ``train_step``
+(scripts/train_whisper_ipa.py:266-311): encoder frozen (:187), teacher forcing on
+``tokens[:, :-1]`` against ``tokens[:, 1:]`` (:228-232), masked CE with the batch-GLOBAL valid count
+(:242-261), gradients w.r.t. every ``decoder.*`` tensor (tied embedding included), PER-TENSOR clip
+(:287-303), mlx-style AdamW without bias correction (:513).
+
+mlx's ``nn.value_and_grad`` is replaced by an explicit forward that saves activations and a
+hand-written backward; every arithmetic step is a libwipa kernel (GEMMs through wipa_gemm on
+operands transposed by wipa_transpose, flash-style attention backward, LayerNorm/GELU/CE backward,
+fused clip+AdamW over one flat parameter buffer).  torch only owns the buffers.
+
+Data parallel (one process per GPU): the (sum CE, valid count) pair is all-reduced BEFORE the
+backward so the normalisation is global, the flat gradient buffer is all-reduced in buckets AFTER
+it, and the per-tensor clip runs on the reduced gradients -- single-process semantics are kept.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib, ops, parallel
+from .runtime import on_stream, ptr, sptr
+from .whisper import Whisper, parameter_names
+
+QK_SCALE = 64 ** -0.25
+OPT_CHUNK = 4096
+
+
+def _ceil(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class DecoderTrainer:
+    def __init__(self, model: Whisper, lr: float = 1e-5, max_grad_norm: float = 1.0, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.01):
+        if model.dtype != torch.float32:
+            raise _lib.WipaError("DecoderTrainer: the fine-tune step runs in float32 (reference: set_dtype(mx.float32))")
+        self.model, self.lr, self.max_grad_norm = model, lr, max_grad_norm
+        self.b1, self.b2 = betas
+        self.eps, self.wd = eps, weight_decay
+        self.L = _lib.lib()
+        d = model.dims
+        self.names = [n for n in parameter_names(d) if n.startswith("decoder.")]
+        P = model.flat_parameters()
+        sizes = [P[n].numel() for n in self.names]
+        assert all(s % 4 == 0 for s in sizes)
+        offs, total = [], 0
+        for s in sizes:
+            offs.append(total)
+            total += s
+        self.offsets = dict(zip(self.names, offs))
+        self.shapes = {n: tuple(P[n].shape) for n in self.names}
+        self.n_params = total
+        with on_stream():
+            dev = model.device
+            self.flat_p = torch.empty(total, dtype=torch.float32, device=dev)
+            self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+            self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
+            self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
+            for n in self.names:
+                self.p(n).copy_(P[n])
+                model._params[n] = self.p(n)  # the model now reads the optimiser's buffer directly
+            # chunk tables for the flat multi-tensor optimiser
+            ch_off, ch_len, ch_seg, seg_first = [], [], [], [0]
+            for si, (o, s) in enumerate(zip(offs, sizes)):
+                for c0 in range(0, s, OPT_CHUNK):
+                    ch_off.append(o + c0)
+                    ch_len.append(min(OPT_CHUNK, s - c0))
+                    ch_seg.append(si)
+                seg_first.append(len(ch_off))
+            self.n_chunks, self.n_seg = len(ch_off), len(sizes)
+            self.ch_off = torch.tensor(ch_off, dtype=torch.int64, device=dev)
+            self.ch_len = torch.tensor(ch_len, dtype=torch.int32, device=dev)
+            self.ch_seg = torch.tensor(ch_seg, dtype=torch.int32, device=dev)
+            self.seg_first = torch.tensor(seg_first, dtype=torch.int32, device=dev)
+            self.partial = torch.empty(self.n_chunks, dtype=torch.float32, device=dev)
+            self.coef = torch.empty(self.n_seg, dtype=torch.float32, device=dev)
+            self.norms = torch.empty(self.n_seg, dtype=torch.float32, device=dev)
+        model._invalidate()
+        self.step_count = 0
+
+    # ---- views into the flat buffers
+    def p(self, name: str) -> torch.Tensor:
+        o = self.offsets[name]
+        return self.flat_p[o:o + _numel(self.shapes[name])].view(self.shapes[name])
+
+    def g(self, name: str) -> torch.Tensor:
+        o = self.offsets[name]
+        return self.flat_g[o:o + _numel(self.shapes[name])].view(self.shapes[name])
+
+    def grads(self) -> Dict[str, torch.Tensor]:
+        return {n: self.g(n) for n in self.names}
+
+    # ---- kernel helpers (all on the library stream)
+    def _lin(self, x, M, K, W, N, bias=None, scale=None, residual=None, out=None):
+        """out[M,N] = (x[M,K] W[N,K]^T + bias) * scale (+ residual)"""
+        out = torch.empty(x.shape[0], N, dtype=torch.float32, device=x.device) if out is None else out
+        ops.gemm(x, W, out, M=M, N=N, K=K, lda=x.stride(0), ldw=W.stride(0), ldc=out.stride(0), bias=bias,
+                 residual=residual, col_scale_n=(N if scale is not None else 0), col_scale=(scale or 1.0))
+        return out
+
+    def _transpose(self, a, rows, cols, rows_pad):
+        """a[rows, cols] (row stride a.stride(0)) -> [cols, rows_pad] with zero padding"""
+        out = torch.empty(cols, rows_pad, dtype=a.dtype, device=a.device)
+        with on_stream() as s:
+            _lib.check(self.L.wipa_transpose(ptr(a), a.stride(0), ptr(out), rows_pad, rows, cols, rows_pad, 0, sptr(s)),
+                       "wipa_transpose")
+        return out
+
+    def _lin_bwd(self, dy, M, N, x, xT, K, W, dW, db=None, dx=None, accumulate_dx=False, need_dx=True, dy_scaled_ok=True):
+        """y = x W^T + b:  dx (+)= dy W ; dW = dy^T x ; db = colsum(dy).
+        dy [M(+pad), N], x [M, K]; xT = transpose(x) [K, Mp] may be passed to share it between linears."""
+        Mp = _ceil(M, 32)
+        out_dx = None
+        if need_dx:
+            Np = _ceil(N, 32)
+            WT = self._transpose(W, N, K, Np)  # [K, Np]
+            out_dx = dx if dx is not None else torch.empty(dy.shape[0], K, dtype=torch.float32, device=dy.device)
+            # contraction over n: A = dy (row stride ld, first Np columns must be readable and zero beyond N)
+            ops.gemm(dy, WT, out_dx, M=M, N=K, K=Np, lda=dy.stride(0), ldw=Np, ldc=out_dx.stride(0),
+                     residual=(out_dx if accumulate_dx else None))
+        dyT = self._transpose(dy, M, N, Mp)  # [N, Mp]
+        if xT is None:
+            xT = self._transpose(x, M, K, Mp)
+        ops.gemm(dyT, xT, dW, M=N, N=K, K=Mp, lda=Mp, ldw=xT.stride(0), ldc=dW.stride(0))
+        if db is not None:
+            with on_stream() as s:
+                _lib.check(self.L.wipa_colsum(ptr(dy), dy.stride(0), M, N, ptr(db), 0, sptr(s)), "wipa_colsum")
+        return out_dx
+
+    def _ln(self, x, w, b):
+        return ops.layernorm(x, w, b, out_dtype=torch.float32)
+
+    def _ln_bwd(self, x, dy, w, dx, accumulate, dw, db, M, D):
+        with on_stream() as s:
+            stats = torch.empty(2 * M, dtype=torch.float32, device=x.device)
+            _lib.check(self.L.wipa_layernorm_bwd(ptr(x), ptr(dy), ptr(w), ptr(dx), int(accumulate), ptr(dw), ptr(db), ptr(stats),
+                                                 M, D, 1e-5, sptr(s)), "wipa_layernorm_bwd")
+
+    def _attn(self, q, k, v, B, H, Tq, Tk, causal, k_rows_per_batch):
+        """q [B*Tq, d], k/v [B*Tk, d] row-major -> (out [B*Tq, d], lse [B,H,Tq], desc)"""
+        d = H * 64
+        with on_stream() as s:
+            out = torch.empty(B * Tq, d, dtype=torch.float32, device=q.device)
+            lse = torch.empty(B, H, Tq, dtype=torch.float32, device=q.device)
+            a = _lib.AttnDesc()
+            a.q, a.k, a.v, a.out, a.lse = ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse)
+            a.q_bs, a.q_rs, a.q_hs = Tq * q.stride(0), q.stride(0), 64
+            a.k_bs, a.k_rs, a.k_hs = Tk * k.stride(0), k.stride(0), 64
+            a.v_bs, a.v_rs, a.v_hs = Tk * v.stride(0), v.stride(0), 64
+            a.o_bs, a.o_rs, a.o_hs = Tq * d, d, 64
+            a.B, a.H, a.Tq, a.Tk, a.causal, a.dtype = B, H, Tq, Tk, int(causal), 0
+            _lib.check(self.L.wipa_attention(C.byref(a), sptr(s)), "wipa_attention")
+        return out, lse, a
+
+    def _attn_bwd(self, desc, out, d_out, lse, dq, dk, dv):
+        with on_stream() as s:
+            dvec = torch.empty_like(lse)
+            _lib.check(self.L.wipa_attention_bwd(C.byref(desc), ptr(out), ptr(d_out), ptr(lse), ptr(dq), ptr(dk), ptr(dv),
+                                                 ptr(dvec), QK_SCALE, sptr(s)), "wipa_attention_bwd")
+
+    # ---- forward + backward ------------------------------------------------------------
+    def loss_and_grads(self, audio_features: torch.Tensor, tokens: torch.Tensor, eot: int, group=None):
+        """features [B, 1500, d] f32 (encoder output, no gradient), tokens [B, T+1] int.
+        Fills self.flat_g (un-clipped, already divided by the global valid count and, under DP,
+        all-reduced).  Returns (loss, sum_ce, n_valid) as device scalars."""
+        m, dm, L = self.model, self.model.dims, self.L
+        P = self.p
+        B, T1 = tokens.shape
+        T = T1 - 1
+        d, H, V, Ta = dm.n_text_state, dm.n_text_head, dm.n_vocab, dm.n_audio_ctx
+        M, Mp = B * T, _ceil(B * T, 32)
+        Vp = _ceil(V, 32)
+        with on_stream() as s:
+            dev = m.device
+            tok = tokens.to(device=dev, dtype=torch.int32).contiguous()
+            tok_in = tok[:, :-1].contiguous()
+            feats = audio_features.to(device=dev, dtype=torch.float32).contiguous().view(B * Ta, d)
+            featsT = self._transpose(feats, B * Ta, d, _ceil(B * Ta, 32))  # [d, ceil32(B*Ta)], shared by all layers
+            x = torch.empty(M, d, dtype=torch.float32, device=dev)
+            _lib.check(L.wipa_embed_tokens(ptr(tok_in), T, B, T, 0, None, ptr(P("decoder.token_embedding.weight")), 0,
+                                           ptr(P("decoder.positional_embedding")), ptr(x), d, sptr(s)), "wipa_embed_tokens")
+            saved = []
+            for l in range(dm.n_text_layer):
+                pre = f"decoder.blocks.{l}"
+                S = {"x_a": x}
+                S["h1"] = self._ln(x, P(f"{pre}.attn_ln.weight"), P(f"{pre}.attn_ln.bias"))
+                S["q"] = self._lin(S["h1"], M, d, P(f"{pre}.attn.query.weight"), d, P(f"{pre}.attn.query.bias"), QK_SCALE)
+                S["k"] = self._lin(S["h1"], M, d, P(f"{pre}.attn.key.weight"), d, None, QK_SCALE)
+                S["v"] = self._lin(S["h1"], M, d, P(f"{pre}.attn.value.weight"), d, P(f"{pre}.attn.value.bias"))
+                S["a"], S["lse1"], S["desc1"] = self._attn(S["q"], S["k"], S["v"], B, H, T, T, True, T)
+                S["x_b"] = self._lin(S["a"], M, d, P(f"{pre}.attn.out.weight"), d, P(f"{pre}.attn.out.bias"), residual=x)
+                S["h2"] = self._ln(S["x_b"], P(f"{pre}.cross_attn_ln.weight"), P(f"{pre}.cross_attn_ln.bias"))
+                S["qc"] = self._lin(S["h2"], M, d, P(f"{pre}.cross_attn.query.weight"), d, P(f"{pre}.cross_attn.query.bias"), QK_SCALE)
+                S["kc"] = self._lin(feats, B * Ta, d, P(f"{pre}.cross_attn.key.weight"), d, None, QK_SCALE)
+                S["vc"] = self._lin(feats, B * Ta, d, P(f"{pre}.cross_attn.value.weight"), d, P(f"{pre}.cross_attn.value.bias"))
+                S["c"], S["lse2"], S["desc2"] = self._attn(S["qc"], S["kc"], S["vc"], B, H, T, Ta, False, Ta)
+                S["x_c"] = self._lin(S["c"], M, d, P(f"{pre}.cross_attn.out.weight"), d, P(f"{pre}.cross_attn.out.bias"),
+                                     residual=S["x_b"])
+                S["h3"] = self._ln(S["x_c"], P(f"{pre}.mlp_ln.weight"), P(f"{pre}.mlp_ln.bias"))
+                S["z"] = self._lin(S["h3"], M, d, P(f"{pre}.mlp1.weight"), 4 * d, P(f"{pre}.mlp1.bias"))
+                S["u"] = torch.empty_like(S["z"])
+                _lib.check(L.wipa_gelu(ptr(S["z"]), ptr(S["u"]), S["z"].numel(), sptr(s)), "wipa_gelu")
+                x = self._lin(S["u"], M, 4 * d, P(f"{pre}.mlp2.weight"), d, P(f"{pre}.mlp2.bias"), residual=S["x_c"])
+                saved.append(S)
+            x_L = x
+            hf = self._ln(x_L, P("decoder.ln.weight"), P("decoder.ln.bias"))
+            E = P("decoder.token_embedding.weight")
+            logits = torch.zeros(Mp, Vp, dtype=torch.float32, device=dev)  # padding rows/cols stay zero
+            ops.gemm(hf, E, logits, M=M, N=V, K=d, lda=d, ldw=d, ldc=Vp)
+            row_buf = torch.empty(2 * M, dtype=torch.float32, device=dev)
+            stats = torch.empty(2, dtype=torch.float32, device=dev)
+            _lib.check(L.wipa_masked_ce(ptr(logits), Vp, ptr(tok), T1, B, T, V, eot, ptr(row_buf), ptr(stats), sptr(s)),
+                       "wipa_masked_ce")
+            sum_ce, n_valid = parallel.allreduce_loss_stats(stats[0], stats[1], group)
+            count = n_valid.reshape(1).contiguous()
+            loss = sum_ce / torch.clamp(n_valid, min=1.0)
+
+            # ------------------------------------------------------------ backward
+            self.flat_g.zero_()
+            G = self.g
+            _lib.check(L.wipa_masked_ce_bwd(ptr(logits), Vp, ptr(tok), T1, B, T, V, ptr(row_buf[M:]), ptr(count), sptr(s)),
+                       "wipa_masked_ce_bwd")
+            dlogits = logits
+            # logits = hf E^T : dhf = dlogits E ; dE = dlogits^T hf
+            ET = self._transpose(E, V, d, Vp)  # [d, Vp]
+            dhf = torch.empty(M, d, dtype=torch.float32, device=dev)
+            ops.gemm(dlogits, ET, dhf, M=M, N=d, K=Vp, lda=Vp, ldw=Vp, ldc=d)
+            dlT = self._transpose(dlogits, M, V, Mp)  # [V, Mp]
+            hfT = self._transpose(hf, M, d, Mp)
+            ops.gemm(dlT, hfT, G("decoder.token_embedding.weight"), M=V, N=d, K=Mp, lda=Mp, ldw=Mp, ldc=d)
+            del dlT, logits, dlogits
+            dx = torch.empty(M, d, dtype=torch.float32, device=dev)
+            self._ln_bwd(x_L, dhf, P("decoder.ln.weight"), dx, False, G("decoder.ln.weight"), G("decoder.ln.bias"), M, d)
+            for l in reversed(range(dm.n_text_layer)):
+                pre = f"decoder.blocks.{l}"
+                S = saved[l]
+                # x_next = x_c + u W2^T + b2
+                du = self._lin_bwd(dx, M, d, S["u"], None, 4 * d, P(f"{pre}.mlp2.weight"), G(f"{pre}.mlp2.weight"), G(f"{pre}.mlp2.bias"))
+                dz = torch.empty_like(du)
+                _lib.check(L.wipa_gelu_bwd(ptr(S["z"]), ptr(du), ptr(dz), dz.numel(), sptr(s)), "wipa_gelu_bwd")
+                dh3 = self._lin_bwd(dz, M, 4 * d, S["h3"], None, d, P(f"{pre}.mlp1.weight"), G(f"{pre}.mlp1.weight"), G(f"{pre}.mlp1.bias"))
+                self._ln_bwd(S["x_c"], dh3, P(f"{pre}.mlp_ln.weight"), dx, True, G(f"{pre}.mlp_ln.weight"), G(f"{pre}.mlp_ln.bias"), M, d)
+                # x_c = x_b + c Wco^T + bco
+                dc = self._lin_bwd(dx, M, d, S["c"], None, d, P(f"{pre}.cross_attn.out.weight"), G(f"{pre}.cross_attn.out.weight"),
+                                   G(f"{pre}.cross_attn.out.bias"))
+                dqc = torch.empty(M, d, dtype=torch.float32, device=dev)
+                dkc = torch.empty(B * Ta, d, dtype=torch.float32, device=dev)
+                dvc = torch.empty(B * Ta, d, dtype=torch.float32, device=dev)
+                self._attn_bwd(S["desc2"], S["c"], dc, S["lse2"], dqc, dkc, dvc)
+                self._lin_bwd(dkc, B * Ta, d, feats, featsT, d, P(f"{pre}.cross_attn.key.weight"), G(f"{pre}.cross_attn.key.weight"),
+                              None, need_dx=False)
+                self._lin_bwd(dvc, B * Ta, d, feats, featsT, d, P(f"{pre}.cross_attn.value.weight"), G(f"{pre}.cross_attn.value.weight"),
+                              G(f"{pre}.cross_attn.value.bias"), need_dx=False)
+                del dkc, dvc
+                dh2 = self._lin_bwd(dqc, M, d, S["h2"], None, d, P(f"{pre}.cross_attn.query.weight"), G(f"{pre}.cross_attn.query.weight"),
+                                    G(f"{pre}.cross_attn.query.bias"))
+                self._ln_bwd(S["x_b"], dh2, P(f"{pre}.cross_attn_ln.weight"), dx, True, G(f"{pre}.cross_attn_ln.weight"),
+                             G(f"{pre}.cross_attn_ln.bias"), M, d)
+                # x_b = x_a + a Wo^T + bo
+                da = self._lin_bwd(dx, M, d, S["a"], None, d, P(f"{pre}.attn.out.weight"), G(f"{pre}.attn.out.weight"), G(f"{pre}.attn.out.bias"))
+                dq = torch.empty(M, d, dtype=torch.float32, device=dev)
+                dk = torch.empty(M, d, dtype=torch.float32, device=dev)
+                dv = torch.empty(M, d, dtype=torch.float32, device=dev)
+                self._attn_bwd(S["desc1"], S["a"], da, S["lse1"], dq, dk, dv)
+                h1T = self._transpose(S["h1"], M, d, Mp)
+                dh1 = self._lin_bwd(dq, M, d, S["h1"], h1T, d, P(f"{pre}.attn.query.weight"), G(f"{pre}.attn.query.weight"),
+                                    G(f"{pre}.attn.query.bias"))
+                self._lin_bwd(dk, M, d, S["h1"], h1T, d, P(f"{pre}.attn.key.weight"), G(f"{pre}.attn.key.weight"), None, dx=dh1,
+                              accumulate_dx=True)
+                self._lin_bwd(dv, M, d, S["h1"], h1T, d, P(f"{pre}.attn.value.weight"), G(f"{pre}.attn.value.weight"),
+                              G(f"{pre}.attn.value.bias"), dx=dh1, accumulate_dx=True)
+                self._ln_bwd(S["x_a"], dh1, P(f"{pre}.attn_ln.weight"), dx, True, G(f"{pre}.attn_ln.weight"), G(f"{pre}.attn_ln.bias"), M, d)
+                saved[l] = None
+            _lib.check(L.wipa_embed_bwd(ptr(tok_in), ptr(dx), B, T, d, ptr(G("decoder.token_embedding.weight")),
+                                        ptr(G("decoder.positional_embedding")), sptr(s)), "wipa_embed_bwd")
+            if T < dm.n_text_ctx:
+                G("decoder.positional_embedding")[T:].zero_()
+            # DP: sum the gradients of all ranks (each already divided by the GLOBAL count)
+            parallel.allreduce_grads({"flat": self.flat_g}, bucket_bytes=256 << 20, group=group) if parallel.world()[1] > 1 else None
+        return loss, sum_ce, n_valid
+
+    def apply_update(self) -> None:
+        """per-tensor clip + AdamW on the flat buffers (flat_g becomes the clipped gradient)."""
+        with on_stream() as s:
+            _lib.check(self.L.wipa_clip_adamw(ptr(self.flat_p), ptr(self.flat_g), ptr(self.flat_m), ptr(self.flat_v), ptr(self.ch_off),
+                                              ptr(self.ch_len), ptr(self.ch_seg), ptr(self.seg_first), self.n_chunks, self.n_seg,
+                                              ptr(self.partial), ptr(self.coef), ptr(self.norms), self.max_grad_norm, self.lr,
+                                              self.b1, self.b2, self.eps, self.wd, sptr(s)), "wipa_clip_adamw")
+        self.model._invalidate()  # fused inference tables are rebuilt lazily from the updated weights
+        self.step_count += 1
+
+    def train_step(self, mel: torch.Tensor, tokens: torch.Tensor, eot: int, group=None):
+        """train_whisper_ipa.py:266-311: encoder forward (frozen), loss + grads, clip, AdamW.
+        Returns (loss as a device scalar, dict of clipped gradients)."""
+        feats = self.model.embed_audio(mel)
+        loss, _, _ = self.loss_and_grads(feats, tokens, eot, group)
+        self.apply_update()
+        return loss, self.grads()
+
+
+def _numel(shape) -> int:
+    n = 1
+    for s in shape:
+        n *= s
+    return n
