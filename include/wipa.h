@@ -284,8 +284,8 @@ int wipa_attention_bwd(const wipa_attn_desc* d, const float* out, const float* d
  * coef/norms [n_seg] are scratch/outputs. */
 int wipa_clip_adamw(float* params, float* grads, float* m, float* v, const int64_t* chunk_off, const int32_t* chunk_len,
                     const int32_t* chunk_seg, const int32_t* seg_first_chunk, int n_chunks, int n_seg, float* partial,
-                    float* coef, float* norms, float max_norm, float lr, float beta1, float beta2, float eps,
-                    float weight_decay, wipa_stream_t s);
+                    float* coef, float* norms, double max_norm, double lr, double beta1, double beta2, double eps,
+                    double weight_decay, wipa_stream_t s);
 
 #ifdef __cplusplus
 }

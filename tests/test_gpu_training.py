@@ -286,3 +286,29 @@ def test_train_script_end_to_end_artefacts(tmp_path, capsys):
     model2 = TS.load_checkpoint_model(str(out / "checkpoint-3"), str(model_dir))
     assert torch.equal(model2.flat_parameters()["decoder.blocks.0.mlp1.weight"].cpu(), saved["decoder.blocks.0.mlp1.weight"])
     assert isinstance(TS.transcribe_file(model2, entries[0]["audio_path"]), str)
+
+
+def test_small_width_gradients_match_oracle():
+    """whisper-small width (d=768, 12 heads, 2 layers): the full-size tile paths of the backward."""
+    from whisper_ipa_amd.training import DecoderTrainer
+    from whisper_ipa_amd.whisper import ModelDimensions, Whisper
+
+    dims = R.ModelDimensions(80, 1500, 768, 12, 1, 51865, 448, 768, 12, 2)
+    W = R.synthetic_weights(dims, seed=13)
+    torch.manual_seed(1)
+    xa = torch.randn(2, 1500, 768) * 0.7
+    tokens = _tokens()[:2]
+    names = [k for k in W if k.startswith("decoder.")]
+    leaves = {k: W[k].detach().clone().requires_grad_(True) for k in names}
+    Wl = dict(W)
+    Wl.update(leaves)
+    ref_loss = R.loss_from_features(Wl, dims, xa, tokens, EOT)
+    ref = dict(zip(names, torch.autograd.grad(ref_loss, [leaves[k] for k in names])))
+    m = Whisper(ModelDimensions(**dims.__dict__), dtype=torch.float32)
+    m.load_weights(W)
+    tr = DecoderTrainer(m)
+    loss, _, _ = tr.loss_and_grads(xa.cuda(), tokens.cuda(), EOT)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(ref_loss)) < 2e-3
+    worst = max(((_rel(tr.g(n), ref[n]), n) for n in tr.names))
+    assert worst[0] < 3e-3, worst

@@ -244,19 +244,20 @@ __global__ __launch_bounds__(256) void adamw_chunks_kernel(float* __restrict__ p
                                                            float* __restrict__ v, const int64_t* __restrict__ chunk_off,
                                                            const int32_t* __restrict__ chunk_len,
                                                            const int32_t* __restrict__ chunk_seg, const float* __restrict__ coef,
-                                                           float lr, float b1, float b2, float eps, float wd) {
+                                                           float lr, float b1, float omb1, float b2, float omb2, float eps,
+                                                           float decay) {
     const int ch = blockIdx.x;
     const int64_t off = chunk_off[ch];
     const int n = chunk_len[ch];
     const float c = coef[chunk_seg[ch]];
     for (int i = threadIdx.x; i < n; i += 256) {
         const float gi = g[off + i] * c;
-        const float mi = b1 * m[off + i] + (1.0f - b1) * gi;
-        const float vi = b2 * v[off + i] + (1.0f - b2) * gi * gi;
+        const float mi = b1 * m[off + i] + omb1 * gi;
+        const float vi = b2 * v[off + i] + omb2 * gi * gi;
         g[off + i] = gi;  // the clipped gradient (train_step returns it)
         m[off + i] = mi;
         v[off + i] = vi;
-        p[off + i] = p[off + i] * (1.0f - lr * wd) - lr * mi / (sqrtf(vi) + eps);  // mlx AdamW, no bias correction
+        p[off + i] = p[off + i] * decay - lr * mi / (sqrtf(vi) + eps);  // mlx AdamW, no bias correction
     }
 }
 
@@ -331,17 +332,19 @@ extern "C" int wipa_embed_bwd(const int32_t* tokens_flat, const float* dx, int B
 
 extern "C" int wipa_clip_adamw(float* params, float* grads, float* m, float* v, const int64_t* chunk_off,
                                const int32_t* chunk_len, const int32_t* chunk_seg, const int32_t* seg_first_chunk, int n_chunks,
-                               int n_seg, float* partial, float* coef, float* norms, float max_norm, float lr, float beta1,
-                               float beta2, float eps, float weight_decay, wipa_stream_t stream) {
+                               int n_seg, float* partial, float* coef, float* norms, double max_norm, double lr, double beta1,
+                               double beta2, double eps, double weight_decay, wipa_stream_t stream) {
     WIPA_REQUIRE(params && grads && m && v && chunk_off && chunk_len && chunk_seg && seg_first_chunk && partial && coef && norms,
                  "wipa_clip_adamw: null pointer");
     WIPA_REQUIRE(n_chunks > 0 && n_seg > 0, "wipa_clip_adamw: empty");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(sumsq_chunks_kernel, dim3(n_chunks), dim3(256), 0, s, grads, chunk_off, chunk_len, partial);
-    hipLaunchKernelGGL(clip_coef_kernel, dim3((n_seg + 63) / 64), dim3(64), 0, s, partial, seg_first_chunk, n_seg, max_norm, coef,
-                       norms);
+    hipLaunchKernelGGL(clip_coef_kernel, dim3((n_seg + 63) / 64), dim3(64), 0, s, partial, seg_first_chunk, n_seg, (float)max_norm,
+                       coef, norms);
+    // the scalar coefficients are formed in double like the Python reference forms them, then rounded once
     hipLaunchKernelGGL(adamw_chunks_kernel, dim3(n_chunks), dim3(256), 0, s, params, grads, m, v, chunk_off, chunk_len, chunk_seg,
-                       coef, lr, beta1, beta2, eps, weight_decay);
+                       coef, (float)lr, (float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                       (float)(1.0 - lr * weight_decay));
     WIPA_LAUNCH_CHECK();
     return WIPA_OK;
 }
