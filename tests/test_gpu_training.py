@@ -288,6 +288,78 @@ def test_train_script_end_to_end_artefacts(tmp_path, capsys):
     assert isinstance(TS.transcribe_file(model2, entries[0]["audio_path"]), str)
 
 
+def _dp_worker(rank, world, port, q):
+    import os
+
+    import torch.distributed as dist
+
+    from whisper_ipa_amd.training import DecoderTrainer
+    from whisper_ipa_amd.whisper import ModelDimensions, Whisper
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # one GPU box: gloo moves the CUDA tensors
+    try:
+        W = R.synthetic_weights(MICRO, seed=7)
+        torch.manual_seed(0)
+        xa = torch.randn(4, 1500, 128) * 0.7
+        rng = np.random.default_rng(9)
+        sot = [50258, 50259, 50359, 50363]
+        seqs = [sot + rng.integers(0, 50257, size=n).tolist() + [EOT] for n in (9, 3, 7, 5)]
+        L = max(len(s) for s in seqs)
+        tokens = torch.tensor([s + [EOT] * (L - len(s)) for s in seqs], dtype=torch.int64)
+        m = Whisper(ModelDimensions(**MICRO.__dict__), dtype=torch.float32)
+        m.load_weights(W)
+        tr = DecoderTrainer(m)
+        lo, hi = rank * 2, rank * 2 + 2
+        loss, s, n = tr.loss_and_grads(xa[lo:hi].cuda(), tokens[lo:hi].cuda(), EOT)
+        torch.cuda.synchronize()
+        q.put((rank, float(loss), float(n), tr.flat_g.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_two_ranks_equal_single_process():
+    """DP semantics: two ranks, each half of the batch, all-reduced loss statistics and
+    gradients == one process on the whole batch (global valid-token normalisation, clip after the reduce)."""
+    import os
+
+    import torch.multiprocessing as mp
+
+    from whisper_ipa_amd.training import DecoderTrainer
+    from whisper_ipa_amd.whisper import ModelDimensions, Whisper
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 300
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    W = R.synthetic_weights(MICRO, seed=7)
+    torch.manual_seed(0)
+    xa = torch.randn(4, 1500, 128) * 0.7
+    rng = np.random.default_rng(9)
+    sot = [50258, 50259, 50359, 50363]
+    seqs = [sot + rng.integers(0, 50257, size=n).tolist() + [EOT] for n in (9, 3, 7, 5)]
+    L = max(len(s) for s in seqs)
+    tokens = torch.tensor([s + [EOT] * (L - len(s)) for s in seqs], dtype=torch.int64)
+    m = Whisper(ModelDimensions(**MICRO.__dict__), dtype=torch.float32)
+    m.load_weights(W)
+    tr = DecoderTrainer(m)
+    loss, s, n = tr.loss_and_grads(xa.cuda(), tokens.cuda(), EOT)
+    torch.cuda.synchronize()
+    full = tr.flat_g.cpu().numpy()
+    for r in res:
+        assert abs(r[1] - float(loss)) < 1e-5 and r[2] == float(n)
+        assert np.abs(r[3] - full).max() < 1e-5 * (np.abs(full).max() + 1e-9) + 1e-7
+    assert np.array_equal(res[0][3], res[1][3])
+
+
 def test_small_width_gradients_match_oracle():
     """whisper-small width (d=768, 12 heads, 2 layers): the full-size tile paths of the backward."""
     from whisper_ipa_amd.training import DecoderTrainer

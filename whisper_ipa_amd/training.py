@@ -53,6 +53,12 @@ class DecoderTrainer:
         self.offsets = dict(zip(self.names, offs))
         self.shapes = {n: tuple(P[n].shape) for n in self.names}
         self.n_params = total
+        # contiguous gradient segments in flat order: [embeddings][block 0]...[block L-1][final ln]; the
+        # backward finishes them from the back, so each can be all-reduced while earlier blocks still compute
+        starts = [offs[self.names.index(f"decoder.blocks.{l}.attn.query.weight")] for l in range(d.n_text_layer)]
+        tail = offs[self.names.index("decoder.ln.weight")]
+        self.block_ranges = [(starts[l], starts[l + 1] if l + 1 < d.n_text_layer else tail) for l in range(d.n_text_layer)]
+        self.head_range, self.tail_range = (0, starts[0]), (tail, total)
         with on_stream():
             dev = model.device
             self.flat_p = torch.empty(total, dtype=torch.float32, device=dev)
@@ -234,6 +240,17 @@ class DecoderTrainer:
             del dlT, logits, dlogits
             dx = torch.empty(M, d, dtype=torch.float32, device=dev)
             self._ln_bwd(x_L, dhf, P("decoder.ln.weight"), dx, False, G("decoder.ln.weight"), G("decoder.ln.bias"), M, d)
+            # DP: each finished gradient segment is all-reduced (SUM; every rank already divided by the GLOBAL
+            # count) asynchronously on RCCL's stream while the earlier blocks are still in their backward
+            pending = []
+
+            def reduce_segment(rng):
+                if parallel.world()[1] > 1 and rng[1] > rng[0]:
+                    import torch.distributed as dist
+
+                    pending.append(dist.all_reduce(self.flat_g[rng[0]:rng[1]], op=dist.ReduceOp.SUM, group=group, async_op=True))
+
+            reduce_segment(self.tail_range)
             for l in reversed(range(dm.n_text_layer)):
                 pre = f"decoder.blocks.{l}"
                 S = saved[l]
@@ -274,12 +291,14 @@ class DecoderTrainer:
                               G(f"{pre}.attn.value.bias"), dx=dh1, accumulate_dx=True)
                 self._ln_bwd(S["x_a"], dh1, P(f"{pre}.attn_ln.weight"), dx, True, G(f"{pre}.attn_ln.weight"), G(f"{pre}.attn_ln.bias"), M, d)
                 saved[l] = None
+                reduce_segment(self.block_ranges[l])
             _lib.check(L.wipa_embed_bwd(ptr(tok_in), ptr(dx), B, T, d, ptr(G("decoder.token_embedding.weight")),
                                         ptr(G("decoder.positional_embedding")), sptr(s)), "wipa_embed_bwd")
             if T < dm.n_text_ctx:
                 G("decoder.positional_embedding")[T:].zero_()
-            # DP: sum the gradients of all ranks (each already divided by the GLOBAL count)
-            parallel.allreduce_grads({"flat": self.flat_g}, bucket_bytes=256 << 20, group=group) if parallel.world()[1] > 1 else None
+            reduce_segment(self.head_range)
+            for work in pending:
+                work.wait()
         return loss, sum_ce, n_valid
 
     def apply_update(self) -> None:
