@@ -189,14 +189,16 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(AttnParams p) {
     float acc[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
-    for (int t0 = wave * G * U; t0 < Tk; t0 += 4 * G * U) {
-        Vec16<T> kvec[U], vvec[U];
+    // software pipeline: the loads of key group i+1 are in flight while group i is reduced
+    auto load_group = [&](int t0, Vec16<T>(&kv_)[U], Vec16<T>(&vv_)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int t = min(t0 + u * G + g, Tk - 1);
-            kvec[u] = *reinterpret_cast<const Vec16<T>*>(Kb + (int64_t)t * k_rs);
-            vvec[u] = *reinterpret_cast<const Vec16<T>*>(Vb + (int64_t)t * v_rs);
+            kv_[u] = *reinterpret_cast<const Vec16<T>*>(Kb + (int64_t)t * k_rs);
+            vv_[u] = *reinterpret_cast<const Vec16<T>*>(Vb + (int64_t)t * v_rs);
         }
+    };
+    auto consume_group = [&](int t0, const Vec16<T>(&kvec)[U], const Vec16<T>(&vvec)[U]) {
         float s[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -222,6 +224,23 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(AttnParams p) {
             for (int e = 0; e < EPL; ++e) acc[e] = fmaf(pr, vvec[u].get(e), acc[e]);
         }
         m = m_new;
+    };
+    constexpr int STEP = 4 * G * U;
+    int t0 = wave * G * U;
+    if (t0 < Tk) {
+        Vec16<T> ka[U], va[U], kb2[U], vb2[U];
+        load_group(t0, ka, va);
+        for (;;) {
+            const int t1 = t0 + STEP;
+            if (t1 < Tk) load_group(t1, kb2, vb2);
+            consume_group(t0, ka, va);
+            if (t1 >= Tk) break;
+            const int t2 = t1 + STEP;
+            if (t2 < Tk) load_group(t2, ka, va);
+            consume_group(t1, kb2, vb2);
+            if (t2 >= Tk) break;
+            t0 = t2;
+        }
     }
     // merge the G key groups of this wave (lanes with equal c)
 #pragma unroll
@@ -338,40 +357,41 @@ __global__ __launch_bounds__(256, 2) void flash_enc_bf16_kernel(const __bf16* __
                 S[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], S[u], 0, 0, 0);
             }
         }
-        // scale to log2 domain, mask the ragged last tile
+        // row max on the raw scores (ragged last tile masked), then p = exp2(S*log2e - m) as one FMA + v_exp
         const bool ragged = (kt * 64 + 64 > T);
         float mx = NEG_BIG;
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                float sv = S[u][i] * LOG2E;
                 if (ragged) {
                     const int key = kt * 64 + 32 * u + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                    if (key >= T) sv = NEG_BIG;
+                    if (key >= T) S[u][i] = NEG_BIG;
                 }
-                S[u][i] = sv;
-                mx = fmaxf(mx, sv);
+                mx = fmaxf(mx, S[u][i]);
             }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m, mx);
-        const float alpha = exp2f(m - m_new);
+        const float m_new = fmaxf(m, mx * LOG2E);  // every tile holds at least one real key, so m_new is finite
         float psum = 0.f;
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float pv = (S[u][i] <= NEG_TEST) ? 0.f : exp2f(S[u][i] - m_new);
+                const float pv = __builtin_amdgcn_exp2f(fmaf(S[u][i], LOG2E, -m_new));  // masked: exp2(-1e30) = 0
                 S[u][i] = pv;
                 psum += pv;
             }
-        l = l * alpha + psum;
-        m = m_new;
+        if (__any(m_new > m)) {  // wave-uniform: the running max rarely moves after the first tiles
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+            l *= alpha;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            O[0][i] *= alpha;
-            O[1][i] *= alpha;
+            for (int i = 0; i < 16; ++i) {
+                O[0][i] *= alpha;
+                O[1][i] *= alpha;
+            }
+            m = m_new;
         }
+        l += psum;
         // O^T += V^T * P^T : P^T comes straight from the S accumulators (k order of the
         // 32x32 C layout: element j of half hh is key 16s' + 8(j>>2) + 4hh + (j&3))
 #pragma unroll

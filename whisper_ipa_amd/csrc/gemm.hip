@@ -318,6 +318,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p) {
     for (int i = 0; i < NT; ++i) wp[i] = p.W + (int64_t)min(n0 + 16 * i + frow, p.N - 1) * p.ldw_b + fq * 16;
 #pragma unroll
     for (int j = 0; j < MT; ++j) xp[j] = p.A + (int64_t)min(m0 + 16 * j + frow, p.M - 1) * p.lda_b + fq * 16;
+    // epilogue operands (bias, device-side output offset) are fetched NOW so their memory round trip
+    // overlaps the weight stream instead of following it
+    const bool vec = p.vec_ok != 0;
+    int64_t coff_dev = p.c_offset + (int64_t)kz * p.slab_stride;
+    if (p.c_offset_dev) coff_dev += *p.c_offset_dev;
+    if (kz > 0) p.bias = nullptr;  // partial slabs: the bias rides on slice 0 only
+    EpiCol cols[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) cols[i] = epi_col(p, n0 + 16 * i + 4 * fq);
     f32x4 acc[NT][MT];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
@@ -374,16 +383,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p) {
 #pragma unroll
     for (int t = 0; t < NT * MT; ++t) red[wave][t][lane] = acc[t / MT][t % MT];
     __syncthreads();
-    const bool vec = p.vec_ok != 0;
-    int64_t coff_dev = p.c_offset + (int64_t)kz * p.slab_stride;
-    if (p.c_offset_dev) coff_dev += *p.c_offset_dev;
-    if (kz > 0) p.bias = nullptr;  // partial slabs: the bias rides on slice 0 only
-    for (int t = wave; t < NT * MT; t += NW) {
-        f32x4 s = red[0][t][lane];
 #pragma unroll
-        for (int w = 1; w < NW; ++w) s += red[w][t][lane];
-        const int i = t / MT, j = t - i * MT;
-        epilogue4<OutT>(p, s, epi_row(p, m0 + 16 * j + frow, coff_dev), epi_col(p, n0 + 16 * i + 4 * fq), vec);
+    for (int t0 = 0; t0 < NT * MT; t0 += NW) {
+        const int t = t0 + wave;
+        if (t < NT * MT) {
+            f32x4 s = red[0][t][lane];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) s += red[w][t][lane];
+            const int i = t / MT, j = t - i * MT;
+            const EpiCol cc = (NT == 1 || i == 0) ? cols[0] : cols[NT - 1];  // NT <= 2: static register indices
+            epilogue4<OutT>(p, s, epi_row(p, m0 + 16 * j + frow, coff_dev), cc, vec);
+        }
     }
 }
 
