@@ -205,6 +205,77 @@ def test_small_width_f32_encoder_and_greedy(small2):
     assert (res.tokens == ref.tokens).all(), (res.tokens.tolist(), ref.tokens.tolist(), ref.margins.min())
 
 
+@pytest.mark.parametrize("name,dims", [
+    ("medium-width", R.ModelDimensions(80, 1500, 1024, 16, 1, 51865, 448, 1024, 16, 1)),
+    ("large-v3-width", R.ModelDimensions(128, 1500, 1280, 20, 1, 51866, 448, 1280, 20, 1)),
+])
+def test_other_model_widths_f32(name, dims):
+    """BASELINE configs 4/5 use whisper-medium (d=1024, 16 heads) and large-v3 (d=1280, 20 heads, 128 mels,
+    51 866 tokens, 100 languages): one layer of each width through the same kernels, f32, against the oracle."""
+    import whisper_ipa_amd as wipa
+    from whisper_ipa_amd.decoding import greedy_decode_tokens
+
+    W = R.synthetic_weights(dims, seed=21)
+    audio = R.synthetic_clip(3, 30.0)[None]
+    mel_ref = R.log_mel_spectrogram(audio[0], dims.n_mels)[None]
+    with torch.no_grad():
+        xa = R.encoder_forward(W, dims, torch.from_numpy(mel_ref))
+    m = _model(dims, W, torch.float32)
+    mel = wipa.log_mel_spectrogram(audio, n_mels=dims.n_mels)
+    assert np.abs(mel.cpu().numpy() - mel_ref).max() < 1e-3
+    feats = m.encoder(mel)
+    err = (feats.cpu() - xa).abs().max().item()
+    assert err < 1e-3, (name, err)
+    sp = R.SpecialTokens.multilingual(100 if dims.n_vocab == 51866 else 99)
+    assert m.num_languages == sp.n_langs
+    always, first = R.suppress_lists(sp)
+    init = list(sp.sot_sequence_including_notimestamps(0))
+    res = greedy_decode_tokens(m, feats, init, always, first, sp.eot, max_new_tokens=10, stop_on_eot=False)
+    with torch.no_grad():
+        ref = R.greedy_decode(W, dims, xa, init, always, first, sp.eot, sample_len=10, stop_on_eot=False)
+    assert (res.tokens == ref.tokens).all(), (name, res.tokens.tolist(), ref.tokens.tolist(), ref.margins.min())
+
+
+def test_full_size_bench_workload_properties():
+    """BASELINE configs[1] at FULL size (whisper-small 12+12 layers, bf16, 64 clips x 30 s): properties that do
+    not need the (too slow) CPU oracle at this size --
+      * batch invariance: a clip's features and token ids do not depend on which batch it rides in
+        (clips 0..3 alone == rows 0..3 of the 64-clip batch, bit for bit);
+      * determinism: two runs give identical ids;
+      * prompt echo and vocabulary range; suppressed ids never appear."""
+    import bench
+    from whisper_ipa_amd import audio as A
+    from whisper_ipa_amd.decoding import greedy_decode_tokens
+    from whisper_ipa_amd.whisper import Whisper
+
+    dims, W = bench.synthetic_weights_small(0)
+    m = Whisper(dims, dtype=torch.bfloat16)
+    m.load_weights(W)
+    del W
+    init, always, first, eot = bench.decode_setup()
+    audio = torch.from_numpy(bench.synthetic_audio(0, 64)).cuda()
+    audio[5, 16000 * 5:] = 0  # one short clip + zero padding, like the dataset's <= 6 s clips
+
+    def run(a):
+        mel = A.log_mel_padded(a, dims.n_mels, torch.bfloat16)
+        feats = m.encode_padded(mel, a.shape[0])
+        res = greedy_decode_tokens(m, feats, init, always, first, eot, max_new_tokens=16, stop_on_eot=False)
+        return feats.float().cpu(), res.tokens
+
+    f64, t64 = run(audio)
+    f64b, t64b = run(audio)
+    assert torch.equal(f64, f64b) and (t64 == t64b).all()
+    f4, t4 = run(audio[:4].contiguous())
+    assert torch.equal(f4, f64[:4]), (f4 - f64[:4]).abs().max()
+    assert (t4 == t64[:4]).all()
+    assert t64.shape == (64, 4 + 16) and (t64[:, :4] == np.array(init)).all()
+    body = t64[:, 4:]
+    assert body.min() >= 0 and body.max() < dims.n_vocab
+    assert not np.isin(body, np.array(always)).any()
+    assert not np.isin(body[:, 0], np.array(first)).any()
+    assert torch.isfinite(f64).all() and len({tuple(r) for r in body.tolist()}) > 8  # rows differ (audio dependence)
+
+
 def test_small_width_bf16_close_and_tokens_match_where_margin_allows(small2):
     """bf16 path (the bench configuration's arithmetic) against the f32 oracle: features within
     bf16 tolerance; greedy tokens must equal the oracle's up to the first step whose oracle

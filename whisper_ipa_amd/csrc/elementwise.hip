@@ -77,6 +77,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
 
 // Decode-step variant: ONE workgroup per row (few rows -> spread them over many CUs), fused with
 // the fixed-order sum of the split-K partial slabs of the preceding residual GEMM.
+constexpr int LN_MAX_SLABS = 4;
 template <typename TO>
 __global__ __launch_bounds__(256) void add_slabs_layernorm_kernel(float* __restrict__ x, int64_t ldx,
                                                                    const float* __restrict__ slabs, int n_slabs,
@@ -87,16 +88,26 @@ __global__ __launch_bounds__(256) void add_slabs_layernorm_kernel(float* __restr
     const int row = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* xr = x + (int64_t)row * ldx;
-    f32x4 v[2];
+    f32x4 v[2], ww[2], bb[2];
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int c = tid * 4 + 1024 * i;
-        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        v[i] = ww[i] = bb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (c < D) {
+            // every load of the row (x, up to LN_MAX_SLABS slabs, w, b) is issued before the first use:
+            // one memory round trip instead of one per slab
             v[i] = *reinterpret_cast<const f32x4*>(xr + c);
-            for (int s = 0; s < n_slabs; ++s)
-                v[i] += *reinterpret_cast<const f32x4*>(slabs + (int64_t)s * slab_stride + (int64_t)row * ldx + c);
+            f32x4 sl[LN_MAX_SLABS];
+#pragma unroll
+            for (int s = 0; s < LN_MAX_SLABS; ++s)
+                sl[s] = (s < n_slabs) ? *reinterpret_cast<const f32x4*>(slabs + (int64_t)s * slab_stride + (int64_t)row * ldx + c)
+                                      : f32x4{0.f, 0.f, 0.f, 0.f};
+            ww[i] = *reinterpret_cast<const f32x4*>(w + c);
+            bb[i] = *reinterpret_cast<const f32x4*>(b + c);
+#pragma unroll
+            for (int s = 0; s < LN_MAX_SLABS; ++s)
+                if (s < n_slabs) v[i] += sl[s];  // fixed order s = 0, 1, ...
             if (n_slabs > 0) *reinterpret_cast<f32x4*>(xr + c) = v[i];
             sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
@@ -127,11 +138,9 @@ __global__ __launch_bounds__(256) void add_slabs_layernorm_kernel(float* __restr
     for (int i = 0; i < 2; ++i) {
         const int c = tid * 4 + 1024 * i;
         if (c < D) {
-            const f32x4 ww = *reinterpret_cast<const f32x4*>(w + c);
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(b + c);
             f32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * ww[e] + bb[e];
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * ww[i][e] + bb[i][e];
             st4<TO>(yr + c, o);
         }
     }
@@ -343,6 +352,7 @@ extern "C" int wipa_add_slabs_layernorm(float* x, int64_t ldx, const float* slab
                                         int y_dtype, int64_t ldy, const float* w, const float* b, int rows, int D, float eps,
                                         wipa_stream_t stream) {
     WIPA_REQUIRE(x && y && w && b && (slabs || n_slabs == 0), "wipa_add_slabs_layernorm: null pointer");
+    WIPA_REQUIRE(n_slabs >= 0 && n_slabs <= LN_MAX_SLABS, "wipa_add_slabs_layernorm: n_slabs=%d (max %d)", n_slabs, LN_MAX_SLABS);
     WIPA_REQUIRE(D % 4 == 0 && D > 0 && D <= 2048, "wipa_add_slabs_layernorm: D=%d must be a multiple of 4 and <= 2048", D);
     WIPA_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && slab_stride % 4 == 0, "wipa_add_slabs_layernorm: strides must be multiples of 4");
     if (rows <= 0) return WIPA_OK;
