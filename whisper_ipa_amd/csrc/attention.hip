@@ -28,7 +28,7 @@ struct AttnParams {
     const int32_t* q_row_dev;
     float* lse;  // optional [B, H, Tq]: log-sum-exp of every score row (saved for the backward pass)
     int64_t q_bs, q_rs, q_hs, k_bs, k_rs, k_hs, v_bs, v_rs, v_hs, o_bs, o_rs, o_hs;
-    int Tq, Tk, causal;
+    int Tq, Tk, causal, H;
 };
 
 constexpr int GA_LD = 68;  // padded f32 row (64 + 4): conflict-free ds_read_b128 across 16 keys
@@ -162,7 +162,9 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(AttnParams p) {
 // =============================================================================
 // K11 decode-step cross-attention
 // =============================================================================
-template <typename T>
+// WPH = waves per (b,h): 4 (the workgroup's waves split the keys; long caches, e.g. 1500 cross keys) or
+// 1 (every wave owns one head and walks all its keys; short self-attention caches: no LDS merge, 4x fewer workgroups)
+template <typename T, int WPH>
 __global__ __launch_bounds__(256) void decode_attn_kernel(AttnParams p) {
     constexpr int EPL = Vec16<T>::EPL;  // elements per 16-byte load
     constexpr int LPK = 64 / EPL;       // lanes per key row (64 dims)
@@ -170,8 +172,10 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(AttnParams p) {
     constexpr int U = 4;                // independent key groups in flight per iteration
     __shared__ float s_m[4], s_l[4];
     __shared__ float s_acc[4][64];
-    const int h = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = WPH == 4 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave, b = blockIdx.y;
+    if (WPH == 1 && h >= p.H) return;  // no workgroup barrier on this path
+    const int kw = WPH == 4 ? wave : 0;
     const int g = lane / LPK, c = lane % LPK;
     const int Tk = p.Tk + (p.tk_dev ? *p.tk_dev : 0);
     const int q_row0 = p.q_row_dev ? *p.q_row_dev : 0;
@@ -225,8 +229,8 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(AttnParams p) {
         }
         m = m_new;
     };
-    constexpr int STEP = 4 * G * U;
-    int t0 = wave * G * U;
+    constexpr int STEP = WPH * G * U;
+    int t0 = kw * G * U;
     if (t0 < Tk) {
         Vec16<T> ka[U], va[U], kb2[U], vb2[U];
         load_group(t0, ka, va);
@@ -253,6 +257,15 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(AttnParams p) {
 #pragma unroll
         for (int e = 0; e < EPL; ++e) acc[e] = acc[e] * a + __shfl_xor(acc[e], o, 64) * bsc;
         m = m_n;
+    }
+    if (WPH == 1) {
+        if (lane < LPK) {
+            const float inv = 1.f / l;
+            T* op = reinterpret_cast<T*>(p.out) + b * p.o_bs + h * p.o_hs + c * EPL;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) op[e] = from_f32<T>(acc[e] * inv);
+        }
+        return;
     }
     if (lane < LPK) {
 #pragma unroll
@@ -492,6 +505,7 @@ static int fill_attn_params(const wipa_attn_desc* d, AttnParams& p) {
     p.Tq = d->Tq;
     p.Tk = d->Tk;
     p.causal = d->causal;
+    p.H = d->H;
     return WIPA_OK;
 }
 
@@ -505,11 +519,21 @@ extern "C" int wipa_decode_attn(const wipa_attn_desc* d, wipa_stream_t stream) {
                  "wipa_decode_attn: strides must keep 16-byte alignment");
     AttnParams p;
     fill_attn_params(d, p);
-    dim3 grid(d->H, d->B);
-    if (d->dtype == WIPA_F32)
-        hipLaunchKernelGGL((decode_attn_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL((decode_attn_kernel<__bf16>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    // short caches (the growing self-attention cache, <= n_text_ctx keys): one wave per head; long ones: 4 waves
+    const bool short_cache = d->Tk + (d->tk_dev ? 448 : 0) <= 512;
+    if (short_cache) {
+        dim3 grid((d->H + 3) / 4, d->B);
+        if (d->dtype == WIPA_F32)
+            hipLaunchKernelGGL((decode_attn_kernel<float, 1>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else
+            hipLaunchKernelGGL((decode_attn_kernel<__bf16, 1>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        dim3 grid(d->H, d->B);
+        if (d->dtype == WIPA_F32)
+            hipLaunchKernelGGL((decode_attn_kernel<float, 4>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else
+            hipLaunchKernelGGL((decode_attn_kernel<__bf16, 4>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    }
     WIPA_LAUNCH_CHECK();
     return WIPA_OK;
 }

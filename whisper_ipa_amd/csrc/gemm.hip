@@ -37,6 +37,7 @@ struct GemmParams {
     float col_scale;
     int tiles_m, tiles_n;
     int vec_ok;
+    int stage_ok;  // epilogue_staged may be used (16-byte row-major stores are legal for this output mapping)
     int k_slices;
     int64_t slab_stride;
 };
@@ -171,6 +172,111 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, const f32x4& a, c
         for (int r = 0; r < 4; ++r) v[r] = 0.f;
     }
     store4<OutT>(p.C, off, v, Cc.nvalid, vec);
+}
+
+// ---------------------------------------------------------------------------------------
+// Staged epilogue of one wave's [16*MTILES rows x 64 columns] accumulator block.  The MFMA C layout
+// gives a lane 4 consecutive columns of ONE row, i.e. 8/16-byte stores that touch 16 different rows per
+// instruction: 32 store instructions per lane for a 128x64 block, issue-bound (the store tail cost as
+// much as half the K=768 main loop).  Here every 16-row slice goes through a wave-private 4 KiB LDS
+// scratch (f32, 256-byte rows, 16-byte chunk index XOR row) and comes back ROW-major: a lane then owns
+// 16 output bytes of one row and 8 (bf16) / 16 (f32) consecutive lanes cover a whole 128/256-byte row
+// segment -> half / equal the store instructions, all full-line, and bias / residual / positional
+// operands are read with the same coalesced shape.
+template <typename OutT, int MTILES>
+__device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x4 (&acc)[4][MTILES], char* scratch, int m_base,
+                                                int n_base, int64_t coff_dev, int lane) {
+    constexpr int EPC = 16 / (int)sizeof(OutT);  // output elements per lane per store (8 bf16 / 4 f32)
+    constexpr int LPR = 64 / EPC;                // lanes per 64-column row segment
+    constexpr int RPP = 64 / LPR;                // rows per pass
+    constexpr int NCH = EPC / 4;                 // 16-byte f32 chunks a lane reads back
+    const int frow = lane & 15, fq = lane >> 4;
+    const int rrow = lane / LPR, cch = lane % LPR;
+    const int n = n_base + cch * EPC;
+    // column context of this lane (constant over the rows)
+    const bool col_ok = n < p.N;
+    const int nvalid = min(EPC, p.N - n);
+    int cgi = 0, cgr = n;
+    if (p.cg_in < p.N) {
+        cgi = n / p.cg_in;
+        cgr = n - cgi * p.cg_in;
+    }
+    const int64_t coff = (int64_t)cgi * p.cg_stride + cgr;
+    float bias[EPC], sc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        bias[e] = (p.bias && !p.bias_along_m && col_ok && e < nvalid) ? p.bias[n + e] : 0.f;
+        sc[e] = (n + e < p.col_scale_n) ? p.col_scale : 1.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < MTILES; ++j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<f32x4*>(scratch + frow * 256 + (((4 * i + fq) ^ frow) << 4)) = acc[i][j];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private scratch: in-order DS, no barrier needed
+#pragma unroll
+        for (int pass = 0; pass < 16 / RPP; ++pass) {
+            const int row = pass * RPP + rrow;
+            float v[EPC];
+#pragma unroll
+            for (int t = 0; t < NCH; ++t) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(scratch + row * 256 + (((cch * NCH + t) ^ row) << 4));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * t + e] = a[e];
+            }
+            const EpiRow R = epi_row(p, m_base + 16 * j + row, coff_dev);
+            if (!R.store || !col_ok) continue;
+            const int64_t off = R.roff + coff;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) v[e] = (v[e] + bias[e] + R.bm) * sc[e];
+            if (p.act == 1) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] = gelu_erf(v[e]);
+            }
+            if (p.pos) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e)
+                    if (e < nvalid) v[e] += p.pos[(int64_t)R.gr * p.ldpos + n + e];
+            }
+            const bool full = nvalid == EPC;
+            if (p.residual) {
+                const OutT* rp = reinterpret_cast<const OutT*>(p.residual) + off;
+                if (full) {
+                    if constexpr (sizeof(OutT) == 4) {
+                        const f32x4 r = *reinterpret_cast<const f32x4*>(rp);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += r[e];
+                    } else {
+                        const bf16x8 r = *reinterpret_cast<const bf16x8*>(rp);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e)
+                        if (e < nvalid) v[e] += to_f32<OutT>(rp[e]);
+                }
+            }
+            if (!R.valid) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] = 0.f;
+            }
+            OutT* cp = reinterpret_cast<OutT*>(p.C) + off;
+            if (full) {
+                if constexpr (sizeof(OutT) == 4) {
+                    *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+                } else {
+                    *reinterpret_cast<bf16x8*>(cp) = bf16x8{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3],
+                                                            (__bf16)v[4], (__bf16)v[5], (__bf16)v[6], (__bf16)v[7]};
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e)
+                    if (e < nvalid) cp[e] = from_f32<OutT>(v[e]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next slice overwrites the scratch
+    }
 }
 
 constexpr int BM = 128, BN = 128, ROWB = 128;  // ROWB: bytes of K per LDS row
@@ -519,6 +625,10 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
     const bool vec = p.vec_ok != 0;
     int64_t coff_dev = p.c_offset;
     if (p.c_offset_dev) coff_dev += *p.c_offset_dev;
+    if (p.stage_ok) {  // the last barrier of the K loop has retired every LDS read: reuse it as per-wave scratch
+        epilogue_staged<OutT, 8>(p, acc, smem + wave * 4096, m0 + wm * 128, n0 + wn * 64, coff_dev, lane);
+        return;
+    }
     EpiCol cols[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) cols[i] = epi_col(p, n0 + wn * 64 + 16 * i + 4 * fq);
@@ -661,14 +771,19 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p) {
             stage(1);
             stage(2);
         }
-        EpiCol cols[4];
+        if (p.stage_ok) {
+            // LDS stage buffer 3 is idle until the next tile's first barrier: 8 x 4 KiB of wave-private scratch
+            epilogue_staged<OutT, 8>(p, acc, smem + 3 * PSTAGE + wave * 4096, m0 + wm * 128, n0 + wn * 64, coff_dev, lane);
+        } else {
+            EpiCol cols[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) cols[i] = epi_col(p, n0 + wn * 64 + 16 * i + 4 * fq);
+            for (int i = 0; i < 4; ++i) cols[i] = epi_col(p, n0 + wn * 64 + 16 * i + 4 * fq);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const EpiRow row = epi_row(p, m0 + wm * 128 + 16 * j + frow, coff_dev);
+            for (int j = 0; j < 8; ++j) {
+                const EpiRow row = epi_row(p, m0 + wm * 128 + 16 * j + frow, coff_dev);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) epilogue4<OutT>(p, acc[i][j], row, cols[i], vec);
+                for (int i = 0; i < 4; ++i) epilogue4<OutT>(p, acc[i][j], row, cols[i], vec);
+            }
         }
         if (!more) break;
         m0 = m1;
@@ -793,6 +908,13 @@ extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
     p.vec_ok = (p.ldc % valign == 0) && (p.rg_stride % valign == 0) && (p.cg_stride % valign == 0) &&
                (p.cg_in % 4 == 0) && (p.c_offset % valign == 0) && (((uintptr_t)d->C) % 16 == 0) &&
                (!d->residual || ((uintptr_t)d->residual) % 16 == 0);
+    {
+        const int64_t epc = 16 / osz;  // elements per 16-byte row-major store
+        static const int no_stage = [] { const char* e = getenv("WIPA_GEMM_NO_STAGE"); return e ? atoi(e) : 0; }();
+        p.stage_ok = !no_stage && (p.ldc % epc == 0) && (p.rg_stride % epc == 0) && (p.cg_stride % epc == 0) &&
+                     (p.cg_in % epc == 0) && (p.c_offset % epc == 0) && !d->c_offset_dev && (((uintptr_t)d->C) % 16 == 0) &&
+                     (!d->residual || ((uintptr_t)d->residual) % 16 == 0);
+    }
     hipStream_t s = (hipStream_t)stream;
     {
         const int rc = init_attrs();
@@ -809,7 +931,9 @@ extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
     }();
     const bool big = force_tile >= 256 ||  // 256: 2-stage kernel, 257: pipelined kernel, for every shape
                      (force_tile != 128 && d->M >= 512 && d->N >= 256 && (int64_t)d->M * d->N >= (1 << 20));
-    if (big && force_tile != 256 && (d->K * esz) / PROWB >= 3) {  // default: 4-stage LDS-DMA pipeline
+    // Measured r01 (encoder shapes, MI355X): the persistent 4-stage pipeline is 3-6 % SLOWER than the plain 2-stage
+    // kernel at K = 768 and K = 3072 (582 vs 551 us on mlp1 without GELU), so it is opt-in (WIPA_GEMM_TILE=257).
+    if (big && force_tile == 257 && (d->K * esz) / PROWB >= 3) {
         if (d->in_dtype == WIPA_BF16)
             return d->out_dtype == WIPA_BF16 ? launch256p<__bf16, __bf16>(p, s) : launch256p<__bf16, float>(p, s);
         return d->out_dtype == WIPA_BF16 ? launch256p<float, __bf16>(p, s) : launch256p<float, float>(p, s);
