@@ -8,6 +8,10 @@ resident in HBM: log-mel -> encoder -> cross-K/V -> prompt + 64 greedy decode po
 (KV cached, EOT latch on, no early stop so the work is fixed) -> token ids on the host.
 N > 1: clips are sharded data-parallel, one process per GPU, no data-path collective
 (weak scaling); the only collective is the barrier / max-reduce of the timing itself.
+Consecutive passes are software-pipelined: up to `--pipeline` (default 3) passes are in flight on
+separate HIP streams with separate workspaces / KV caches, each doing ALL of its work inside the
+timed region, so the encoder of one batch overlaps the decode loop of the previous one
+(`ms_per_step` = timed wall time / steps, i.e. the steady-state time per 64-clip batch).
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed on the launch
 stream) and `cpu_baseline` (the CPU oracle = a port, timed on this box's host cores on a
@@ -49,6 +53,9 @@ def host_cores() -> int:
 
 
 BATCH = 64          # clips per GPU
+N_PIPELINE = 3      # consecutive passes kept in flight on separate HIP streams (see --pipeline).  Measured r01
+                    # (ms per 64-clip pass): 1 -> 133.2, 2 -> 106.9, 3 -> 99.3, 4 -> 108.1, 6 -> 99.9: the MFMA-bound
+                    # encoder of pass i+1 runs in the shadows of the launch/HBM-bound decode loop of pass i
 N_STREAMS = 1       # sub-batches of the 64 clips, one HIP stream each (measured r01: 1 -> 162 ms,
                     # 2 -> 156 ms, 4 -> 200 ms, 8 -> 266 ms per pass: the per-step cost of the decode
                     # loop is launch/latency bound and does not shrink with the sub-batch)
@@ -141,13 +148,28 @@ def one_pass(model, audio_chunks, setup):
     from whisper_ipa_amd.decoding import greedy_collect, greedy_launch
     from whisper_ipa_amd.runtime import use_stream
 
+    return pass_collect(pass_launch(model, audio_chunks, setup, 0))
+
+
+def pass_launch(model, audio_chunks, setup, stream_base: int):
+    """enqueue one whole pass (asynchronously) on library streams stream_base, stream_base+1, ..."""
+    from whisper_ipa_amd import audio as A
+    from whisper_ipa_amd.decoding import greedy_launch
+    from whisper_ipa_amd.runtime import use_stream
+
     init, always, first, eot = setup
     handles = []
     for sid, a in enumerate(audio_chunks):
-        with use_stream(sid):
+        with use_stream(stream_base + sid):
             mel = A.log_mel_padded(a, model.dims.n_mels, model.dtype)
             feats = model.encode_padded(mel, a.shape[0])
             handles.append(greedy_launch(model, feats, init, always, first, eot, max_new_tokens=NEW_TOKENS))
+    return handles
+
+
+def pass_collect(handles):
+    from whisper_ipa_amd.decoding import greedy_collect
+
     return np.concatenate([greedy_collect(h).tokens for h in handles], axis=0)
 
 
@@ -235,10 +257,11 @@ def cpu_baseline(n_clips: int = 1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--streams", type=int, default=N_STREAMS, help="clip sub-batches run on this many HIP streams")
+    ap.add_argument("--pipeline", type=int, default=N_PIPELINE, help="consecutive passes kept in flight on separate HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -271,7 +294,8 @@ def main():
     log("model + audio resident on the GPU")
 
     for i in range(args.warmup):
-        one_pass(model, audio_chunks, setup)
+        for pset in range(args.pipeline):  # warm every stream set (workspaces, KV caches, captured graphs)
+            pass_collect(pass_launch(model, audio_chunks, setup, pset * args.streams))
         torch.cuda.synchronize()
         log(f"warmup pass {i} done")
     torch.cuda.synchronize()
@@ -279,8 +303,16 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tokens = one_pass(model, audio_chunks, setup)
+    # --pipeline P > 1: pass i runs on stream set (i % P) and is only collected when its stream set is needed
+    # again, so the encoder of pass i+1 can overlap the decode loop of pass i (each pass still does all its work
+    # inside the timed region; every pass owns separate workspaces / KV caches)
+    inflight = []
+    for i in range(args.steps):
+        if len(inflight) == args.pipeline:
+            tokens = pass_collect(inflight.pop(0))
+        inflight.append(pass_launch(model, audio_chunks, setup, (i % args.pipeline) * args.streams))
+    while inflight:
+        tokens = pass_collect(inflight.pop(0))
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -309,7 +341,7 @@ def main():
             "data": "synthetic (seeded noise clips, random-init whisper-small weights)",
             "config": {"workload": f"whisper-small bf16 batched inference, batch={B}x30s synthetic clips per GPU, "
                                    f"log-mel + encoder + cross-KV + {NEW_TOKENS} greedy KV-cached decode steps",
-                       "clips_per_gpu": B, "new_tokens": NEW_TOKENS, "streams_per_gpu": args.streams,
+                       "clips_per_gpu": B, "new_tokens": NEW_TOKENS, "streams_per_gpu": args.streams, "passes_in_flight": args.pipeline,
                        "parallelism": f"dp{world} (clip sharding, no collective)"},
             "tokens_checksum": int(tokens.sum() % 1000003),
         }

@@ -404,7 +404,7 @@ template <typename T, typename OutT, int MT, int NT, int NW>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p) {
     __shared__ f32x4 red[NW][MT * NT][64];
     typedef typename Mma<T>::Frag Frag;
-    constexpr int UB = (NT == 1) ? 6 : 4;  // k-steps whose loads are in flight together
+    constexpr int UB = (NT == 1) ? 6 : (NT == 2 ? 4 : 3);  // k-steps whose loads are in flight together
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int frow = lane & 15, fq = lane >> 4;
     const int n0 = blockIdx.x * (16 * NT);
@@ -497,7 +497,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p) {
 #pragma unroll
             for (int w = 1; w < NW; ++w) s += red[w][t][lane];
             const int i = t / MT, j = t - i * MT;
-            const EpiCol cc = (NT == 1 || i == 0) ? cols[0] : cols[NT - 1];  // NT <= 2: static register indices
+            EpiCol cc = cols[0];  // select with static register indices (i is wave dependent)
+#pragma unroll
+            for (int ii = 1; ii < NT; ++ii)
+                if (i == ii) cc = cols[ii];
             epilogue4<OutT>(p, s, epi_row(p, m0 + 16 * j + frow, coff_dev), cc, vec);
         }
     }
@@ -514,6 +517,7 @@ int launch_skinny_cfg(const GemmParams& p, hipStream_t s) {
 template <typename T, typename OutT, int MT>
 int launch_skinny_mt(const GemmParams& p, hipStream_t s) {
     const int ksteps = p.K * (int)sizeof(T) / 64 / p.k_slices;
+    if (p.N >= 8192 && MT == 4) return launch_skinny_cfg<T, OutT, MT, 4, 4>(p, s);  // logits: 64 columns per workgroup
     if (p.N >= 8192) return launch_skinny_cfg<T, OutT, MT, 2, 4>(p, s);
     if (ksteps >= 64) return launch_skinny_cfg<T, OutT, MT, 1, 8>(p, s);
     return launch_skinny_cfg<T, OutT, MT, 1, 4>(p, s);
