@@ -25,6 +25,11 @@ import os
 import sys
 import time
 
+# The pipelined passes live on several HIP streams; ROCm multiplexes streams onto GPU_MAX_HW_QUEUES hardware
+# queues (default 4).  Measured r01 with 4 passes in flight: 2 queues 119.9 ms, 4 -> 108.4, 8 -> 95.4 per pass.
+# Must be set before the HIP runtime starts (i.e. before torch touches the GPU).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
@@ -53,9 +58,10 @@ def host_cores() -> int:
 
 
 BATCH = 64          # clips per GPU
-N_PIPELINE = 3      # consecutive passes kept in flight on separate HIP streams (see --pipeline).  Measured r01
-                    # (ms per 64-clip pass): 1 -> 133.2, 2 -> 106.9, 3 -> 99.3, 4 -> 108.1, 6 -> 99.9: the MFMA-bound
-                    # encoder of pass i+1 runs in the shadows of the launch/HBM-bound decode loop of pass i
+N_PIPELINE = 4      # consecutive passes kept in flight on separate HIP streams (see --pipeline).  Measured r01 with
+                    # GPU_MAX_HW_QUEUES=8 (ms per 64-clip pass, repeatable to 0.5 %): 1 -> 133.2, 3 -> 98.8, 4 -> 94.7,
+                    # 5 -> 123.5: the MFMA-bound encoder of later passes runs in the shadows of the launch/HBM-bound
+                    # decode loops of earlier ones
 N_STREAMS = 1       # sub-batches of the 64 clips, one HIP stream each (measured r01: 1 -> 162 ms,
                     # 2 -> 156 ms, 4 -> 200 ms, 8 -> 266 ms per pass: the per-step cost of the decode
                     # loop is launch/latency bound and does not shrink with the sub-batch)
@@ -342,6 +348,7 @@ def main():
             "config": {"workload": f"whisper-small bf16 batched inference, batch={B}x30s synthetic clips per GPU, "
                                    f"log-mel + encoder + cross-KV + {NEW_TOKENS} greedy KV-cached decode steps",
                        "clips_per_gpu": B, "new_tokens": NEW_TOKENS, "streams_per_gpu": args.streams, "passes_in_flight": args.pipeline,
+                       "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "parallelism": f"dp{world} (clip sharding, no collective)"},
             "tokens_checksum": int(tokens.sum() % 1000003),
         }
