@@ -229,22 +229,15 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(AttnParams p) {
         }
         m = m_new;
     };
+    // One register set (U K-rows + U V-rows in flight per lane), latency hidden by the other waves of the CU.
+    // A register double-buffer measured the same 5.4 TB/s stand-alone but needs 135 VGPRs; the lean form keeps
+    // the kernel small enough to share a SIMD with the 2 x 212-VGPR waves of the encoder GEMM of another
+    // in-flight pass (see bench.py --pipeline), where it can use the HBM bandwidth the GEMM leaves idle.
     constexpr int STEP = WPH * G * U;
-    int t0 = kw * G * U;
-    if (t0 < Tk) {
-        Vec16<T> ka[U], va[U], kb2[U], vb2[U];
+    for (int t0 = kw * G * U; t0 < Tk; t0 += STEP) {
+        Vec16<T> ka[U], va[U];
         load_group(t0, ka, va);
-        for (;;) {
-            const int t1 = t0 + STEP;
-            if (t1 < Tk) load_group(t1, kb2, vb2);
-            consume_group(t0, ka, va);
-            if (t1 >= Tk) break;
-            const int t2 = t1 + STEP;
-            if (t2 < Tk) load_group(t2, ka, va);
-            consume_group(t1, kb2, vb2);
-            if (t2 >= Tk) break;
-            t0 = t2;
-        }
+        consume_group(t0, ka, va);
     }
     // merge the G key groups of this wave (lanes with equal c)
 #pragma unroll
