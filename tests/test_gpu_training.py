@@ -286,6 +286,18 @@ def test_train_script_end_to_end_artefacts(tmp_path, capsys):
     model2 = TS.load_checkpoint_model(str(out / "checkpoint-3"), str(model_dir))
     assert torch.equal(model2.flat_parameters()["decoder.blocks.0.mlp1.weight"].cpu(), saved["decoder.blocks.0.mlp1.weight"])
     assert isinstance(TS.transcribe_file(model2, entries[0]["audio_path"]), str)
+    # evaluate_model flow (reference evaluate_model.py:127-232): batched decode == clip-by-clip decode
+    import evaluate_model as EM
+    res = EM.main(["--checkpoint", str(out / "checkpoint-3"), "--base-model", str(model_dir), "--test-data", str(tmp_path / "test.json"),
+                   "--num-samples", "0", "--n-mels", "80", "--batch-size", "3", "--results-json", str(tmp_path / "res.json")])
+    text = capsys.readouterr().out
+    assert "Base Whisper Model - Overall Results" in text and "Model Comparison" in text and "Evaluation Complete" in text
+    assert res["trained"]["num_samples"] == 4 and {"per", "pfer", "per_std", "pfer_std"} <= set(res["base"])
+    assert json.load(open(tmp_path / "res.json"))["trained"]["per"] == res["trained"]["per"]
+    opts = EM.DecodingOptions(language="en", without_timestamps=True)
+    paths = [e["audio_path"] for e in entries[:4]]
+    assert EM.transcribe_batch(model2, paths, 80, opts) == [EM.transcribe_batch(model2, [p], 80, opts)[0] for p in paths]
+    assert EM.transcribe_batch(model2, [paths[0], str(tmp_path / "missing.wav")], 80, opts)[1] == ""
 
 
 def _dp_worker(rank, world, port, q):

@@ -154,7 +154,11 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, const f32x4& a, c
     for (int r = 0; r < 4; ++r) v[r] = (a[r] + Cc.b[r] + R.bm) * Cc.sc[r];
     if (p.act == 1) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+        for (int r = 0; r < 4; r += 2) {
+            const f32x2 g = gelu_erf2(f32x2{v[r], v[r + 1]});
+            v[r] = g.x;
+            v[r + 1] = g.y;
+        }
     }
     if (p.pos) {
 #pragma unroll
@@ -231,7 +235,11 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x4
             for (int e = 0; e < EPC; ++e) v[e] = (v[e] + bias[e] + R.bm) * sc[e];
             if (p.act == 1) {
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) v[e] = gelu_erf(v[e]);
+                for (int e = 0; e < EPC; e += 2) {
+                    const f32x2 g = gelu_erf2(f32x2{v[e], v[e + 1]});
+                    v[e] = g.x;
+                    v[e + 1] = g.y;
+                }
             }
             if (p.pos) {
 #pragma unroll
@@ -551,7 +559,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][W tile | A tile]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
 
     const int nblocks = p.tiles_m * p.tiles_n;
@@ -571,23 +579,26 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
     const int tile_n = in_group / gm;
     const int m0 = tile_m * LBM, n0 = tile_n * LBN;
 
-    // staging: pass i covers rows 64*i + 8*wave + (lane>>3); lane's physical chunk is lane&7
-    const char* gW[4];
-    const char* gA[4];
+    // staging: pass i covers rows 64*i + 8*wave + (lane>>3); lane's physical chunk is lane&7.  The DMA is the BUFFER
+    // form (buffer_load_dwordx4 ... lds): one resource per operand tile (SGPRs), a per-lane 32-bit byte offset computed
+    // once, and the K-step as the scalar offset -- no 64-bit VALU address arithmetic per piece in the loop.
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (int64_t)n0 * p.ldw_b), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)m0 * p.lda_b), 0, 0x7fffffff, 0x00020000);
+    int oW[4], oA[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = 64 * i + 8 * wave + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);
-        gW[i] = p.W + (int64_t)min(n0 + row, p.N - 1) * p.ldw_b + c * 16;
-        gA[i] = p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda_b + c * 16;
+        oW[i] = (min(n0 + row, p.N - 1) - n0) * (int)p.ldw_b + c * 16;
+        oA[i] = (min(m0 + row, p.M - 1) - m0) * (int)p.lda_b + c * 16;
     }
     auto stage = [&](int kt, int buf) {
-        const int64_t kb = (int64_t)kt * ROWB;
+        const int kb = kt * ROWB;
         char* base = smem + buf * (2 * LTILE) + wave * (8 * ROWB);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gW[i] + kb), (lds_ptr_t)(base + i * 64 * ROWB), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gA[i] + kb), (lds_ptr_t)(base + LTILE + i * 64 * ROWB), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)(base + i * 64 * ROWB), 16, oW[i], kb, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(base + LTILE + i * 64 * ROWB), 16, oA[i], kb, 0, 0);
         }
     };
 
@@ -933,8 +944,10 @@ extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
         const char* e = getenv("WIPA_GEMM_TILE");  // debugging / A-B timing: 128 or 256
         return e ? atoi(e) : 0;
     }();
-    const bool big = force_tile >= 256 ||  // 256: 2-stage kernel, 257: pipelined kernel, for every shape
-                     (force_tile != 128 && d->M >= 512 && d->N >= 256 && (int64_t)d->M * d->N >= (1 << 20));
+    // the 256-tile kernels address a tile with 32-bit buffer offsets: 256 rows x row pitch + K bytes must stay below 2^31
+    const bool pitch_ok = p.lda_b < (1 << 22) && p.ldw_b < (1 << 22) && d->K * esz < (1 << 22);
+    const bool big = pitch_ok && (force_tile >= 256 ||  // 256: 2-stage kernel, 257: pipelined kernel, for every shape
+                                  (force_tile != 128 && d->M >= 512 && d->N >= 256 && (int64_t)d->M * d->N >= (1 << 20)));
     // Measured r01 (encoder shapes, MI355X): the persistent 4-stage pipeline is 3-6 % SLOWER than the plain 2-stage
     // kernel at K = 768 and K = 3072 (582 vs 551 us on mlp1 without GELU), so it is opt-in (WIPA_GEMM_TILE=257).
     if (big && force_tile == 257 && (d->K * esz) / PROWB >= 3) {

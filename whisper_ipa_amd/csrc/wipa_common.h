@@ -106,4 +106,24 @@ __device__ __forceinline__ float erf_fast(float x) {
     return copysignf(y, x);
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
+
+// Two GELUs at once for the GEMM epilogues, written so that the arithmetic maps onto the packed-f32 VALU
+// (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth per issue slot).  Same Abramowitz-Stegun 7.1.26 series as
+// erf_fast, folded into the normal CDF:  Phi(x) = 1 - h (x >= 0), h (x < 0),  h = 0.5 P(t) exp(-x^2/2),
+// t = 1 / (1 + 0.3275911 |x| / sqrt(2)),  and  gelu(x) = x Phi(x) = max(x, 0) - |x| h.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+    const f32x2 ax = __builtin_elementwise_abs(x);
+    const f32x2 d = __builtin_elementwise_fma(f32x2{0.2316418882f, 0.2316418882f}, ax, f32x2{1.f, 1.f});
+    const f32x2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    f32x2 p = __builtin_elementwise_fma(f32x2{0.5307027145f, 0.5307027145f}, t, f32x2{-0.7265760135f, -0.7265760135f});
+    p = __builtin_elementwise_fma(p, t, f32x2{0.7107068705f, 0.7107068705f});
+    p = __builtin_elementwise_fma(p, t, f32x2{-0.142248368f, -0.142248368f});
+    p = __builtin_elementwise_fma(p, t, f32x2{0.127414796f, 0.127414796f});
+    p = p * t;
+    const f32x2 s = x * 0.8493218003f;  // sqrt(log2(e) / 2): exp(-x^2/2) = exp2(-s^2)
+    const f32x2 s2 = s * s;
+    const f32x2 e = {__builtin_amdgcn_exp2f(-s2.x), __builtin_amdgcn_exp2f(-s2.y)};
+    return __builtin_elementwise_fma(-ax, p * e, __builtin_elementwise_max(x, f32x2{0.f, 0.f}));
+}
 #endif
