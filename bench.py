@@ -8,7 +8,7 @@ resident in HBM: log-mel -> encoder -> cross-K/V -> prompt + 64 greedy decode po
 (KV cached, EOT latch on, no early stop so the work is fixed) -> token ids on the host.
 N > 1: clips are sharded data-parallel, one process per GPU, no data-path collective
 (weak scaling); the only collective is the barrier / max-reduce of the timing itself.
-Consecutive passes are software-pipelined: up to `--pipeline` (default 3) passes are in flight on
+Consecutive passes are software-pipelined: up to `--pipeline` (default 4) passes are in flight on
 separate HIP streams with separate workspaces / KV caches, each doing ALL of its work inside the
 timed region, so the encoder of one batch overlaps the decode loop of the previous one
 (`ms_per_step` = timed wall time / steps, i.e. the steady-state time per 64-clip batch).

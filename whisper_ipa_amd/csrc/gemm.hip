@@ -206,12 +206,10 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x4
         cgr = n - cgi * p.cg_in;
     }
     const int64_t coff = (int64_t)cgi * p.cg_stride + cgr;
-    float bias[EPC], sc[EPC];
+    float bias[EPC];
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-        bias[e] = (p.bias && !p.bias_along_m && col_ok && e < nvalid) ? p.bias[n + e] : 0.f;
-        sc[e] = (n + e < p.col_scale_n) ? p.col_scale : 1.0f;
-    }
+    for (int e = 0; e < EPC; ++e) bias[e] = (p.bias && !p.bias_along_m && col_ok && e < nvalid) ? p.bias[n + e] : 0.f;
+    const float sc = n < p.col_scale_n ? p.col_scale : 1.0f;  // stage_ok guarantees col_scale_n % EPC == 0: one decision per lane
 #pragma unroll
     for (int j = 0; j < MTILES; ++j) {
 #pragma unroll
@@ -232,7 +230,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x4
             if (!R.store || !col_ok) continue;
             const int64_t off = R.roff + coff;
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) v[e] = (v[e] + bias[e] + R.bm) * sc[e];
+            for (int e = 0; e < EPC; ++e) v[e] = (v[e] + bias[e] + R.bm) * sc;
             if (p.act == 1) {
 #pragma unroll
                 for (int e = 0; e < EPC; e += 2) {
@@ -927,7 +925,7 @@ extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
         const int64_t epc = 16 / osz;  // elements per 16-byte row-major store
         static const int no_stage = [] { const char* e = getenv("WIPA_GEMM_NO_STAGE"); return e ? atoi(e) : 0; }();
         p.stage_ok = !no_stage && (p.ldc % epc == 0) && (p.rg_stride % epc == 0) && (p.cg_stride % epc == 0) &&
-                     (p.cg_in % epc == 0) && (p.c_offset % epc == 0) && !d->c_offset_dev && (((uintptr_t)d->C) % 16 == 0) &&
+                     (p.cg_in % epc == 0) && (p.c_offset % epc == 0) && (p.col_scale_n % epc == 0) && !d->c_offset_dev && (((uintptr_t)d->C) % 16 == 0) &&
                      (!d->residual || ((uintptr_t)d->residual) % 16 == 0);
     }
     hipStream_t s = (hipStream_t)stream;
