@@ -275,13 +275,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(local_rank)
+    # Rehearsal on a one-GPU box: WIPA_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo for the two timing
+    # collectives (RCCL refuses two ranks on one device); the driver's real runs use one GPU per rank and RCCL.
+    share_gpu = os.environ.get("WIPA_BENCH_SHARE_GPU") == "1"
+    device_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist  # RCCL: only for the timing barrier / max-reduce
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
 
     from whisper_ipa_amd.whisper import Whisper
 
