@@ -87,7 +87,7 @@ typedef struct wipa_gemm_desc {
     int32_t act; /* 0 none, 1 gelu(erf) */
     int32_t col_scale_n;
     float col_scale;
-    int32_t k_slices; /* 0/1: whole K.  >1 (M <= 64 only): K is cut into k_slices contiguous slices
+    int32_t k_slices; /* 0/1: whole K.  >1 (M <= 256 only): K is cut into k_slices contiguous slices
                        * computed by different workgroups; slice z writes its PARTIAL sums (bias in
                        * slice 0 only, no act/pos/residual) to C + z*slab_stride -- to be summed in a
                        * fixed order by wipa_add_slabs_layernorm (deterministic split-K). */

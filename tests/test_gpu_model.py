@@ -274,6 +274,11 @@ def test_full_size_bench_workload_properties():
     assert not np.isin(body, np.array(always)).any()
     assert not np.isin(body[:, 0], np.array(first)).any()
     assert torch.isfinite(f64).all() and len({tuple(r) for r in body.tolist()}) > 8  # rows differ (audio dependence)
+    # a batch beyond the 64-row skinny-GEMM group (decode projections ride on grid.y): rows 0..63 unchanged
+    audio96 = torch.cat([audio, torch.from_numpy(bench.synthetic_audio(64, 32)).cuda()])
+    f96, t96 = run(audio96)
+    assert torch.equal(f96[:64], f64) and (t96[:64] == t64).all()
+    assert len({tuple(r) for r in t96[64:, 4:].tolist()}) > 4
 
 
 def test_small_width_bf16_close_and_tokens_match_where_margin_allows(small2):

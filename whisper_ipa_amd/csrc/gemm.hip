@@ -536,7 +536,7 @@ int launch_skinny(const GemmParams& p, hipStream_t s) {
     return launch_skinny_mt<T, OutT, 4>(p, s);
 }
 
-constexpr int SKINNY_MAX_M = 64;
+constexpr int SKINNY_MAX_M = 256;  // rows beyond 64 ride on grid.y: every 64-row group streams the (L2-resident) weight slice again
 
 // ---------------------------------------------------------------------------------------
 // Large-tile GEMM: 256x256 output tile, 8 waves (2 along M x 4 along N, 128x64 per wave =

@@ -258,7 +258,7 @@ int enqueue_step(const wipa_model_cfg* cfg, const void* const* w, char* st, cons
     auto residual_gemm = [&](const void* A, int K, const void* W, const void* bias) -> int {
         wipa_gemm_desc g;
         memset(&g, 0, sizeof(g));
-        g.k_slices = B <= 64 ? k_slices_for(K, dt) : 1;  // split-K lives in the skinny (M <= 64) kernel
+        g.k_slices = B <= 256 ? k_slices_for(K, dt) : 1;  // split-K lives in the skinny (M <= 256) kernel
         g.slab_stride = slab_stride;
         pend = g.k_slices;
         return gemm(A, K, W, K, slabs, d, B, d, K, dt, WIPA_F32, (const float*)bias, 0, nullptr, stream, &g);
