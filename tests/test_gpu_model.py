@@ -142,6 +142,43 @@ def test_greedy_eot_latch_and_early_stop():
     assert np.abs(res.sum_logprobs - ref.sum_logprobs).max() < 1e-3
 
 
+def test_greedy_full_length_and_batch_of_one(micro):
+    """Edge cases of the decode loop: the reference's maximum sample length (n_text_ctx // 2 = 224 new tokens, the
+    self-KV cache crossing every wave-split / tail boundary of the decode attention) and a batch of ONE clip, both
+    bit-exact against the oracle's greedy loop."""
+    from whisper_ipa_amd.decoding import greedy_decode_tokens
+
+    W, mels, xa = micro
+    sp = R.SpecialTokens.multilingual()
+    always, first = R.suppress_lists(sp)
+    init = list(sp.sot_sequence_including_notimestamps(0))
+    m = _model(MICRO, W, torch.float32)
+    n = MICRO.n_text_ctx // 2
+    res = greedy_decode_tokens(m, xa.cuda(), init, always, first, sp.eot, max_new_tokens=n, stop_on_eot=False)
+    with torch.no_grad():
+        ref = R.greedy_decode(W, MICRO, xa, init, always, first, sp.eot, sample_len=n, stop_on_eot=False)
+    assert res.tokens.shape == (2, 4 + n) == ref.tokens.shape
+    gate = np.cumprod(ref.margins > 1e-3, axis=1).astype(bool)  # compare up to the first fp32 near-tie, if any
+    assert gate[:, :64].all()
+    assert (res.tokens[:, 4:][gate] == ref.tokens[:, 4:][gate]).all()
+    one = greedy_decode_tokens(m, xa[:1].cuda(), init, always, first, sp.eot, max_new_tokens=32, stop_on_eot=False)
+    assert (one.tokens[0] == res.tokens[0, : 4 + 32]).all()
+
+
+def test_teacher_forced_rows_longer_than_the_text_context_are_refused(micro):
+    """ipa_data_loader.py:124-131 does not truncate, so a row can exceed n_text_ctx = 448; the reference then fails on
+    the positional-embedding slice.  Here the C ABI reports it instead of reading past the table."""
+    from whisper_ipa_amd._lib import WipaError
+
+    W, mels, xa = micro
+    m = _model(MICRO, W, torch.float32)
+    ok = torch.randint(0, 50000, (1, MICRO.n_text_ctx), dtype=torch.int64).cuda()
+    assert m.logits(ok, xa[:1].cuda()).shape == (1, MICRO.n_text_ctx, MICRO.n_vocab)
+    too_long = torch.randint(0, 50000, (1, MICRO.n_text_ctx + 1), dtype=torch.int64).cuda()
+    with pytest.raises((WipaError, ValueError)):
+        m.logits(too_long, xa[:1].cuda())
+
+
 def test_detect_language_matches_oracle(micro):
     from whisper_ipa_amd.decoding import detect_language
     from whisper_ipa_amd.tokenizer import get_tokenizer
