@@ -365,28 +365,38 @@ __global__ __launch_bounds__(256, 2) void flash_enc_bf16_kernel(const __bf16* __
         }
         // row max on the raw scores (ragged last tile masked), then p = exp2(S*log2e - m) as one FMA + v_exp
         const bool ragged = (kt * 64 + 64 > T);
+        if (ragged) {  // last tile only.  The empty asm keeps this a scalar BRANCH: if-converted, the 32 compares and
+                       // selects ran on every tile and cost as much VALU time as the softmax itself.
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kt * 64 + 32 * u + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    if (key >= T) S[u][i] = NEG_BIG;
+                }
+        }
         float mx = NEG_BIG;
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (ragged) {
-                    const int key = kt * 64 + 32 * u + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                    if (key >= T) S[u][i] = NEG_BIG;
-                }
-                mx = fmaxf(mx, S[u][i]);
-            }
+            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, S[u][i]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m, mx * LOG2E);  // every tile holds at least one real key, so m_new is finite
-        float psum = 0.f;
+        // two scores per VALU slot (v_pk_fma_f32 / v_pk_add_f32); only the exponentials stay scalar
+        f32x2 psum2 = {0.f, 0.f};
+        const f32x2 l2e = {LOG2E, LOG2E}, mneg = {-m_new, -m_new};
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float pv = __builtin_amdgcn_exp2f(fmaf(S[u][i], LOG2E, -m_new));  // masked: exp2(-1e30) = 0
-                S[u][i] = pv;
-                psum += pv;
+            for (int i = 0; i < 16; i += 2) {
+                const f32x2 x = __builtin_elementwise_fma(f32x2{S[u][i], S[u][i + 1]}, l2e, mneg);  // masked: exp2(-1e30) = 0
+                const f32x2 pv = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+                S[u][i] = pv.x;
+                S[u][i + 1] = pv.y;
+                psum2 += pv;
             }
+        const float psum = psum2.x + psum2.y;
         if (__any(m_new > m)) {  // wave-uniform: the running max rarely moves after the first tiles
             const float alpha = __builtin_amdgcn_exp2f(m - m_new);
             l *= alpha;
