@@ -210,14 +210,33 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x4
 #pragma unroll
     for (int e = 0; e < EPC; ++e) bias[e] = (p.bias && !p.bias_along_m && col_ok && e < nvalid) ? p.bias[n + e] : 0.f;
     const float sc = n < p.col_scale_n ? p.col_scale : 1.0f;  // stage_ok guarantees col_scale_n % EPC == 0: one decision per lane
+    // The residual of slice j+1 is fetched while slice j goes through the LDS transpose: without this each pass issued its
+    // own dependent 16-byte load and the f32-residual epilogue ran at ~1.7x its HBM time.
+    constexpr int NPASS = 16 / RPP;
+    const bool res_vec = p.residual != nullptr && col_ok && nvalid == EPC;
+    Vec16<OutT> rnext[NPASS];
+    auto fetch_residual = [&](int j, Vec16<OutT> (&dst)[NPASS]) {
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const EpiRow R = epi_row(p, m_base + 16 * j + pass * RPP + rrow, coff_dev);
+            if (R.store) dst[pass] = *reinterpret_cast<const Vec16<OutT>*>(reinterpret_cast<const OutT*>(p.residual) + R.roff + coff);
+        }
+    };
+    if (res_vec) fetch_residual(0, rnext);
 #pragma unroll
     for (int j = 0; j < MTILES; ++j) {
+        Vec16<OutT> rcur[NPASS];
+        if (res_vec) {
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) rcur[pass] = rnext[pass];
+            if (j + 1 < MTILES) fetch_residual(j + 1, rnext);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             *reinterpret_cast<f32x4*>(scratch + frow * 256 + (((4 * i + fq) ^ frow) << 4)) = acc[i][j];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private scratch: in-order DS, no barrier needed
 #pragma unroll
-        for (int pass = 0; pass < 16 / RPP; ++pass) {
+        for (int pass = 0; pass < NPASS; ++pass) {
             const int row = pass * RPP + rrow;
             float v[EPC];
 #pragma unroll
@@ -248,15 +267,8 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x4
             if (p.residual) {
                 const OutT* rp = reinterpret_cast<const OutT*>(p.residual) + off;
                 if (full) {
-                    if constexpr (sizeof(OutT) == 4) {
-                        const f32x4 r = *reinterpret_cast<const f32x4*>(rp);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += r[e];
-                    } else {
-                        const bf16x8 r = *reinterpret_cast<const bf16x8*>(rp);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
-                    }
+                    for (int e = 0; e < EPC; ++e) v[e] += rcur[pass].get(e);
                 } else {
 #pragma unroll
                     for (int e = 0; e < EPC; ++e)
