@@ -665,170 +665,6 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// Pipelined 256x256 GEMM: same tile / wave decomposition as gemm_nt256_kernel, but the K-step is
-// 64 BYTES per row and FOUR LDS stages of 32 KiB rotate, filled by LDS-DMA three stages ahead.
-// The loop never drains the DMA queue: a counted s_waitcnt vmcnt(8) retires only the stage about to
-// be read (4 DMAs per stage per thread, 2 younger stages stay in flight across the raw s_barrier),
-// so the ~1-2 us global->LDS latency is covered by three stages of MFMAs instead of stalling every
-// K-step (the 2-stage kernel above waits vmcnt(0) once per K-step).
-// LDS rows are 64 B; bank swizzle on 16-byte chunks: phys = chunk ^ f((row>>2)&3), f = {0,2,3,1},
-// which makes every ds_read_b128 lane group of gfx950 hit 16 distinct slots.
-constexpr int PROWB = 64;                 // bytes of K per LDS row and stage
-constexpr int PTILE = LBM * PROWB;        // 16 KiB per operand tile
-constexpr int PSTAGE = 2 * PTILE;         // 32 KiB
-constexpr int PSTAGES = 4;
-constexpr int PSMEM = PSTAGES * PSTAGE;   // 128 KiB
-
-__device__ __forceinline__ int pswz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
-
-template <typename T, typename OutT>
-__global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [4 stages][W tile | A tile]
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
-
-    // PERSISTENT: one workgroup per CU walks the tile list (XCD-contiguous chunks, GROUP_M super-rows).
-    // The LDS-DMA of the NEXT tile's first three stages is issued before the epilogue of the current
-    // tile, so the global->LDS latency of a tile start and the output stores overlap instead of adding.
-    const int ntiles = p.tiles_m * p.tiles_n;
-    const int nwg = gridDim.x;
-    auto tile_of = [&](int seq, int& m0, int& n0) {
-        // seq-th tile of this workgroup -> global tile id: XCD x owns a contiguous chunk of the id space
-        const int q = ntiles >> 3, r = ntiles & 7;
-        const int xcd = blockIdx.x & 7;
-        const int first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-        const int count = q + (xcd < r ? 1 : 0);
-        const int local = (blockIdx.x >> 3) + seq * (nwg >> 3);  // nwg is a multiple of 8
-        if (local >= count) return false;
-        const int id = first + local;
-        const int group_size = GROUP_M * p.tiles_n;
-        const int group = id / group_size;
-        const int first_m = group * GROUP_M;
-        const int gm = min(p.tiles_m - first_m, GROUP_M);
-        const int in_group = id - group * group_size;
-        m0 = (first_m + in_group % gm) * LBM;
-        n0 = (in_group / gm) * LBN;
-        return true;
-    };
-
-    // staging: round i covers rows 128*i + 16*wave + (lane>>2); lane's physical chunk is lane&3
-    const char* gW[2];
-    const char* gA[2];
-    auto set_tile = [&](int m0, int n0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = 128 * i + 16 * wave + (lane >> 2);
-            const int c = (lane & 3) ^ pswz(row);
-            gW[i] = p.W + (int64_t)min(n0 + row, p.N - 1) * p.ldw_b + c * 16;
-            gA[i] = p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda_b + c * 16;
-        }
-    };
-    auto stage = [&](int kt) {
-        const int64_t kb = (int64_t)kt * PROWB;
-        char* base = smem + (kt & (PSTAGES - 1)) * PSTAGE + wave * (16 * PROWB);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gW[i] + kb), (lds_ptr_t)(base + i * 128 * PROWB), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gA[i] + kb), (lds_ptr_t)(base + PTILE + i * 128 * PROWB), 16, 0, 0);
-        }
-    };
-
-    f32x4 acc[4][8];  // [n tile i][m tile j]
-    const int frow = lane & 15;
-    const int fq = lane >> 4;
-    const int coff = (fq ^ pswz(frow)) << 4;  // rows 16x + frow share (row>>2)&3 with frow
-    const int nk = p.K * (int)sizeof(T) / PROWB;
-
-    auto compute = [&](int kt) {
-        const char* wb = smem + (kt & (PSTAGES - 1)) * PSTAGE + (wn * 64 + frow) * PROWB + coff;
-        const char* ab = smem + (kt & (PSTAGES - 1)) * PSTAGE + PTILE + (wm * 128 + frow) * PROWB + coff;
-        typename Mma<T>::Frag fw[4], fx[8];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fw[i] = *reinterpret_cast<const typename Mma<T>::Frag*>(wb + i * 16 * PROWB);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) fx[j] = *reinterpret_cast<const typename Mma<T>::Frag*>(ab + j * 16 * PROWB);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) Mma<T>::run(fw[i], fx[j], acc[i][j]);
-    };
-
-    const bool vec = p.vec_ok != 0;
-    int64_t coff_dev = p.c_offset;
-    if (p.c_offset_dev) coff_dev += *p.c_offset_dev;
-
-    int m0, n0;
-    if (!tile_of(0, m0, n0)) return;
-    set_tile(m0, n0);
-    // three stages in flight (nk >= 3 is guaranteed by the dispatcher; nk % 4 == 0 is NOT required)
-    stage(0);
-    stage(1);
-    stage(2);
-    for (int seq = 0;; ++seq) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int kt = 0; kt < nk - 2; ++kt) {
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // stage kt landed (this wave's part); kt+1, kt+2 in flight
-            __builtin_amdgcn_s_barrier();                      // ... every wave's part; everyone is done reading stage kt-1
-            if (kt + 3 < nk) stage(kt + 3);                    // refill the buffer stage kt-1 used
-            compute(kt);
-        }
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        compute(nk - 2);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        compute(nk - 1);
-
-        // next tile: start its first three stages now (LDS is free once every wave is past its last reads)
-        int m1 = 0, n1 = 0;
-        const bool more = tile_of(seq + 1, m1, n1);
-        __builtin_amdgcn_s_barrier();
-        if (more) {
-            set_tile(m1, n1);
-            // stage index k uses buffer k % 4; the next tile restarts at k = 0 -- buffers 0..2 are all free here
-            stage(0);
-            stage(1);
-            stage(2);
-        }
-        if (p.stage_ok) {
-            // LDS stage buffer 3 is idle until the next tile's first barrier: 8 x 4 KiB of wave-private scratch
-            epilogue_staged<OutT, 8>(p, acc, smem + 3 * PSTAGE + wave * 4096, m0 + wm * 128, n0 + wn * 64, coff_dev, lane);
-        } else {
-            EpiCol cols[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) cols[i] = epi_col(p, n0 + wn * 64 + 16 * i + 4 * fq);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const EpiRow row = epi_row(p, m0 + wm * 128 + 16 * j + frow, coff_dev);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) epilogue4<OutT>(p, acc[i][j], row, cols[i], vec);
-            }
-        }
-        if (!more) break;
-        m0 = m1;
-        n0 = n1;
-    }
-}
-
-template <typename T, typename OutT>
-int launch256p(GemmParams p, hipStream_t s) {
-    p.tiles_m = (p.M + LBM - 1) / LBM;
-    p.tiles_n = (p.N + LBN - 1) / LBN;
-    // persistent grid: one workgroup per CU (128 KiB of LDS each), a multiple of the 8 XCDs
-    const int ntiles = p.tiles_m * p.tiles_n;
-    int nwg = 256;
-    while (nwg > 8 && nwg / 2 >= ntiles) nwg /= 2;
-    hipLaunchKernelGGL((gemm_nt256p_kernel<T, OutT>), dim3(nwg), dim3(512), PSMEM, s, p);
-    WIPA_LAUNCH_CHECK();
-    return WIPA_OK;
-}
-
 template <typename T, typename OutT>
 int launch256(GemmParams p, hipStream_t s) {
     p.tiles_m = (p.M + LBM - 1) / LBM;
@@ -859,14 +695,6 @@ int init_attrs() {
                               reinterpret_cast<const void*>(&gemm_nt256_kernel<float, float>)};
         for (const void* f : big) {
             const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LSMEM);
-            if (e != hipSuccess) err = e;
-        }
-        const void* pipe[4] = {reinterpret_cast<const void*>(&gemm_nt256p_kernel<__bf16, __bf16>),
-                               reinterpret_cast<const void*>(&gemm_nt256p_kernel<__bf16, float>),
-                               reinterpret_cast<const void*>(&gemm_nt256p_kernel<float, __bf16>),
-                               reinterpret_cast<const void*>(&gemm_nt256p_kernel<float, float>)};
-        for (const void* f : pipe) {
-            const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, PSMEM);
             if (e != hipSuccess) err = e;
         }
     });
@@ -956,16 +784,9 @@ extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
     }();
     // the 256-tile kernels address a tile with 32-bit buffer offsets: 256 rows x row pitch + K bytes must stay below 2^31
     const bool pitch_ok = p.lda_b < (1 << 22) && p.ldw_b < (1 << 22) && d->K * esz < (1 << 22);
-    const bool big = pitch_ok && (force_tile >= 256 ||  // 256: 2-stage kernel, 257: pipelined kernel, for every shape
+    const bool big = pitch_ok && (force_tile >= 256 ||  // WIPA_GEMM_TILE=256: the 256x256 kernel for every shape
                                   (force_tile != 128 && d->M >= 512 && d->N >= 256 && (int64_t)d->M * d->N >= (1 << 20)));
-    // Measured r01 (encoder shapes, MI355X): the persistent 4-stage pipeline is 3-6 % SLOWER than the plain 2-stage
-    // kernel at K = 768 and K = 3072 (582 vs 551 us on mlp1 without GELU), so it is opt-in (WIPA_GEMM_TILE=257).
-    if (big && force_tile == 257 && (d->K * esz) / PROWB >= 3) {
-        if (d->in_dtype == WIPA_BF16)
-            return d->out_dtype == WIPA_BF16 ? launch256p<__bf16, __bf16>(p, s) : launch256p<__bf16, float>(p, s);
-        return d->out_dtype == WIPA_BF16 ? launch256p<float, __bf16>(p, s) : launch256p<float, float>(p, s);
-    }
-    if (big) {  // WIPA_GEMM_TILE=256: the 2-stage variant (kept for A/B timing)
+    if (big) {
         if (d->in_dtype == WIPA_BF16)
             return d->out_dtype == WIPA_BF16 ? launch256<__bf16, __bf16>(p, s) : launch256<__bf16, float>(p, s);
         return d->out_dtype == WIPA_BF16 ? launch256<float, __bf16>(p, s) : launch256<float, float>(p, s);
