@@ -70,16 +70,25 @@ HBM_PEAK_GBS = 8000.0
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 
-def small_dims():
+def model_dims(name: str = "small"):
+    """Published Whisper sizes.  "small" is the benchmark configuration; the others are for sizing runs
+    (`--model medium --batch 256` is BASELINE.json configs[3])."""
     from whisper_ipa_amd.whisper import ModelDimensions
 
-    return ModelDimensions(80, 1500, 768, 12, 12, 51865, 448, 768, 12, 12)
+    table = {"tiny": (80, 384, 6, 4, 51865), "base": (80, 512, 8, 6, 51865), "small": (80, 768, 12, 12, 51865),
+             "medium": (80, 1024, 16, 24, 51865), "large-v3": (128, 1280, 20, 32, 51866)}
+    n_mels, d, heads, layers, vocab = table[name]
+    return ModelDimensions(n_mels, 1500, d, heads, layers, vocab, 448, d, heads, layers)
 
 
-def synthetic_weights_small(seed: int = 0):
-    """Random-init whisper-small in mlx_whisper naming (no checkpoint exists offline).  Same
+def small_dims():
+    return model_dims("small")
+
+
+def synthetic_weights_small(seed: int = 0, name: str = "small"):
+    """Random-init whisper-<name> in mlx_whisper naming (no checkpoint exists offline).  Same
     recipe as the oracle's generator, restated here so the product path does not import it."""
-    dims = small_dims()
+    dims = model_dims(name)
     g = torch.Generator().manual_seed(seed)
     std, emb_std, pos_std, out_scale = 0.06, 0.2, 1.2, 4.0
 
@@ -269,6 +278,8 @@ def main():
     ap.add_argument("--streams", type=int, default=N_STREAMS, help="clip sub-batches run on this many HIP streams")
     ap.add_argument("--pipeline", type=int, default=N_PIPELINE, help="consecutive passes kept in flight on separate HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", default="small", choices=["tiny", "base", "small", "medium", "large-v3"],
+                    help="sizing runs only: the benchmark metric is quoted on whisper-small")
     args = ap.parse_args()
 
     torch.set_num_threads(host_cores())
@@ -294,7 +305,7 @@ def main():
 
     B = args.batch
     log(f"start: rank {rank}/{world}, host cores {host_cores()}")
-    dims, W = synthetic_weights_small(0)
+    dims, W = synthetic_weights_small(0, args.model)
     log("weights generated")
     model = Whisper(dims, dtype=torch.bfloat16)
     model.load_weights(W)
@@ -340,7 +351,7 @@ def main():
     if rank == 0:
         audio_seconds = world * B * 30.0 * args.steps
         out = {
-            "metric": "audio-seconds/sec transcribed (whisper-small, 30s clips)",
+            "metric": f"audio-seconds/sec transcribed (whisper-{args.model}, 30s clips)",
             "value": round(audio_seconds / elapsed, 1),
             "unit": "audio-s/s",
             "n_gpus": world,
@@ -351,8 +362,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "bf16",
-            "data": "synthetic (seeded noise clips, random-init whisper-small weights)",
-            "config": {"workload": f"whisper-small bf16 batched inference, batch={B}x30s synthetic clips per GPU, "
+            "data": f"synthetic (seeded noise clips, random-init whisper-{args.model} weights)",
+            "config": {"workload": f"whisper-{args.model} bf16 batched inference, batch={B}x30s synthetic clips per GPU, "
                                    f"log-mel + encoder + cross-KV + {NEW_TOKENS} greedy KV-cached decode steps",
                        "clips_per_gpu": B, "new_tokens": NEW_TOKENS, "streams_per_gpu": args.streams, "passes_in_flight": args.pipeline,
                        "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
@@ -362,7 +373,7 @@ def main():
         log(f"timed region done: {elapsed:.3f} s for {args.steps} passes")
         out["roofline"] = roofline_cross_attn(model, audio_chunks[0].shape[0])
         log("roofline microbench done")
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model == "small":
             out["cpu_baseline"] = cpu_baseline(1)
             log("cpu baseline done")
         print(json.dumps(out), flush=True)
