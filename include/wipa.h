@@ -87,10 +87,11 @@ typedef struct wipa_gemm_desc {
     int32_t act; /* 0 none, 1 gelu(erf) */
     int32_t col_scale_n;
     float col_scale;
-    int32_t k_slices; /* 0/1: whole K.  >1 (M <= 256 only): K is cut into k_slices contiguous slices
+    int32_t k_slices; /* 0/1: whole K.  >1: K is cut into k_slices contiguous slices
                        * computed by different workgroups; slice z writes its PARTIAL sums (bias in
                        * slice 0 only, no act/pos/residual) to C + z*slab_stride -- to be summed in a
-                       * fixed order by wipa_add_slabs_layernorm (deterministic split-K). */
+                       * fixed order by wipa_add_slabs_layernorm or wipa_sum_slabs (deterministic split-K).  M <= 256
+                       * runs in the weight-streaming kernel, larger M in the 128x128 tile kernel. */
 } wipa_gemm_desc;
 int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t s);
 
@@ -258,8 +259,12 @@ int wipa_masked_ce(const float* logits, int64_t ldl, const int32_t* tokens, int6
 /* out[c][r] = in[r][c]; out columns rows..rows_pad-1 are written as zero (K padding for wipa_gemm). */
 int wipa_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int rows, int cols, int rows_pad, int dtype,
                    wipa_stream_t s);
-/* out[c] (+)= sum_r x[r][c]  (bias gradients). */
-int wipa_colsum(const float* x, int64_t ld, int rows, int cols, float* out, int accumulate, wipa_stream_t s);
+/* out[c] (+)= sum_r x[r][c]  (bias gradients), summed in a fixed order.  workspace (optional, f32): with at least
+ * 2*cols floats the rows are cut into up to 64 chunks reduced by separate workgroups (partials in the workspace). */
+int wipa_colsum(const float* x, int64_t ld, int rows, int cols, float* out, int accumulate, float* workspace,
+                int64_t workspace_floats, wipa_stream_t s);
+/* out[i] (+)= sum over k of slabs[k * slab_stride + i], k ascending: the reduction of a split-K wipa_gemm (k_slices > 1). */
+int wipa_sum_slabs(const float* slabs, int n_slabs, int64_t slab_stride, float* out, int64_t n, int accumulate, wipa_stream_t s);
 /* LayerNorm backward: dx (+)= ..., dw, db; stats f32 [2*rows] scratch (mean, rstd). x, dy, dx contiguous [rows, D]. */
 int wipa_layernorm_bwd(const float* x, const float* dy, const float* w, float* dx, int accumulate_dx, float* dw, float* db,
                        float* stats, int rows, int D, float eps, wipa_stream_t s);

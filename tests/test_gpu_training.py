@@ -37,10 +37,29 @@ def test_transpose_and_colsum():
     cs = torch.empty(133).cuda()
     with on_stream() as s:
         _lib.check(L.wipa_transpose(ptr(a), 133, ptr(out), 96, 70, 133, 96, 0, sptr(s)))
-        _lib.check(L.wipa_colsum(ptr(a), 133, 70, 133, ptr(cs), 0, sptr(s)))
+        _lib.check(L.wipa_colsum(ptr(a), 133, 70, 133, ptr(cs), 0, None, 0, sptr(s)))
     torch.cuda.synchronize()
     assert torch.equal(out[:, :70], a.T) and (out[:, 70:] == 0).all()
     assert _rel(cs, a.sum(0)) < 1e-6
+    # many rows: chunked two-pass reduction through the workspace (ragged last chunk, accumulate, deterministic)
+    big = torch.randn(3001, 200, generator=g).cuda()[:, :133]  # row stride 200
+    ws = torch.empty(64 * 133).cuda()
+    acc0 = torch.randn(133, generator=g).cuda()
+    outs = []
+    for _ in range(2):
+        cs2 = acc0.clone()
+        with on_stream() as s:
+            _lib.check(L.wipa_colsum(ptr(big), 200, 3001, 133, ptr(cs2), 1, ptr(ws), ws.numel(), sptr(s)))
+        torch.cuda.synchronize()
+        outs.append(cs2)
+    assert torch.equal(outs[0], outs[1])
+    assert _rel(outs[0], acc0 + big.double().sum(0).float()) < 1e-5
+    small_ws = torch.empty(3 * 133).cuda()  # room for 3 chunks only
+    cs3 = torch.empty(133).cuda()
+    with on_stream() as s:
+        _lib.check(L.wipa_colsum(ptr(big), 200, 3001, 133, ptr(cs3), 0, ptr(small_ws), small_ws.numel(), sptr(s)))
+    torch.cuda.synchronize()
+    assert _rel(cs3, big.double().sum(0).float()) < 1e-5
 
 
 @pytest.mark.parametrize("causal,Tq,Tk", [(True, 21, 21), (False, 13, 150), (True, 70, 70)])

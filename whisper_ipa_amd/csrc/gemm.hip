@@ -368,12 +368,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
     const int frow = lane & 15;
     const int fsw = (lane >> 1) & 7;  // == ((row >> 1) & 7) for row = 16*x + (lane & 15)
     const int fq = lane >> 4;
-    const int nk = p.K * (int)sizeof(T) / ROWB;
+    // split-K (weight gradients: small M x N, very long K): slice blockIdx.y of k_slices owns a contiguous range of
+    // K-steps and writes its partial tile to slab blockIdx.y; the caller adds the slabs in order (wipa_sum_slabs)
+    const int nk_all = p.K * (int)sizeof(T) / ROWB;
+    const int kz = blockIdx.y;
+    const int k_per = nk_all / p.k_slices, k_rem = nk_all % p.k_slices;
+    const int kt0 = kz * k_per + min(kz, k_rem);
+    const int nk = kt0 + k_per + (kz < k_rem ? 1 : 0);
 
-    gload(0);
-    swrite(0);
+    if (kt0 < nk) {
+        gload(kt0);
+        swrite(kt0 & 1);
+    }
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt0; kt < nk; ++kt) {
         if (kt + 1 < nk) gload(kt + 1);
         const char* wb = smem + (kt & 1) * (2 * TILE_BYTES) + (wn * 64 + frow) * ROWB;
         const char* ab = smem + (kt & 1) * (2 * TILE_BYTES) + TILE_BYTES + (wm * 64 + frow) * ROWB;
@@ -397,8 +405,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
 
     // ---- epilogue
     const bool vec = p.vec_ok != 0;
-    int64_t coff_dev = p.c_offset;
+    int64_t coff_dev = p.c_offset + (int64_t)kz * p.slab_stride;
     if (p.c_offset_dev) coff_dev += *p.c_offset_dev;
+    if (kz > 0) p.bias = nullptr;  // partial slabs: the bias rides on slice 0 only
     EpiCol cols[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) cols[i] = epi_col(p, n0 + wn * 64 + 16 * i + 4 * fq);
@@ -704,7 +713,7 @@ int init_attrs() {
 
 template <typename T, typename OutT>
 int launch(const GemmParams& p, hipStream_t s) {
-    hipLaunchKernelGGL((gemm_nt_kernel<T, OutT>), dim3(p.tiles_m * p.tiles_n), dim3(256), SMEM_BYTES, s, p);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, OutT>), dim3(p.tiles_m * p.tiles_n, p.k_slices), dim3(256), SMEM_BYTES, s, p);
     WIPA_LAUNCH_CHECK();
     return WIPA_OK;
 }
@@ -751,7 +760,6 @@ extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
     p.k_slices = d->k_slices > 1 ? d->k_slices : 1;
     p.slab_stride = d->slab_stride;
     if (p.k_slices > 1) {
-        WIPA_REQUIRE(d->M <= SKINNY_MAX_M, "wipa_gemm: k_slices needs M <= %d (M=%d)", SKINNY_MAX_M, d->M);
         WIPA_REQUIRE(!d->residual && !d->pos && d->act == 0 && d->col_scale_n == 0,
                      "wipa_gemm: k_slices writes partial sums: no residual/pos/act/col_scale");
         WIPA_REQUIRE(p.k_slices <= 16 && d->slab_stride % 4 == 0, "wipa_gemm: bad k_slices / slab_stride");
@@ -784,7 +792,8 @@ extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
     }();
     // the 256-tile kernels address a tile with 32-bit buffer offsets: 256 rows x row pitch + K bytes must stay below 2^31
     const bool pitch_ok = p.lda_b < (1 << 22) && p.ldw_b < (1 << 22) && d->K * esz < (1 << 22);
-    const bool big = pitch_ok && (force_tile >= 256 ||  // WIPA_GEMM_TILE=256: the 256x256 kernel for every shape
+    const bool big = pitch_ok && p.k_slices == 1 && (  // split-K beyond the skinny rows lives in the 128x128 kernel
+                     force_tile >= 256 ||  // WIPA_GEMM_TILE=256: the 256x256 kernel for every shape
                                   (force_tile != 128 && d->M >= 512 && d->N >= 256 && (int64_t)d->M * d->N >= (1 << 20)));
     if (big) {
         if (d->in_dtype == WIPA_BF16)

@@ -86,6 +86,8 @@ class DecoderTrainer:
             self.norms = torch.empty(self.n_seg, dtype=torch.float32, device=dev)
         model._invalidate()
         self.step_count = 0
+        self._colsum_ws = None  # partial sums of the chunked bias-gradient reduction (wipa_colsum)
+        self._dw_slabs = None   # split-K partial weight gradients (wipa_gemm k_slices + wipa_sum_slabs)
 
     # ---- views into the flat buffers
     def p(self, name: str) -> torch.Tensor:
@@ -130,10 +132,25 @@ class DecoderTrainer:
         dyT = self._transpose(dy, M, N, Mp)  # [N, Mp]
         if xT is None:
             xT = self._transpose(x, M, K, Mp)
-        ops.gemm(dyT, xT, dW, M=N, N=K, K=Mp, lda=Mp, ldw=xT.stride(0), ldc=dW.stride(0))
+        # weight gradient: small [N, K] output, contraction over all M tokens.  When the tile grid alone cannot fill the
+        # chip (768 x 768 over 48 000 encoder positions is 36 tiles), K is split into slabs that are summed in order.
+        tiles = ((N + 127) // 128) * ((K + 127) // 128)
+        slices = max(1, min(16, 512 // tiles, (Mp // 32) // 8))
+        if slices > 1 and dW.is_contiguous():
+            need = slices * N * K
+            if self._dw_slabs is None or self._dw_slabs.numel() < need:
+                self._dw_slabs = torch.empty(need, dtype=torch.float32, device=dy.device)
+            ops.gemm(dyT, xT, self._dw_slabs, M=N, N=K, K=Mp, lda=Mp, ldw=xT.stride(0), ldc=K, k_slices=slices, slab_stride=N * K)
+            with on_stream() as s:
+                _lib.check(self.L.wipa_sum_slabs(ptr(self._dw_slabs), slices, N * K, ptr(dW), N * K, 0, sptr(s)), "wipa_sum_slabs")
+        else:
+            ops.gemm(dyT, xT, dW, M=N, N=K, K=Mp, lda=Mp, ldw=xT.stride(0), ldc=dW.stride(0))
         if db is not None:
             with on_stream() as s:
-                _lib.check(self.L.wipa_colsum(ptr(dy), dy.stride(0), M, N, ptr(db), 0, sptr(s)), "wipa_colsum")
+                if self._colsum_ws is None:
+                    self._colsum_ws = torch.empty(64 * 4 * self.model.dims.n_text_state, dtype=torch.float32, device=dy.device)
+                _lib.check(self.L.wipa_colsum(ptr(dy), dy.stride(0), M, N, ptr(db), 0, ptr(self._colsum_ws),
+                                              self._colsum_ws.numel(), sptr(s)), "wipa_colsum")
         return out_dx
 
     def _ln(self, x, w, b):
