@@ -144,6 +144,11 @@ int wipa_attention(const wipa_attn_desc* d, wipa_stream_t s);
  * out [B*T, ldo] bf16. */
 int wipa_flash_attn_enc_bf16(const void* qk, int64_t ldqk, const void* vt, int64_t ldvt, void* out, int64_t ldo,
                              int B, int H, int T, wipa_stream_t s);
+/* K5 in f32: the same encoder attention on the f32 MFMA (exact f32 products) for models kept in float32, as the
+ * reference's scripts do (transcribe_single.py:13, train_whisper_ipa.py:505).  q, k, v: [B*T, ld*] f32 with head h at
+ * column h*64 (q and k pre-scaled by 64^-0.25 each); out [B*T, ldo].  Row strides multiples of 4, pointers 16-byte aligned. */
+int wipa_flash_attn_enc_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, float* out,
+                            int64_t ldo, int B, int H, int T, wipa_stream_t s);
 
 /* K11/K12 decode-step attention (HBM-bound): ONE query row per (b,h) (Tq must be 1) against
  * cached K/V with the strides of wipa_attn_desc; 8 (bf16) / 16 (f32) lanes stream one 64-dim key

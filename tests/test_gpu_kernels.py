@@ -164,6 +164,26 @@ def test_flash_attention_spiked_scores(ops):
     assert _rel(out, ref) < 1.5e-2
 
 
+@pytest.mark.parametrize("T", [1500, 200, 64, 37])
+def test_flash_attention_encoder_f32(ops, T):
+    """f32 MFMA flash attention (the reference's own dtype) against softmax(QK^T)V in float64; ragged last key tile,
+    partial query block, and spiked scores that move the running maximum between tiles."""
+    g = torch.Generator().manual_seed(T)
+    B, H = 2, 3
+    D = H * 64
+    q = torch.randn(B, T, H, 64, generator=g) * 0.6
+    k = torch.randn(B, T, H, 64, generator=g) * 0.6
+    v = torch.randn(B, T, H, 64, generator=g)
+    for t in range(5, T, 61):
+        k[0, t, 1] = q[0, t % 29, 1] * (1.0 + t / 40.0)
+    qk = torch.cat([q.reshape(B * T, D), k.reshape(B * T, D)], dim=1).contiguous()
+    out = ops.flash_attn_enc_f32(qk.cuda(), v.reshape(B * T, D).contiguous().cuda(), B, H, T)
+    torch.cuda.synchronize()
+    s = torch.einsum("bqhd,bkhd->bhqk", q.double(), k.double())
+    ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1), v.double()).reshape(B * T, D).float()
+    assert _rel(out, ref) < 2e-5
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("Tk", [1500, 97, 8])
 def test_decode_cross_attention(ops, dtype, Tk):

@@ -78,6 +78,8 @@ SIGNATURES = {
     "wipa_embed_tokens": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                   c_int, c_void_p]),
     "wipa_attention": (c_int, [_P(AttnDesc), c_void_p]),
+    "wipa_flash_attn_enc_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int,
+                                       c_int, c_void_p]),
     "wipa_flash_attn_enc_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
                                          c_void_p]),
     "wipa_decode_attn": (c_int, [_P(AttnDesc), c_void_p]),

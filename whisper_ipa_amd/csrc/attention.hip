@@ -446,6 +446,161 @@ __global__ __launch_bounds__(256, 2) void flash_enc_bf16_kernel(const __bf16* __
     }
 }
 
+// =============================================================================
+// K5 in f32 (the reference's own dtype: set_dtype(float32)): encoder flash attention on the f32 MFMA
+// (v_mfma_f32_32x32x2_f32, exact f32 products, f32 accumulation).  Same structure as the bf16 kernel:
+// S^T = K Q^T so that a lane owns one query column, P stays in the S accumulators and feeds O^T += V^T P^T.
+// The contraction index of an f32 MFMA step is 2 wide (lane half hh picks the element), so
+//   * Q is held as qf[s] = Q[q][2s + hh] and the K tile is stored with even and odd k separated
+//     ([key][parity][32]): a lane reads its 32 operands of a key row with 8 ds_read_b128;
+//   * the keys of P^T are contracted in the order the 32x32 accumulator layout holds them
+//     (step s of half hh = key 8(s>>2) + 4hh + (s&3)), which are 4 consecutive keys per ds_read_b128 of V^T.
+// V arrives [key][d]; the staging transposes it into the V^T tile.
+constexpr int FF_LD = 68;                  // floats per LDS row: 64 + 4 (conflict-free ds_read_b128 down a column)
+constexpr int FF_TILE = 64 * FF_LD;        // floats per operand tile
+
+__global__ __launch_bounds__(256, 2) void flash_enc_f32_kernel(const float* __restrict__ q, int64_t ldq,
+                                                               const float* __restrict__ k, int64_t ldk,
+                                                               const float* __restrict__ v, int64_t ldv,
+                                                               float* __restrict__ out, int64_t ldo, int T) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * FF_TILE];  // [buf][K tile | V^T tile], 69 632 B
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int nkt = (T + 63) / 64;
+
+    float qf[32];
+    {
+        const float* qp = q + ((int64_t)b * T + min(q0 + r, T - 1)) * ldq + h * 64 + hh;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) qf[s] = qp[2 * s];
+    }
+    // staging roles.  K: key row tid>>2, 16 consecutive k (segment tid&3).  V: key tid&63, 16 consecutive d (tid>>6).
+    const int krow = tid >> 2, kseg = tid & 3;
+    const int vkey = tid & 63, vseg = tid >> 6;
+    const float* kg = k + (int64_t)b * T * ldk + h * 64 + 16 * kseg;
+    const float* vg = v + (int64_t)b * T * ldv + h * 64 + 16 * vseg;
+    f32x4 rk[4], rv[4];
+    auto gload = [&](int kt) {
+        const float* kp = kg + (int64_t)min(kt * 64 + krow, T - 1) * ldk;
+        const float* vp = vg + (int64_t)min(kt * 64 + vkey, T - 1) * ldv;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            rk[c] = *reinterpret_cast<const f32x4*>(kp + 4 * c);
+            rv[c] = *reinterpret_cast<const f32x4*>(vp + 4 * c);
+        }
+    };
+    auto swrite = [&](int buf) {
+        float* kt = smem + buf * 2 * FF_TILE + krow * FF_LD + 8 * kseg;
+        // even k -> [0, 32), odd k -> [32, 64) of the key row
+        *reinterpret_cast<f32x4*>(kt) = f32x4{rk[0][0], rk[0][2], rk[1][0], rk[1][2]};
+        *reinterpret_cast<f32x4*>(kt + 4) = f32x4{rk[2][0], rk[2][2], rk[3][0], rk[3][2]};
+        *reinterpret_cast<f32x4*>(kt + 32) = f32x4{rk[0][1], rk[0][3], rk[1][1], rk[1][3]};
+        *reinterpret_cast<f32x4*>(kt + 36) = f32x4{rk[2][1], rk[2][3], rk[3][1], rk[3][3]};
+        float* vt = smem + buf * 2 * FF_TILE + FF_TILE + (16 * vseg) * FF_LD + vkey;  // V^T[d][key]
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vt[(4 * c + e) * FF_LD] = rv[c][e];
+    };
+
+    f32x16 O[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) O[0][i] = O[1][i] = 0.f;
+    float m = NEG_BIG, l = 0.f;  // m in the log2 domain
+
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) gload(kt + 1);
+        const float* kbuf = smem + (kt & 1) * 2 * FF_TILE;
+        const float* vbuf = kbuf + FF_TILE;
+        f32x16 S[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) S[u][i] = 0.f;
+            const float* kr = kbuf + (32 * u + r) * FF_LD + 32 * hh;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const f32x4 kf = *reinterpret_cast<const f32x4*>(kr + 4 * c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) S[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[4 * c + e], S[u], 0, 0, 0);
+            }
+        }
+        if (kt * 64 + 64 > T) {  // ragged last tile: a scalar branch (see the bf16 kernel)
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kt * 64 + 32 * u + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    if (key >= T) S[u][i] = NEG_BIG;
+                }
+        }
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, S[u][i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m, mx * LOG2E);
+        f32x2 psum2 = {0.f, 0.f};
+        const f32x2 l2e = {LOG2E, LOG2E}, mneg = {-m_new, -m_new};
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                const f32x2 x = __builtin_elementwise_fma(f32x2{S[u][i], S[u][i + 1]}, l2e, mneg);
+                const f32x2 pv = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+                S[u][i] = pv.x;
+                S[u][i + 1] = pv.y;
+                psum2 += pv;
+            }
+        if (__any(m_new > m)) {
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+            l *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                O[0][i] *= alpha;
+                O[1][i] *= alpha;
+            }
+            m = m_new;
+        }
+        l += psum2.x + psum2.y;
+        // O^T[d][q] += V^T[d][key] P^T[key][q]; step s of accumulator element s: key 32u + 8(s>>2) + 4hh + (s&3)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const float* vr = vbuf + (32 * dt + r) * FF_LD + 32 * u + 4 * hh;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 vf = *reinterpret_cast<const f32x4*>(vr + 8 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        O[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[e], S[u][4 * g + e], O[dt], 0, 0, 0);
+                }
+            }
+        if (kt + 1 < nkt) swrite((kt + 1) & 1);
+        __syncthreads();
+    }
+    l += __shfl_xor(l, 32, 64);
+    const int qrow = q0 + r;
+    if (qrow < T) {
+        const float inv = 1.f / l;
+        float* op = out + ((int64_t)b * T + qrow) * ldo + h * 64 + 4 * hh;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                *reinterpret_cast<f32x4*>(op + 32 * dt + 8 * g4) =
+                    f32x4{O[dt][4 * g4] * inv, O[dt][4 * g4 + 1] * inv, O[dt][4 * g4 + 2] * inv, O[dt][4 * g4 + 3] * inv};
+    }
+}
+
 }  // namespace
 
 extern "C" int wipa_attention(const wipa_attn_desc* d, wipa_stream_t stream) {
@@ -489,6 +644,19 @@ extern "C" int wipa_flash_attn_enc_bf16(const void* qk, int64_t ldqk, const void
     dim3 grid((T + 127) / 128, H, B);
     hipLaunchKernelGGL(flash_enc_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)qk, ldqk,
                        (const __bf16*)vt, ldvt, (__bf16*)out, ldo, H, T);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+extern "C" int wipa_flash_attn_enc_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                                       float* out, int64_t ldo, int B, int H, int T, wipa_stream_t stream) {
+    WIPA_REQUIRE(q && k && v && out, "wipa_flash_attn_enc_f32: null pointer");
+    WIPA_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0, "wipa_flash_attn_enc_f32: row strides must be multiples of 4");
+    WIPA_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 && ((uintptr_t)out % 16) == 0,
+                 "wipa_flash_attn_enc_f32: operands must be 16-byte aligned");
+    WIPA_REQUIRE(B > 0 && H > 0 && T > 0, "wipa_flash_attn_enc_f32: bad shape");
+    dim3 grid((T + 127) / 128, H, B);
+    hipLaunchKernelGGL(flash_enc_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, ldq, k, ldk, v, ldv, out, ldo, T);
     WIPA_LAUNCH_CHECK();
     return WIPA_OK;
 }

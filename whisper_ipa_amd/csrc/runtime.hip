@@ -146,15 +146,8 @@ extern "C" int wipa_encoder_forward(const wipa_model_cfg* cfg, const void* const
             RT_CALL(wipa_flash_attn_enc_bf16(qk, 2 * d, vb, T_ENC_PAD, ao, d, B, H, T, stream));
         } else {
             RT_CALL(gemm(ln, d, lw[4], d, vb, d, M, d, d, dt, dt, (const float*)lw[5], 0, nullptr, stream));
-            wipa_attn_desc a;
-            memset(&a, 0, sizeof(a));
-            a.q = qk; a.k = (const char*)qk + (size_t)d * e; a.v = vb; a.out = ao;
-            a.q_bs = (int64_t)T * 2 * d; a.q_rs = 2 * d; a.q_hs = 64;
-            a.k_bs = a.q_bs; a.k_rs = 2 * d; a.k_hs = 64;
-            a.v_bs = (int64_t)T * d; a.v_rs = d; a.v_hs = 64;
-            a.o_bs = (int64_t)T * d; a.o_rs = d; a.o_hs = 64;
-            a.B = B; a.H = H; a.Tq = T; a.Tk = T; a.causal = 0; a.dtype = dt;
-            RT_CALL(wipa_attention(&a, stream));
+            RT_CALL(wipa_flash_attn_enc_f32((const float*)qk, 2 * d, (const float*)qk + d, 2 * d, (const float*)vb, d, (float*)ao, d,
+                                            B, H, T, stream));
         }
         RT_CALL(gemm(ao, d, lw[6], d, x, d, M, d, d, dt, WIPA_F32, (const float*)lw[7], 0, x, stream));
         RT_CALL(wipa_layernorm(x, WIPA_F32, d, ln, dt, d, (const float*)lw[8], (const float*)lw[9], M, d, 1e-5f, stream));

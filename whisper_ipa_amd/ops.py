@@ -122,6 +122,19 @@ def flash_attn_enc(qk: torch.Tensor, vt: torch.Tensor, B: int, H: int, T: int) -
     return out
 
 
+def flash_attn_enc_f32(qk: torch.Tensor, v: torch.Tensor, B: int, H: int, T: int) -> torch.Tensor:
+    """qk [B*T, 2D] f32 (q|k, pre-scaled), v [B*T, D] f32 -> [B*T, D] f32 on the f32 MFMA."""
+    L = _lib.lib()
+    D = H * 64
+    assert qk.dtype == torch.float32 and v.dtype == torch.float32
+    with on_stream() as s:
+        out = torch.empty(B * T, D, dtype=torch.float32, device=qk.device)
+        k = qk[:, D:]
+        _lib.check(L.wipa_flash_attn_enc_f32(ptr(qk), qk.stride(0), ptr(k), qk.stride(0), ptr(v), v.stride(0), ptr(out), D,
+                                             B, H, T, sptr(s)), "wipa_flash_attn_enc_f32")
+    return out
+
+
 def decode_cross_attn(q: torch.Tensor, kv: torch.Tensor) -> torch.Tensor:
     """q [B, H*64], kv [B, 2H, Tk, 64] -> [B, H*64]."""
     L = _lib.lib()
