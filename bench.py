@@ -376,7 +376,7 @@ def main():
         out["roofline"] = roofline_cross_attn(model, audio_chunks[0].shape[0])
         log("roofline microbench done")
         if world == 1 and not args.no_cpu_baseline and args.model == "small":
-            out["cpu_baseline"] = cpu_baseline(1)
+            out["cpu_baseline"] = cpu_baseline(8)  # ~20 s of host work
             log("cpu baseline done")
         print(json.dumps(out), flush=True)
     if dist is not None:
