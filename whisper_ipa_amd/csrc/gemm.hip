@@ -282,10 +282,10 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x4
             OutT* cp = reinterpret_cast<OutT*>(p.C) + off;
             if (full) {
                 if constexpr (sizeof(OutT) == 4) {
-                    *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+                    __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(cp));
                 } else {
-                    *reinterpret_cast<bf16x8*>(cp) = bf16x8{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3],
-                                                            (__bf16)v[4], (__bf16)v[5], (__bf16)v[6], (__bf16)v[7]};
+                    __builtin_nontemporal_store(bf16x8{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3],
+                                                            (__bf16)v[4], (__bf16)v[5], (__bf16)v[6], (__bf16)v[7]}, reinterpret_cast<bf16x8*>(cp));
                 }
             } else {
 #pragma unroll
