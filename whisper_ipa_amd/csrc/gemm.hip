@@ -219,7 +219,10 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x4
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
             const EpiRow R = epi_row(p, m_base + 16 * j + pass * RPP + rrow, coff_dev);
-            if (R.store) dst[pass] = *reinterpret_cast<const Vec16<OutT>*>(reinterpret_cast<const OutT*>(p.residual) + R.roff + coff);
+            if (R.store) {
+                typedef decltype(dst[pass].v) VT;
+                dst[pass].v = __builtin_nontemporal_load(reinterpret_cast<const VT*>(reinterpret_cast<const OutT*>(p.residual) + R.roff + coff));
+            }
         }
     };
     if (res_vec) fetch_residual(0, rnext);
