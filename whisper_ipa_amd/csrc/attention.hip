@@ -314,33 +314,31 @@ __global__ __launch_bounds__(256, 2) void flash_enc_bf16_kernel(const __bf16* __
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
     }
-    // staging roles: rows srow, srow+32 ; 16-byte chunk schunk
-    const int srow = tid >> 3, schunk = tid & 7;
-    const __bf16* kg = qk + (int64_t)b * T * ldqk + D + h * 64 + schunk * 8;      // + key*ldqk
-    const __bf16* vg = vt + ((int64_t)b * D + h * 64) * ldvt + schunk * 8;        // + d*ldvt + k0
-    int lds_off[2];
+    // Staging by LDS-DMA (buffer_load_dwordx4 ... lds): no VGPR round trip, no ds_write.  A 1-KiB piece is 8 tile rows of
+    // 128 B; lane l lands at byte 16 l of the piece, i.e. (row l>>3, physical chunk l&7), and fetches the SOURCE chunk
+    // (l&7) ^ ((row>>1)&7) -- the same XOR the fragment reads apply.  Wave w moves pieces 2w, 2w+1 of the K tile and of
+    // the V^T tile.  Keys beyond T are out of the K resource's range and read as zero; V^T is zero there already.
+    typedef __attribute__((address_space(3))) void* lds_t;
+    const __bf16* kbase = qk + (int64_t)b * T * ldqk + D + h * 64;
+    const __bf16* vbase = vt + ((int64_t)b * D + h * 64) * ldvt;
+    const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (int)(((int64_t)(T - 1) * ldqk + 64) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (int)(((int64_t)63 * ldvt + ldvt) * 2), 0x00020000);
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    int offK[2], offV[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int row = srow + 32 * i;
-        lds_off[i] = row * FA_ROWB + ((schunk ^ ((row >> 1) & 7)) << 4);
+        const int row = 8 * (2 * wv + i) + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        offK[i] = row * (int)ldqk * 2 + c * 16;   // + k0 * ldqk * 2 (scalar)
+        offV[i] = row * (int)ldvt * 2 + c * 16;   // + k0 * 2 (scalar)
     }
-    f32x4 rk[2], rv[2];
-    auto gload = [&](int kt) {
+    auto stage = [&](int kt, int buf) {
+        char* base = smem + buf * 2 * FA_TILE + (2 * wv) * 1024;
         const int k0 = kt * 64;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int row = srow + 32 * i;
-            const int key = min(k0 + row, T - 1);
-            rk[i] = *reinterpret_cast<const f32x4*>(kg + (int64_t)key * ldqk);
-            rv[i] = *reinterpret_cast<const f32x4*>(vg + (int64_t)row * ldvt + k0);
-        }
-    };
-    auto swrite = [&](int buf) {
-        char* base = smem + buf * 2 * FA_TILE;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<f32x4*>(base + lds_off[i]) = rk[i];
-            *reinterpret_cast<f32x4*>(base + FA_TILE + lds_off[i]) = rv[i];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, (lds_t)(base + i * 1024), 16, offK[i], k0 * (int)ldqk * 2, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, (lds_t)(base + FA_TILE + i * 1024), 16, offV[i], k0 * 2, 0, 0);
         }
     };
 
@@ -350,11 +348,11 @@ __global__ __launch_bounds__(256, 2) void flash_enc_bf16_kernel(const __bf16* __
     float m = NEG_BIG, l = 0.f;  // m in the log2 domain (scores * log2e)
     const int rsw = (r >> 1) & 7;  // swizzle term of rows 32x + r
 
-    gload(0);
-    swrite(0);
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) gload(kt + 1);
+        if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
         const char* kbuf = smem + (kt & 1) * 2 * FA_TILE;
         const char* vbuf = kbuf + FA_TILE;
         f32x16 S[2];
@@ -433,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void flash_enc_bf16_kernel(const __bf16* __
                     O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, O[dt], 0, 0, 0);
                 }
             }
-        if (kt + 1 < nkt) swrite((kt + 1) & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
     l += __shfl_xor(l, 32, 64);
