@@ -242,6 +242,80 @@ __global__ __launch_bounds__(GS_THREADS) void greedy_step_kernel(const float* __
     }
 }
 
+// Register-resident variant for V <= 65536 (every Whisper vocabulary): the filtered row is fetched ONCE with 16-byte loads
+// that are all in flight together (13 per thread for V = 51 865), the arg-max and the sum of exponentials both run out of
+// registers.  The two-pass scalar kernel above took 30 us per step on 64 rows (latency-bound: 2 x 51 dependent loads).
+constexpr int GS_MAXQ = 16;
+__global__ __launch_bounds__(GS_THREADS) void greedy_step_reg_kernel(const float* __restrict__ logits, int64_t ldl, int V,
+                                                                     const float* __restrict__ mask_first,
+                                                                     const float* __restrict__ mask_always,
+                                                                     int32_t* __restrict__ tokens, int64_t ld_tok,
+                                                                     const int32_t* __restrict__ pos_dev, int n_init, int eot,
+                                                                     float* __restrict__ sum_logprobs,
+                                                                     int32_t* __restrict__ not_done) {
+    __shared__ float s_v[GS_THREADS / 64];
+    __shared__ int s_i[GS_THREADS / 64];
+    __shared__ float s_sum[GS_THREADS / 64];
+    const int b = blockIdx.x;
+    const int p = *pos_dev;
+    if (p + 1 < n_init) return;  // prompt token already in place
+    const float* mask = (p + 1 == n_init) ? mask_first : mask_always;
+    const float* row = logits + (int64_t)b * ldl;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nq = V >> 2;
+    f32x4 vals[GS_MAXQ];
+#pragma unroll
+    for (int j = 0; j < GS_MAXQ; ++j) {
+        const int qi = tid + j * GS_THREADS;
+        if (qi < nq) {
+            vals[j] = *reinterpret_cast<const f32x4*>(row + 4 * qi) + *reinterpret_cast<const f32x4*>(mask + 4 * qi);
+        } else {
+            vals[j] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
+    }
+    const int ti = 4 * nq + tid;  // the (V mod 4) trailing elements
+    const bool has_tail = tid < 4 && ti < V;
+    const float tailv = has_tail ? row[ti] + mask[ti] : -INFINITY;
+    MaxIdx m{tailv, has_tail ? ti : 0x7fffffff};
+#pragma unroll
+    for (int j = 0; j < GS_MAXQ; ++j) {
+        const int qi = tid + j * GS_THREADS;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m = better(m, MaxIdx{vals[j][e], qi < nq ? 4 * qi + e : 0x7fffffff});
+    }
+    m = wave_argmax(m);
+    if (lane == 0) {
+        s_v[wave] = m.v;
+        s_i[wave] = m.i;
+    }
+    __syncthreads();
+    MaxIdx bm{s_v[0], s_i[0]};
+#pragma unroll
+    for (int w = 1; w < GS_THREADS / 64; ++w) bm = better(bm, MaxIdx{s_v[w], s_i[w]});
+    float se = __expf(tailv - bm.v);
+#pragma unroll
+    for (int j = 0; j < GS_MAXQ; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) se += __expf(vals[j][e] - bm.v);
+    se = wave_reduce_sum(se);
+    if (lane == 0) s_sum[wave] = se;
+    __syncthreads();
+    if (tid == 0) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < GS_THREADS / 64; ++w) tot += s_sum[w];
+        const int prev = tokens[(int64_t)b * ld_tok + p];
+        int next = bm.i;
+        if (prev == eot) {
+            next = eot;
+        } else {
+            sum_logprobs[b] += -logf(tot);
+        }
+        tokens[(int64_t)b * ld_tok + p + 1] = next;
+        if (next != eot) atomicAdd(not_done, 1);
+    }
+}
+
 __global__ void add_i32_kernel(int32_t* p, int32_t v) { *p += v; }
 
 // ------------------------------------------------------------------ masked cross entropy
@@ -407,8 +481,14 @@ extern "C" int wipa_greedy_step(const float* logits, int64_t ldl, int B, int V, 
                                 int n_init, int eot, float* sum_logprobs, int32_t* not_done, wipa_stream_t stream) {
     WIPA_REQUIRE(logits && mask_first && mask_always && tokens && pos_dev && sum_logprobs && not_done,
                  "wipa_greedy_step: null pointer");
-    hipLaunchKernelGGL(greedy_step_kernel, dim3(B), dim3(GS_THREADS), 0, (hipStream_t)stream, logits, ldl, V, mask_first,
-                       mask_always, tokens, ld_tok, pos_dev, n_init, eot, sum_logprobs, not_done);
+    const bool reg_ok = V <= 4 * GS_MAXQ * GS_THREADS && ldl % 4 == 0 && ((uintptr_t)logits % 16) == 0 &&
+                        ((uintptr_t)mask_first % 16) == 0 && ((uintptr_t)mask_always % 16) == 0;
+    if (reg_ok)
+        hipLaunchKernelGGL(greedy_step_reg_kernel, dim3(B), dim3(GS_THREADS), 0, (hipStream_t)stream, logits, ldl, V, mask_first,
+                           mask_always, tokens, ld_tok, pos_dev, n_init, eot, sum_logprobs, not_done);
+    else
+        hipLaunchKernelGGL(greedy_step_kernel, dim3(B), dim3(GS_THREADS), 0, (hipStream_t)stream, logits, ldl, V, mask_first,
+                           mask_always, tokens, ld_tok, pos_dev, n_init, eot, sum_logprobs, not_done);
     WIPA_LAUNCH_CHECK();
     return WIPA_OK;
 }
