@@ -187,7 +187,7 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, const f32x4& a, c
 // 16 output bytes of one row and 8 (bf16) / 16 (f32) consecutive lanes cover a whole 128/256-byte row
 // segment -> half / equal the store instructions, all full-line, and bias / residual / positional
 // operands are read with the same coalesced shape.
-template <typename OutT, int MTILES>
+template <typename OutT, int MTILES, int J0 = 0, int NJ = MTILES>  // row slices J0 .. J0+NJ-1 of the MTILES the wave holds
 __device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x4 (&acc)[4][MTILES], char* scratch, int m_base,
                                                 int n_base, int64_t coff_dev, int lane) {
     constexpr int EPC = 16 / (int)sizeof(OutT);  // output elements per lane per store (8 bf16 / 4 f32)
@@ -213,7 +213,8 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x4
     // The residual of slice j+1 is fetched while slice j goes through the LDS transpose: without this each pass issued its
     // own dependent 16-byte load and the f32-residual epilogue ran at ~1.7x its HBM time.
     constexpr int NPASS = 16 / RPP;
-    const bool res_vec = p.residual != nullptr && col_ok && nvalid == EPC;
+    constexpr bool PREFETCH = MTILES <= 8;  // with 12 row slices (192 accumulators) the prefetch registers would spill
+    const bool res_vec = PREFETCH && p.residual != nullptr && col_ok && nvalid == EPC;
     Vec16<OutT> rnext[NPASS];
     auto fetch_residual = [&](int j, Vec16<OutT> (&dst)[NPASS]) {
 #pragma unroll
@@ -225,14 +226,14 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x4
             }
         }
     };
-    if (res_vec) fetch_residual(0, rnext);
+    if (res_vec) fetch_residual(J0, rnext);
 #pragma unroll
-    for (int j = 0; j < MTILES; ++j) {
+    for (int j = J0; j < J0 + NJ; ++j) {
         Vec16<OutT> rcur[NPASS];
         if (res_vec) {
 #pragma unroll
             for (int pass = 0; pass < NPASS; ++pass) rcur[pass] = rnext[pass];
-            if (j + 1 < MTILES) fetch_residual(j + 1, rnext);
+            if (j + 1 < J0 + NJ) fetch_residual(j + 1, rnext);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -270,8 +271,16 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x4
             if (p.residual) {
                 const OutT* rp = reinterpret_cast<const OutT*>(p.residual) + off;
                 if (full) {
+                    if constexpr (PREFETCH) {
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e) v[e] += rcur[pass].get(e);
+                        for (int e = 0; e < EPC; ++e) v[e] += rcur[pass].get(e);
+                    } else {
+                        typedef decltype(rcur[pass].v) VT;
+                        Vec16<OutT> rr;
+                        rr.v = __builtin_nontemporal_load(reinterpret_cast<const VT*>(rp));
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) v[e] += rr.get(e);
+                    }
                 } else {
 #pragma unroll
                     for (int e = 0; e < EPC; ++e)
@@ -677,6 +686,122 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// 384 (M) x 256 (N) tile (WIPA_GEMM_TILE=384 forces it, =256 forbids it), 8 waves (2 x 4), 192 x 64 per wave = 4 x 12 MFMA tiles
+// (192 accumulator registers).  Stages (256 + 384) x 128 B = 80 KiB per K-step: 1/153.6 byte per FLOP instead of 1/128, and
+// N = 768 gives 750 tiles = 2.93 rounds instead of 4.39.  LDS 2 x 80 KiB = all of it.
+constexpr int XBM = 384;
+constexpr int XW_TILE = LBN * ROWB;        // 32 KiB
+constexpr int XA_TILE = XBM * ROWB;        // 48 KiB
+constexpr int XSTAGE = XW_TILE + XA_TILE;  // 80 KiB
+constexpr int XSMEM = 2 * XSTAGE;          // 160 KiB
+
+template <typename T, typename OutT>
+__global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][W tile 256 rows | A tile 384 rows]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nblocks = p.tiles_m * p.tiles_n;
+    int id;
+    {
+        const int bid = blockIdx.x;
+        const int q = nblocks >> 3, r = nblocks & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int group_size = GROUP_M * p.tiles_n;
+    const int group = id / group_size;
+    const int first_m = group * GROUP_M;
+    const int gm = min(p.tiles_m - first_m, GROUP_M);
+    const int in_group = id - group * group_size;
+    const int tile_m = first_m + in_group % gm;
+    const int tile_n = in_group / gm;
+    const int m0 = tile_m * XBM, n0 = tile_n * LBN;
+
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (int64_t)n0 * p.ldw_b), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)m0 * p.lda_b), 0, 0x7fffffff, 0x00020000);
+    int oW[4], oA[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int row = 64 * i + 8 * wave + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        if (i < 4) oW[i] = (min(n0 + row, p.N - 1) - n0) * (int)p.ldw_b + c * 16;
+        oA[i] = (min(m0 + row, p.M - 1) - m0) * (int)p.lda_b + c * 16;
+    }
+    auto stage = [&](int kt, int buf) {
+        const int kb = kt * ROWB;
+        char* base = smem + buf * XSTAGE + wave * (8 * ROWB);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)(base + i * 64 * ROWB), 16, oW[i], kb, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(base + XW_TILE + i * 64 * ROWB), 16, oA[i], kb, 0, 0);
+    };
+    f32x4 acc[4][12];  // [n tile i][m tile j]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 12; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15;
+    const int fsw = (lane >> 1) & 7;
+    const int fq = lane >> 4;
+    const int nk = p.K * (int)sizeof(T) / ROWB;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        const char* wb = smem + (kt & 1) * XSTAGE + (wn * 64 + frow) * ROWB;
+        const char* ab = smem + (kt & 1) * XSTAGE + XW_TILE + (wm * 192 + frow) * ROWB;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int coff = ((fq + 4 * kk) ^ fsw) << 4;
+            typename Mma<T>::Frag fw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fw[i] = *reinterpret_cast<const typename Mma<T>::Frag*>(wb + i * 16 * ROWB + coff);
+#pragma unroll
+            for (int jg = 0; jg < 3; ++jg) {  // the A fragments four at a time: 192 accumulators leave no room for twelve
+                typename Mma<T>::Frag fx[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fx[j] = *reinterpret_cast<const typename Mma<T>::Frag*>(ab + (4 * jg + j) * 16 * ROWB + coff);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) Mma<T>::run(fw[i], fx[j], acc[i][4 * jg + j]);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    const bool vec = p.vec_ok != 0;
+    int64_t coff_dev = p.c_offset;
+    if (p.c_offset_dev) coff_dev += *p.c_offset_dev;
+    if (p.stage_ok) {
+        epilogue_staged<OutT, 12>(p, acc, smem + wave * 4096, m0 + wm * 192, n0 + wn * 64, coff_dev, lane);
+        return;
+    }
+    EpiCol cols[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cols[i] = epi_col(p, n0 + wn * 64 + 16 * i + 4 * fq);
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        const EpiRow row = epi_row(p, m0 + wm * 192 + 16 * j + frow, coff_dev);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) epilogue4<OutT>(p, acc[i][j], row, cols[i], vec);
+    }
+}
+
+template <typename T, typename OutT>
+int launch384(GemmParams p, hipStream_t s) {
+    p.tiles_m = (p.M + XBM - 1) / XBM;
+    p.tiles_n = (p.N + LBN - 1) / LBN;
+    hipLaunchKernelGGL((gemm_nt384_kernel<T, OutT>), dim3(p.tiles_m * p.tiles_n), dim3(512), XSMEM, s, p);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
 template <typename T, typename OutT>
 int launch256(GemmParams p, hipStream_t s) {
     p.tiles_m = (p.M + LBM - 1) / LBM;
@@ -707,6 +832,14 @@ int init_attrs() {
                               reinterpret_cast<const void*>(&gemm_nt256_kernel<float, float>)};
         for (const void* f : big) {
             const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LSMEM);
+            if (e != hipSuccess) err = e;
+        }
+        const void* wide[4] = {reinterpret_cast<const void*>(&gemm_nt384_kernel<__bf16, __bf16>),
+                               reinterpret_cast<const void*>(&gemm_nt384_kernel<__bf16, float>),
+                               reinterpret_cast<const void*>(&gemm_nt384_kernel<float, __bf16>),
+                               reinterpret_cast<const void*>(&gemm_nt384_kernel<float, float>)};
+        for (const void* f : wide) {
+            const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, XSMEM);
             if (e != hipSuccess) err = e;
         }
     });
@@ -798,6 +931,22 @@ extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
     const bool big = pitch_ok && p.k_slices == 1 && (  // split-K beyond the skinny rows lives in the 128x128 kernel
                      force_tile >= 256 ||  // WIPA_GEMM_TILE=256: the 256x256 kernel for every shape
                                   (force_tile != 128 && d->M >= 512 && d->N >= 256 && (int64_t)d->M * d->N >= (1 << 20)));
+    // 384 x 256 tile (fewer staged bytes per FLOP, 2.93 instead of 4.39 rounds at N = 768) where it measured faster:
+    // f32 outputs (no spills in that instantiation), long K, or a 256-tile grid that wastes > 10 % of its last round.
+    bool use384 = force_tile == 384;
+    if (big && force_tile == 0) {
+        const int64_t t256 = (int64_t)((d->M + LBM - 1) / LBM) * ((d->N + LBN - 1) / LBN);
+        const int64_t t384 = (int64_t)((d->M + XBM - 1) / XBM) * ((d->N + LBN - 1) / LBN);
+        const double e256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);
+        const double e384 = (double)t384 / (double)(((t384 + 255) / 256) * 256);
+        use384 = d->M >= 2 * XBM && e384 >= 0.9 * e256 &&
+                 (d->out_dtype == WIPA_F32 || d->K * esz >= 4096 || (e256 < 0.9 && e384 >= 0.95));
+    }
+    if (big && use384) {
+        if (d->in_dtype == WIPA_BF16)
+            return d->out_dtype == WIPA_BF16 ? launch384<__bf16, __bf16>(p, s) : launch384<__bf16, float>(p, s);
+        return d->out_dtype == WIPA_BF16 ? launch384<float, __bf16>(p, s) : launch384<float, float>(p, s);
+    }
     if (big) {
         if (d->in_dtype == WIPA_BF16)
             return d->out_dtype == WIPA_BF16 ? launch256<__bf16, __bf16>(p, s) : launch256<__bf16, float>(p, s);
