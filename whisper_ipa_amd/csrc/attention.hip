@@ -295,15 +295,17 @@ constexpr int FA_ROWB = 128;                // bytes per LDS row (64 bf16)
 constexpr int FA_TILE = 64 * FA_ROWB;       // 8 KiB
 constexpr float LOG2E = 1.4426950408889634f;
 
-__global__ __launch_bounds__(256, 2) void flash_enc_bf16_kernel(const __bf16* __restrict__ qk, int64_t ldqk,
-                                                                const __bf16* __restrict__ vt, int64_t ldvt,
-                                                                __bf16* __restrict__ out, int64_t ldo, int H, int T) {
+// blockDim.x / 64 = 4 or 8 waves: 128 or 256 queries share every K / V^T tile (8 waves halve the L2->LDS fill per FLOP).
+__global__ __launch_bounds__(512) void flash_enc_bf16_kernel(const __bf16* __restrict__ qk, int64_t ldqk,
+                                                             const __bf16* __restrict__ vt, int64_t ldvt,
+                                                             __bf16* __restrict__ out, int64_t ldo, int H, int T) {
     __shared__ __attribute__((aligned(16))) char smem[4 * FA_TILE];  // [buf][K tile | V^T tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int h = blockIdx.y, b = blockIdx.z;
     const int D = H * 64;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int nw = blockDim.x >> 6;
+    const int q0 = blockIdx.x * (nw * 32) + wave * 32;
     const int nkt = (T + 63) / 64;
 
     // Q fragments: B operand of S^T = K * Q^T.  lane (r,hh) holds Q[q0+r][16s + 8hh + 0..7]
@@ -324,21 +326,24 @@ __global__ __launch_bounds__(256, 2) void flash_enc_bf16_kernel(const __bf16* __
     const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (int)(((int64_t)(T - 1) * ldqk + 64) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (int)(((int64_t)63 * ldvt + ldvt) * 2), 0x00020000);
     const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int ppw = 8 / nw;  // 1-KiB pieces of each tile per wave: 2 (four waves) or 1 (eight)
     int offK[2], offV[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int row = 8 * (2 * wv + i) + (lane >> 3);
+        const int row = 8 * (ppw * wv + i) + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);
         offK[i] = row * (int)ldqk * 2 + c * 16;   // + k0 * ldqk * 2 (scalar)
         offV[i] = row * (int)ldvt * 2 + c * 16;   // + k0 * 2 (scalar)
     }
     auto stage = [&](int kt, int buf) {
-        char* base = smem + buf * 2 * FA_TILE + (2 * wv) * 1024;
+        char* base = smem + buf * 2 * FA_TILE + (ppw * wv) * 1024;
         const int k0 = kt * 64;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, (lds_t)(base + i * 1024), 16, offK[i], k0 * (int)ldqk * 2, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, (lds_t)(base + FA_TILE + i * 1024), 16, offV[i], k0 * 2, 0, 0);
+            if (i < ppw) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, (lds_t)(base + i * 1024), 16, offK[i], k0 * (int)ldqk * 2, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, (lds_t)(base + FA_TILE + i * 1024), 16, offV[i], k0 * 2, 0, 0);
+            }
         }
     };
 
@@ -645,8 +650,10 @@ extern "C" int wipa_flash_attn_enc_bf16(const void* qk, int64_t ldqk, const void
     WIPA_REQUIRE(ldqk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "wipa_flash_attn_enc_bf16: ld alignment");
     WIPA_REQUIRE(ldvt >= ((T + 63) / 64) * 64, "wipa_flash_attn_enc_bf16: ldvt=%lld must cover ceil64(T)", (long long)ldvt);
     WIPA_REQUIRE(B > 0 && H > 0 && T > 0, "wipa_flash_attn_enc_bf16: bad shape");
-    dim3 grid((T + 127) / 128, H, B);
-    hipLaunchKernelGGL(flash_enc_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)qk, ldqk,
+    static const int q128 = [] { const char* e = getenv("WIPA_FLASH_Q128"); return e ? atoi(e) : 0; }();
+    const int nw = (T > 256 && !q128) ? 8 : 4;
+    dim3 grid((T + nw * 32 - 1) / (nw * 32), H, B);
+    hipLaunchKernelGGL(flash_enc_bf16_kernel, grid, dim3(nw * 64), 0, (hipStream_t)stream, (const __bf16*)qk, ldqk,
                        (const __bf16*)vt, ldvt, (__bf16*)out, ldo, H, T);
     WIPA_LAUNCH_CHECK();
     return WIPA_OK;
