@@ -182,6 +182,23 @@ def pass_launch(model, audio_chunks, setup, stream_base: int):
     return handles
 
 
+def group_launch(model, audio, setup, stream_id: int, n_batches: int):
+    """enqueue n_batches passes as ONE decode group: log-mel + encoder per 64-clip batch, then one greedy loop over all
+    n_batches * B clips (the decode-step projections stream the decoder weights once for the whole group)."""
+    from whisper_ipa_amd import audio as A
+    from whisper_ipa_amd.decoding import greedy_launch
+    from whisper_ipa_amd.runtime import use_stream
+
+    init, always, first, eot = setup
+    with use_stream(stream_id):
+        feats = []
+        for _ in range(n_batches):
+            mel = A.log_mel_padded(audio, model.dims.n_mels, model.dtype)
+            feats.append(model.encode_padded(mel, audio.shape[0]))
+        allf = feats[0] if n_batches == 1 else torch.cat(feats, dim=0)
+        return [greedy_launch(model, allf, init, always, first, eot, max_new_tokens=NEW_TOKENS)]
+
+
 def pass_collect(handles):
     from whisper_ipa_amd.decoding import greedy_collect
 
@@ -278,6 +295,8 @@ def main():
     ap.add_argument("--streams", type=int, default=N_STREAMS, help="clip sub-batches run on this many HIP streams")
     ap.add_argument("--pipeline", type=int, default=N_PIPELINE, help="consecutive passes kept in flight on separate HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--decode-group", type=int, default=1,
+                    help="EXPERIMENT: decode this many consecutive 64-clip batches together (encoder still per batch)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"],
                     help="sizing runs only: the benchmark metric is quoted in bf16 (f32 is what the reference's scripts set)")
     ap.add_argument("--model", default="small", choices=["tiny", "base", "small", "medium", "large-v3"],
@@ -321,7 +340,10 @@ def main():
 
     for i in range(args.warmup):
         for pset in range(args.pipeline):  # warm every stream set (workspaces, KV caches, captured graphs)
-            pass_collect(pass_launch(model, audio_chunks, setup, pset * args.streams))
+            if args.decode_group > 1:
+                pass_collect(group_launch(model, audio_chunks[0], setup, pset, args.decode_group))
+            else:
+                pass_collect(pass_launch(model, audio_chunks, setup, pset * args.streams))
         torch.cuda.synchronize()
         log(f"warmup pass {i} done")
     torch.cuda.synchronize()
@@ -333,10 +355,20 @@ def main():
     # again, so the encoder of pass i+1 can overlap the decode loop of pass i (each pass still does all its work
     # inside the timed region; every pass owns separate workspaces / KV caches)
     inflight = []
-    for i in range(args.steps):
-        if len(inflight) == args.pipeline:
-            tokens = pass_collect(inflight.pop(0))
-        inflight.append(pass_launch(model, audio_chunks, setup, (i % args.pipeline) * args.streams))
+    if args.decode_group > 1:
+        i, gi = 0, 0
+        while i < args.steps:
+            g = min(args.decode_group, args.steps - i)
+            if len(inflight) == args.pipeline:
+                tokens = pass_collect(inflight.pop(0))
+            inflight.append(group_launch(model, audio_chunks[0], setup, gi % args.pipeline, g))
+            i += g
+            gi += 1
+    else:
+        for i in range(args.steps):
+            if len(inflight) == args.pipeline:
+                tokens = pass_collect(inflight.pop(0))
+            inflight.append(pass_launch(model, audio_chunks, setup, (i % args.pipeline) * args.streams))
     while inflight:
         tokens = pass_collect(inflight.pop(0))
     torch.cuda.synchronize()
@@ -367,7 +399,7 @@ def main():
             "data": f"synthetic (seeded noise clips, random-init whisper-{args.model} weights)",
             "config": {"workload": f"whisper-{args.model} {args.dtype} batched inference, batch={B}x30s synthetic clips per GPU, "
                                    f"log-mel + encoder + cross-KV + {NEW_TOKENS} greedy KV-cached decode steps",
-                       "clips_per_gpu": B, "new_tokens": NEW_TOKENS, "streams_per_gpu": args.streams, "passes_in_flight": args.pipeline,
+                       "clips_per_gpu": B, "new_tokens": NEW_TOKENS, "streams_per_gpu": args.streams, "passes_in_flight": args.pipeline, "decode_group": args.decode_group,
                        "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "parallelism": f"dp{world} (clip sharding, no collective)"},
             "tokens_checksum": int(tokens.sum() % 1000003),
