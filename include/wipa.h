@@ -90,8 +90,11 @@ typedef struct wipa_gemm_desc {
     int32_t k_slices; /* 0/1: whole K.  >1: K is cut into k_slices contiguous slices
                        * computed by different workgroups; slice z writes its PARTIAL sums (bias in
                        * slice 0 only, no act/pos/residual) to C + z*slab_stride -- to be summed in a
-                       * fixed order by wipa_add_slabs_layernorm or wipa_sum_slabs (deterministic split-K).  M <= 256
+                       * fixed order by wipa_add_slabs_layernorm or wipa_sum_slabs (deterministic split-K).  M <= 1024
                        * runs in the weight-streaming kernel, larger M in the 128x128 tile kernel. */
+    int32_t stream_weights; /* 1: the rows are decode rows (one or a few per clip) and W is a weight matrix: use the
+                             * weight-streaming kernel up to M = 1024 instead of 256, so that a prompt prefill of
+                             * 4 rows per clip rounds exactly like the single-row steps (batch invariance) */
 } wipa_gemm_desc;
 int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t s);
 
@@ -160,6 +163,9 @@ int wipa_decode_attn(const wipa_attn_desc* d, wipa_stream_t s);
  * out [B, H*64] T. */
 int wipa_decode_cross_attn(const void* q, const void* kv, void* out, int B, int H, int Tk, int dtype,
                            wipa_stream_t s);
+/* n_q (1..4) query rows per clip against the same cache: q / out [B*n_q, H*64] rows (b, t); every K/V row is read once. */
+int wipa_decode_cross_attn_multi(const void* q, const void* kv, void* out, int B, int H, int Tk, int n_q, int dtype,
+                                 wipa_stream_t s);
 
 /* ------------------------------------------------------------------ K13 greedy step
  * GreedyDecoder.update + SuppressBlank + SuppressTokens of mlx_whisper.decoding
@@ -237,6 +243,12 @@ int wipa_decoder_begin(const wipa_model_cfg* cfg, void* state, int B, const int3
 int wipa_decoder_run(const wipa_model_cfg* cfg, const void* const* weights, void* state, int B, int n_init, int eot,
                      const float* mask_first, const float* mask_always, int n_steps, int use_graph,
                      wipa_stream_t s);
+/* The first n_init steps (the prompt positions 0..n_init-1 and the first generated token) as ONE batched pass: same
+ * resulting state as wipa_decoder_run(..., n_steps = n_init, ...) right after wipa_decoder_begin, but the cached cross K/V
+ * are streamed once for all prompt positions and the small per-step kernels run once (mlx_whisper also feeds the whole
+ * prompt through the decoder in one forward).  Continue with wipa_decoder_run for the remaining steps. */
+int wipa_decoder_prefill(const wipa_model_cfg* cfg, const void* const* w, void* state, int B, int n_init, int eot,
+                         const float* mask_first, const float* mask_always, wipa_stream_t s);
 /* drop the cached step graphs that reference this state blob (call before freeing it). */
 int wipa_decoder_release(void* state);
 

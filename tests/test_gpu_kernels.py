@@ -164,6 +164,29 @@ def test_flash_attention_spiked_scores(ops):
     assert _rel(out, ref) < 1.5e-2
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n_q", [2, 3, 4])
+def test_decode_cross_attention_multi_query(dtype, n_q):
+    """prompt prefill: n_q query rows per clip against one pass over the cached cross K/V == n_q single-query launches."""
+    import ctypes as C
+
+    from whisper_ipa_amd import _lib, ops as O
+    from whisper_ipa_amd.runtime import dt_code, on_stream, ptr, sptr
+
+    g = torch.Generator().manual_seed(n_q)
+    B, H, Tk = 3, 2, 1500
+    q = (torch.randn(B * n_q, H * 64, generator=g) * 0.5).to(dtype).cuda()
+    kv = torch.randn(B, 2 * H, Tk, 64, generator=g).to(dtype).cuda()
+    out = torch.empty_like(q)
+    with on_stream() as s:
+        _lib.check(_lib.lib().wipa_decode_cross_attn_multi(ptr(q), ptr(kv), ptr(out), B, H, Tk, n_q, dt_code(dtype), sptr(s)))
+    torch.cuda.synchronize()
+    for t in range(n_q):
+        one = O.decode_cross_attn(q.view(B, n_q, -1)[:, t].contiguous(), kv)
+        torch.cuda.synchronize()
+        assert torch.equal(out.view(B, n_q, -1)[:, t], one), t
+
+
 @pytest.mark.parametrize("T", [1500, 200, 64, 37])
 def test_flash_attention_encoder_f32(ops, T):
     """f32 MFMA flash attention (the reference's own dtype) against softmax(QK^T)V in float64; ragged last key tile,

@@ -179,6 +179,33 @@ def test_teacher_forced_rows_longer_than_the_text_context_are_refused(micro):
         m.logits(too_long, xa[:1].cuda())
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_prompt_prefill_equals_stepwise_prompt(micro, monkeypatch, dtype):
+    """wipa_decoder_prefill (the prompt in one batched pass, cross K/V streamed once for all prompt positions) against the
+    position-by-position prompt: same token ids, same sum of log-probabilities, in f32 and in bf16."""
+    from whisper_ipa_amd.decoding import greedy_decode_tokens
+
+    W, mels, xa = micro
+    sp = R.SpecialTokens.multilingual()
+    always, first = R.suppress_lists(sp)
+    init = list(sp.sot_sequence_including_notimestamps(0))
+    m = _model(MICRO, W, dtype)
+    feats = xa.cuda().to(dtype)
+    a = greedy_decode_tokens(m, feats, init, always, first, sp.eot, max_new_tokens=24, stop_on_eot=False)
+    monkeypatch.setenv("WIPA_NO_PREFILL", "1")
+    b = greedy_decode_tokens(m, feats, init, always, first, sp.eot, max_new_tokens=24, stop_on_eot=False)
+    assert a.tokens.shape == b.tokens.shape == (2, 4 + 24)
+    assert (a.tokens == b.tokens).all(), (a.tokens.tolist(), b.tokens.tolist())
+    assert np.abs(a.sum_logprobs - b.sum_logprobs).max() < (1e-3 if dtype == torch.float32 else 0.3)
+    monkeypatch.delenv("WIPA_NO_PREFILL")
+    for n_init in (2, 3):  # shorter prompts take the same path
+        c = greedy_decode_tokens(m, feats, init[:n_init], always, first, sp.eot, max_new_tokens=6, stop_on_eot=False)
+        monkeypatch.setenv("WIPA_NO_PREFILL", "1")
+        d = greedy_decode_tokens(m, feats, init[:n_init], always, first, sp.eot, max_new_tokens=6, stop_on_eot=False)
+        monkeypatch.delenv("WIPA_NO_PREFILL")
+        assert (c.tokens == d.tokens).all()
+
+
 def test_detect_language_matches_oracle(micro):
     from whisper_ipa_amd.decoding import detect_language
     from whisper_ipa_amd.tokenizer import get_tokenizer

@@ -31,6 +31,7 @@ class GemmDesc(C.Structure):
         ("rg_in", C.c_int32), ("rg_valid", C.c_int32), ("cg_in", C.c_int32),
         ("zero_invalid_rows", C.c_int32), ("bias_along_m", C.c_int32), ("act", C.c_int32),
         ("col_scale_n", C.c_int32), ("col_scale", c_float), ("k_slices", C.c_int32),
+        ("stream_weights", C.c_int32),
     ]
 
 
@@ -94,6 +95,8 @@ SIGNATURES = {
     "wipa_decoder_begin": (c_int, [_P(ModelCfg), c_void_p, c_int, _P(C.c_int32), c_int, c_void_p]),
     "wipa_decoder_run": (c_int, [_P(ModelCfg), _P(c_void_p), c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
                                  c_int, c_void_p]),
+    "wipa_decoder_prefill": (c_int, [_P(ModelCfg), _P(c_void_p), c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "wipa_decode_cross_attn_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "wipa_decoder_release": (c_int, [c_void_p]),
     "wipa_decoder_logits_workspace_bytes": (c_size_t, [_P(ModelCfg), c_int, c_int]),
     "wipa_decoder_logits": (c_int, [_P(ModelCfg), _P(c_void_p), c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_size_t,

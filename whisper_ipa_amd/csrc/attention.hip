@@ -288,6 +288,116 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(AttnParams p) {
     }
 }
 
+// Prompt prefill: the NQ prompt positions of a clip attend to the SAME cached cross K/V, so one pass over the cache serves
+// all of them (the per-position decode step would stream the 3.5 GB cache NQ times).  Same decomposition and the same
+// per-query arithmetic order as decode_attn_kernel<T, 4>: 4 waves split the keys, LDS merge; q / out rows are (b, t).
+template <typename T, int NQ>
+__global__ __launch_bounds__(256) void decode_attn_multi_kernel(AttnParams p) {
+    constexpr int EPL = Vec16<T>::EPL;
+    constexpr int LPK = 64 / EPL;
+    constexpr int G = 64 / LPK;
+    constexpr int U = 4;
+    __shared__ float s_m[NQ][4], s_l[NQ][4];
+    __shared__ float s_acc[NQ][4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int g = lane / LPK, c = lane % LPK;
+    const int Tk = p.Tk;
+    float qf[NQ][EPL];
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {
+        const T* qp = reinterpret_cast<const T*>(p.q) + b * p.q_bs + (int64_t)t * p.q_rs + h * p.q_hs + c * EPL;
+        Vec16<T> qv = *reinterpret_cast<const Vec16<T>*>(qp);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) qf[t][e] = qv.get(e);
+    }
+    const T* Kb = reinterpret_cast<const T*>(p.k) + b * p.k_bs + h * p.k_hs + c * EPL;
+    const T* Vb = reinterpret_cast<const T*>(p.v) + b * p.v_bs + h * p.v_hs + c * EPL;
+    const int64_t k_rs = p.k_rs, v_rs = p.v_rs;
+    float m[NQ], l[NQ], acc[NQ][EPL];
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {
+        m[t] = NEG_BIG;
+        l[t] = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[t][e] = 0.f;
+    }
+    constexpr int STEP = 4 * G * U;
+    for (int t0 = wave * G * U; t0 < Tk; t0 += STEP) {
+        Vec16<T> ka[U], va[U];
+        typedef decltype(ka[0].v) VT;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int key = min(t0 + u * G + g, Tk - 1);
+            ka[u].v = __builtin_nontemporal_load(reinterpret_cast<const VT*>(Kb + (int64_t)key * k_rs));
+            va[u].v = __builtin_nontemporal_load(reinterpret_cast<const VT*>(Vb + (int64_t)key * v_rs));
+        }
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) {
+            float s[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float a = 0.f;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) a = fmaf(qf[t][e], ka[u].get(e), a);
+#pragma unroll
+                for (int o = 1; o < LPK; o <<= 1) a += __shfl_xor(a, o, 64);
+                s[u] = (t0 + u * G + g < Tk) ? a : NEG_BIG;
+            }
+            float m_new = m[t];
+#pragma unroll
+            for (int u = 0; u < U; ++u) m_new = fmaxf(m_new, s[u]);
+            const float alpha = __expf(m[t] - m_new);
+            l[t] *= alpha;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc[t][e] *= alpha;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float pr = (s[u] <= NEG_TEST) ? 0.f : __expf(s[u] - m_new);
+                l[t] += pr;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) acc[t][e] = fmaf(pr, va[u].get(e), acc[t][e]);
+            }
+            m[t] = m_new;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {
+#pragma unroll
+        for (int o = LPK; o < 64; o <<= 1) {
+            const float m_o = __shfl_xor(m[t], o, 64);
+            const float l_o = __shfl_xor(l[t], o, 64);
+            const float m_n = fmaxf(m[t], m_o);
+            const float a = __expf(m[t] - m_n), bsc = __expf(m_o - m_n);
+            l[t] = l[t] * a + l_o * bsc;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc[t][e] = acc[t][e] * a + __shfl_xor(acc[t][e], o, 64) * bsc;
+            m[t] = m_n;
+        }
+        if (lane < LPK) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) s_acc[t][wave][c * EPL + e] = acc[t][e];
+            if (lane == 0) {
+                s_m[t][wave] = m[t];
+                s_l[t][wave] = l[t];
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 64 * NQ) {
+        const int t = tid >> 6, dd = tid & 63;
+        const float mm = fmaxf(fmaxf(s_m[t][0], s_m[t][1]), fmaxf(s_m[t][2], s_m[t][3]));
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float sc = __expf(s_m[t][w] - mm);
+            num += s_acc[t][w][dd] * sc;
+            den += s_l[t][w] * sc;
+        }
+        reinterpret_cast<T*>(p.out)[b * p.o_bs + (int64_t)t * p.o_rs + h * p.o_hs + dd] = from_f32<T>(num / den);
+    }
+}
+
 // =============================================================================
 // K5 encoder flash attention, bf16 MFMA 32x32x16
 // =============================================================================
@@ -736,3 +846,34 @@ extern "C" int wipa_decode_cross_attn(const void* q, const void* kv, void* out, 
     d.B = B; d.H = H; d.Tq = 1; d.Tk = Tk; d.causal = 0; d.dtype = dtype;
     return wipa_decode_attn(&d, stream);
 }
+
+extern "C" int wipa_decode_cross_attn_multi(const void* q, const void* kv, void* out, int B, int H, int Tk, int n_q, int dtype,
+                                            wipa_stream_t stream) {
+    WIPA_REQUIRE(q && kv && out, "wipa_decode_cross_attn_multi: null pointer");
+    WIPA_REQUIRE(B > 0 && H > 0 && Tk > 0 && n_q >= 1 && n_q <= 4, "wipa_decode_cross_attn_multi: bad shape (n_q=%d)", n_q);
+    WIPA_REQUIRE(dtype == WIPA_F32 || dtype == WIPA_BF16, "wipa_decode_cross_attn_multi: bad dtype %d", dtype);
+    if (n_q == 1) return wipa_decode_cross_attn(q, kv, out, B, H, Tk, dtype, stream);
+    wipa_attn_desc d;
+    memset(&d, 0, sizeof(d));
+    const size_t e = wipa_dtype_size(dtype);
+    d.q = q; d.k = kv; d.v = (const char*)kv + (size_t)H * Tk * 64 * e; d.out = out;
+    d.q_bs = (int64_t)n_q * H * 64; d.q_rs = (int64_t)H * 64; d.q_hs = 64;
+    d.k_bs = (int64_t)2 * H * Tk * 64; d.k_rs = 64; d.k_hs = (int64_t)Tk * 64;
+    d.v_bs = d.k_bs; d.v_rs = 64; d.v_hs = d.k_hs;
+    d.o_bs = d.q_bs; d.o_rs = d.q_rs; d.o_hs = 64;
+    d.B = B; d.H = H; d.Tq = n_q; d.Tk = Tk; d.causal = 0; d.dtype = dtype;
+    AttnParams p;
+    fill_attn_params(&d, p);
+    const dim3 grid(H, B);
+    hipStream_t s = (hipStream_t)stream;
+#define WIPA_MULTI(T, NQ) hipLaunchKernelGGL((decode_attn_multi_kernel<T, NQ>), grid, dim3(256), 0, s, p)
+    if (dtype == WIPA_F32) {
+        if (n_q == 2) WIPA_MULTI(float, 2); else if (n_q == 3) WIPA_MULTI(float, 3); else WIPA_MULTI(float, 4);
+    } else {
+        if (n_q == 2) WIPA_MULTI(__bf16, 2); else if (n_q == 3) WIPA_MULTI(__bf16, 3); else WIPA_MULTI(__bf16, 4);
+    }
+#undef WIPA_MULTI
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+

@@ -570,6 +570,7 @@ int launch_skinny(const GemmParams& p, hipStream_t s) {
 }
 
 constexpr int SKINNY_MAX_M = 256;  // rows beyond 64 ride on grid.y: every 64-row group streams the (L2-resident) weight slice again
+constexpr int SKINNY_STREAM_MAX_M = 1024;  // ... and up to here for wipa_gemm_desc.stream_weights
 
 // ---------------------------------------------------------------------------------------
 // Large-tile GEMM: 256x256 output tile, 8 waves (2 along M x 4 along N, 128x64 per wave =
@@ -917,7 +918,9 @@ extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
         const int rc = init_attrs();
         if (rc != WIPA_OK) return rc;
     }
-    if (d->M <= SKINNY_MAX_M && !(d->in_dtype == WIPA_F32 && d->out_dtype == WIPA_BF16)) {
+    // weight-streaming kernel: M <= 256 rows, or up to 1024 when the caller marks them as decode rows (prompt prefill)
+    const bool skinny_shape = d->M <= SKINNY_MAX_M || (d->stream_weights && d->M <= SKINNY_STREAM_MAX_M);
+    if (skinny_shape && !(d->in_dtype == WIPA_F32 && d->out_dtype == WIPA_BF16)) {
         if (d->in_dtype == WIPA_BF16)
             return d->out_dtype == WIPA_BF16 ? launch_skinny<__bf16, __bf16>(p, s) : launch_skinny<__bf16, float>(p, s);
         return launch_skinny<float, float>(p, s);

@@ -171,16 +171,18 @@ inline int k_slices_for(int K, int dtype) {
     int s = ksteps / 12;
     return s < 1 ? 1 : (s > MAX_SLABS ? MAX_SLABS : s);
 }
+constexpr int MAX_PROMPT = 4;  // prompt positions handled by one prefill pass (wipa_decoder_begin takes 1..4 tokens)
 DecScratch dec_scratch(const wipa_model_cfg* c, int B) {
     const size_t e = wipa_dtype_size(c->dtype), d = c->n_text_state;
+    const size_t R = (size_t)B * MAX_PROMPT;  // rows: one per clip in a decode step, up to four per clip in the prefill
     DecScratch s;
     size_t o = 0;
-    s.x = o;    o += align256((size_t)B * d * 4);
-    s.ln = o;   o += align256((size_t)B * d * e);
-    s.q = o;    o += align256((size_t)B * d * e);
-    s.ao = o;   o += align256((size_t)B * d * e);
-    s.h = o;    o += align256((size_t)B * 4 * d * e);
-    s.slabs = o; o += align256((size_t)MAX_SLABS * B * d * 4);
+    s.x = o;    o += align256(R * d * 4);
+    s.ln = o;   o += align256(R * d * e);
+    s.q = o;    o += align256(R * d * e);
+    s.ao = o;   o += align256(R * d * e);
+    s.h = o;    o += align256(R * 4 * d * e);
+    s.slabs = o; o += align256((size_t)MAX_SLABS * R * d * 4);
     s.posd = o; o += 256;
     s.total = o;
     return s;
@@ -251,7 +253,7 @@ int enqueue_step(const wipa_model_cfg* cfg, const void* const* w, char* st, cons
     auto residual_gemm = [&](const void* A, int K, const void* W, const void* bias) -> int {
         wipa_gemm_desc g;
         memset(&g, 0, sizeof(g));
-        g.k_slices = B <= 256 ? k_slices_for(K, dt) : 1;  // split-K lives in the skinny (M <= 256) kernel
+        g.k_slices = B <= 256 ? k_slices_for(K, dt) : 1;  // split-K lives in the weight-streaming (M <= 256) kernel
         g.slab_stride = slab_stride;
         pend = g.k_slices;
         return gemm(A, K, W, K, slabs, d, B, d, K, dt, WIPA_F32, (const float*)bias, 0, nullptr, stream, &g);
@@ -302,6 +304,110 @@ int enqueue_step(const wipa_model_cfg* cfg, const void* const* w, char* st, cons
     RT_CALL(ln_step(w[2], w[3]));
     float* logits = (float*)(st + L.logits);
     RT_CALL(gemm(ln, d, w[0], d, logits, L.ld_logits, B, cfg->n_vocab, d, dt, WIPA_F32, nullptr, 0, nullptr, stream));
+    RT_CALL(wipa_greedy_step(logits, L.ld_logits, B, cfg->n_vocab, mask_first, mask_always, tokens, L.ld_tok, pos, n_init,
+                             eot, (float*)(st + L.sum_logprobs), (int32_t*)(st + L.not_done), stream));
+    hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, pos, posd, d);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+__global__ void set_pos_kernel(int32_t* pos, int64_t* posd, int value, int d) {
+    *pos = value;
+    *posd = (int64_t)value * d;
+}
+
+// The first n_init decoder steps as ONE batched pass over the prompt (rows (b, t), t < n_init): mlx_whisper runs the
+// prompt through the decoder in one forward too.  Self-K/V of positions 0..n_init-1 land in the cache, the cross K/V are
+// streamed once for all prompt positions (decode_attn_multi_kernel), logits are computed for the last position only, and
+// the greedy update writes token n_init.  Afterwards the state equals that after n_init calls of enqueue_step.
+int enqueue_prefill(const wipa_model_cfg* cfg, const void* const* w, char* st, const wipa_dec_layout& L, int B, int n_init,
+                    int eot, const float* mask_first, const float* mask_always, wipa_stream_t stream) {
+    const int dt = cfg->dtype;
+    const size_t e = wipa_dtype_size(dt);
+    const int d = cfg->n_text_state, H = cfg->n_text_head, nctx = cfg->n_text_ctx, Ta = cfg->n_audio_ctx;
+    const int P = n_init, M = B * P;
+    const DecScratch S = dec_scratch(cfg, B);
+    char* sc = st + L.scratch;
+    float* x = (float*)(sc + S.x);
+    char* ln = sc + S.ln;
+    void* q = sc + S.q;
+    void* ao = sc + S.ao;
+    void* hb = sc + S.h;
+    int64_t* posd = (int64_t*)(sc + S.posd);
+    int32_t* tokens = (int32_t*)(st + L.tokens);
+    int32_t* pos = (int32_t*)(st + L.pos);
+    float* slabs = (float*)(sc + S.slabs);
+    const int64_t slab_stride = (int64_t)M * d;
+    int pend = 0;
+    auto ln_step = [&](const void* lw_w, const void* lw_b) -> int {
+        const int rc = wipa_add_slabs_layernorm(x, d, slabs, pend, slab_stride, ln, dt, d, (const float*)lw_w, (const float*)lw_b,
+                                                M, d, 1e-5f, stream);
+        pend = 0;
+        return rc;
+    };
+    auto residual_gemm = [&](const void* A, int K, const void* W, const void* bias) -> int {
+        wipa_gemm_desc g;
+        memset(&g, 0, sizeof(g));
+        g.stream_weights = 1;
+        g.k_slices = M <= 1024 ? k_slices_for(K, dt) : 1;
+        g.slab_stride = slab_stride;
+        pend = g.k_slices;
+        return gemm(A, K, W, K, slabs, d, M, d, K, dt, WIPA_F32, (const float*)bias, 0, nullptr, stream, &g);
+    };
+    RT_CALL(wipa_embed_tokens(tokens, L.ld_tok, B, P, 0, nullptr, w[0], dt, (const float*)w[1], x, d, stream));
+    for (int l = 0; l < cfg->n_text_layer; ++l) {
+        const void* const* lw = w + WIPA_DEC_GLOBAL + WIPA_DEC_PER_LAYER * l;
+        char* skv = st + L.self_kv + (size_t)l * 3 * B * nctx * d * e;  // [3][B][nctx][d]
+        char* ckv = st + L.cross_kv + (size_t)l * B * 2 * H * Ta * 64 * e;
+        RT_CALL(ln_step(lw[0], lw[1]));
+        {
+            // q|k|v of positions 0..P-1 -> slot[n / d][b][t][n % d]
+            wipa_gemm_desc g;
+            memset(&g, 0, sizeof(g));
+        g.stream_weights = 1;
+            g.col_scale_n = 2 * d; g.col_scale = QK_SCALE;
+            g.rg_in = P; g.rg_valid = P; g.rg_stride = (int64_t)nctx * d;
+            g.cg_in = d; g.cg_stride = (int64_t)B * nctx * d;
+            RT_CALL(gemm(ln, d, lw[2], d, skv, d, M, 3 * d, d, dt, dt, (const float*)lw[3], 0, nullptr, stream, &g));
+        }
+        {
+            wipa_attn_desc a;
+            memset(&a, 0, sizeof(a));
+            const size_t slot = (size_t)B * nctx * d * e;
+            a.q = skv; a.k = skv + slot; a.v = skv + 2 * slot; a.out = ao;
+            a.q_bs = (int64_t)nctx * d; a.q_rs = d; a.q_hs = 64;
+            a.k_bs = a.q_bs; a.k_rs = d; a.k_hs = 64;
+            a.v_bs = a.q_bs; a.v_rs = d; a.v_hs = 64;
+            a.o_bs = (int64_t)P * d; a.o_rs = d; a.o_hs = 64;
+            a.B = B; a.H = H; a.Tq = P; a.Tk = P; a.causal = 1; a.dtype = dt;
+            RT_CALL(wipa_attention(&a, stream));
+        }
+        RT_CALL(residual_gemm(ao, d, lw[4], lw[5]));
+        RT_CALL(ln_step(lw[6], lw[7]));
+        {
+            wipa_gemm_desc g;
+            memset(&g, 0, sizeof(g));
+        g.stream_weights = 1;
+            g.col_scale_n = d; g.col_scale = QK_SCALE;
+            RT_CALL(gemm(ln, d, lw[8], d, q, d, M, d, d, dt, dt, (const float*)lw[9], 0, nullptr, stream, &g));
+        }
+        RT_CALL(wipa_decode_cross_attn_multi(q, ckv, ao, B, H, Ta, P, dt, stream));
+        RT_CALL(residual_gemm(ao, d, lw[12], lw[13]));
+        RT_CALL(ln_step(lw[14], lw[15]));
+        {
+            wipa_gemm_desc g;
+            memset(&g, 0, sizeof(g));
+            g.stream_weights = 1;
+            RT_CALL(gemm(ln, d, lw[16], d, hb, 4 * d, M, 4 * d, d, dt, dt, (const float*)lw[17], 1, nullptr, stream, &g));
+        }
+        RT_CALL(residual_gemm(hb, 4 * d, lw[18], lw[19]));
+    }
+    RT_CALL(ln_step(w[2], w[3]));
+    float* logits = (float*)(st + L.logits);
+    // logits of the LAST prompt position only: rows (b, P-1) of ln, i.e. row stride P*d
+    RT_CALL(gemm(ln + (size_t)(P - 1) * d * e, (int64_t)P * d, w[0], d, logits, L.ld_logits, B, cfg->n_vocab, d, dt, WIPA_F32, nullptr, 0,
+                 nullptr, stream));
+    hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, pos, posd, P - 1, d);
     RT_CALL(wipa_greedy_step(logits, L.ld_logits, B, cfg->n_vocab, mask_first, mask_always, tokens, L.ld_tok, pos, n_init,
                              eot, (float*)(st + L.sum_logprobs), (int32_t*)(st + L.not_done), stream));
     hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, pos, posd, d);
@@ -404,6 +510,16 @@ extern "C" int wipa_decoder_run(const wipa_model_cfg* cfg, const void* const* w,
     }
     for (int i = 0; i < n_steps; ++i) WIPA_CHECK_HIP(hipGraphLaunch(exec, s));
     return WIPA_OK;
+}
+
+extern "C" int wipa_decoder_prefill(const wipa_model_cfg* cfg, const void* const* w, void* state, int B, int n_init, int eot,
+                                    const float* mask_first, const float* mask_always, wipa_stream_t stream) {
+    RT_CALL(cfg_check(cfg));
+    WIPA_REQUIRE(w && state && mask_first && mask_always && B > 0, "wipa_decoder_prefill: bad arguments");
+    WIPA_REQUIRE(n_init >= 1 && n_init <= MAX_PROMPT, "wipa_decoder_prefill: 1..%d prompt tokens (got %d)", MAX_PROMPT, n_init);
+    const wipa_dec_layout L = dec_layout(cfg, B);
+    if (n_init == 1) return enqueue_step(cfg, w, (char*)state, L, B, n_init, eot, mask_first, mask_always, stream);
+    return enqueue_prefill(cfg, w, (char*)state, L, B, n_init, eot, mask_first, mask_always, stream);
 }
 
 extern "C" int wipa_decoder_release(void* state) {

@@ -9,6 +9,8 @@ memory; the host only looks at the last token column every few steps to stop ear
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 import zlib
 from dataclasses import dataclass, field
@@ -144,6 +146,11 @@ class GreedyHandle:
     keep: tuple = ()  # tensors that must outlive the enqueued work
 
 
+def _use_prefill(n_init: int, total_steps: int) -> bool:
+    """Batched prompt pass (wipa_decoder_prefill) unless WIPA_NO_PREFILL=1 asks for the step-by-step prompt."""
+    return n_init >= 2 and total_steps >= n_init and os.environ.get("WIPA_NO_PREFILL") != "1"
+
+
 def greedy_launch(model, audio_features: torch.Tensor, initial_tokens: Sequence[int], suppress_always: Sequence[int],
                   suppress_first: Sequence[int], eot: int, max_new_tokens: int, use_graph: bool = True) -> GreedyHandle:
     """Enqueue cross-KV projection + a FIXED number of decoder steps on the current library
@@ -164,8 +171,13 @@ def greedy_launch(model, audio_features: torch.Tensor, initial_tokens: Sequence[
         _lib.check(L.wipa_decoder_set_audio(C.byref(pk["cfg"]), pk["dec_tab"], ptr(feats), ptr(st.blob), B, sptr(s)),
                    "wipa_decoder_set_audio")
         _lib.check(L.wipa_decoder_begin(C.byref(pk["cfg"]), ptr(st.blob), B, init, n_init, sptr(s)), "wipa_decoder_begin")
+        rest = total
+        if _use_prefill(n_init, total):  # the prompt positions and the first new token in one batched pass
+            _lib.check(L.wipa_decoder_prefill(C.byref(pk["cfg"]), pk["dec_tab"], ptr(st.blob), B, n_init, eot, ptr(m_first),
+                                              ptr(m_always), sptr(s)), "wipa_decoder_prefill")
+            rest = total - n_init
         _lib.check(L.wipa_decoder_run(C.byref(pk["cfg"]), pk["dec_tab"], ptr(st.blob), B, n_init, eot, ptr(m_first),
-                                      ptr(m_always), total, int(use_graph), sptr(s)), "wipa_decoder_run")
+                                      ptr(m_always), rest, int(use_graph), sptr(s)), "wipa_decoder_run")
     return GreedyHandle(st, s, n_init, total, (feats, m_always, m_first))
 
 
@@ -201,6 +213,10 @@ def greedy_decode_tokens(model, audio_features: torch.Tensor, initial_tokens: Se
         _lib.check(L.wipa_decoder_set_audio(C.byref(pk["cfg"]), pk["dec_tab"], ptr(feats), ptr(st.blob), B, sptr(s)),
                    "wipa_decoder_set_audio")
         _lib.check(L.wipa_decoder_begin(C.byref(pk["cfg"]), ptr(st.blob), B, init, n_init, sptr(s)), "wipa_decoder_begin")
+        if _use_prefill(n_init, total):
+            _lib.check(L.wipa_decoder_prefill(C.byref(pk["cfg"]), pk["dec_tab"], ptr(st.blob), B, n_init, eot, ptr(m_first),
+                                              ptr(m_always), sptr(s)), "wipa_decoder_prefill")
+            done_steps = n_init
         while done_steps < total:
             n = min(check_every if stop_on_eot else total, total - done_steps)
             if done_steps == 0:
