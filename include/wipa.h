@@ -248,7 +248,7 @@ int wipa_decoder_run(const wipa_model_cfg* cfg, const void* const* weights, void
  * are streamed once for all prompt positions and the small per-step kernels run once (mlx_whisper also feeds the whole
  * prompt through the decoder in one forward).  Continue with wipa_decoder_run for the remaining steps. */
 int wipa_decoder_prefill(const wipa_model_cfg* cfg, const void* const* w, void* state, int B, int n_init, int eot,
-                         const float* mask_first, const float* mask_always, wipa_stream_t s);
+                         const float* mask_first, const float* mask_always, int use_graph, wipa_stream_t s);
 /* drop the cached step graphs that reference this state blob (call before freeing it). */
 int wipa_decoder_release(void* state);
 

@@ -416,7 +416,7 @@ int enqueue_prefill(const wipa_model_cfg* cfg, const void* const* w, char* st, c
 }
 
 // graph cache: one captured step per (state blob, weights, masks, shape)
-typedef std::tuple<const void*, const void*, const void*, const void*, int, int, int, int> GraphKey;
+typedef std::tuple<const void*, const void*, const void*, const void*, int, int, int, int, int> GraphKey;  // ..., kind: 0 step, 1 prefill
 std::mutex g_graph_mu;
 std::map<GraphKey, hipGraphExec_t> g_graphs;
 
@@ -487,7 +487,7 @@ extern "C" int wipa_decoder_run(const wipa_model_cfg* cfg, const void* const* w,
     }
     WIPA_REQUIRE(s != nullptr, "wipa_decoder_run: graph capture needs a non-default stream");
     hipGraphExec_t exec = nullptr;
-    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype);
+    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype, 0);
     {
         std::lock_guard<std::mutex> lk(g_graph_mu);
         auto it = g_graphs.find(key);
@@ -513,13 +513,42 @@ extern "C" int wipa_decoder_run(const wipa_model_cfg* cfg, const void* const* w,
 }
 
 extern "C" int wipa_decoder_prefill(const wipa_model_cfg* cfg, const void* const* w, void* state, int B, int n_init, int eot,
-                                    const float* mask_first, const float* mask_always, wipa_stream_t stream) {
+                                    const float* mask_first, const float* mask_always, int use_graph, wipa_stream_t stream) {
     RT_CALL(cfg_check(cfg));
     WIPA_REQUIRE(w && state && mask_first && mask_always && B > 0, "wipa_decoder_prefill: bad arguments");
     WIPA_REQUIRE(n_init >= 1 && n_init <= MAX_PROMPT, "wipa_decoder_prefill: 1..%d prompt tokens (got %d)", MAX_PROMPT, n_init);
     const wipa_dec_layout L = dec_layout(cfg, B);
-    if (n_init == 1) return enqueue_step(cfg, w, (char*)state, L, B, n_init, eot, mask_first, mask_always, stream);
-    return enqueue_prefill(cfg, w, (char*)state, L, B, n_init, eot, mask_first, mask_always, stream);
+    char* st = (char*)state;
+    auto enqueue = [&]() -> int {
+        if (n_init == 1) return enqueue_step(cfg, w, st, L, B, n_init, eot, mask_first, mask_always, stream);
+        return enqueue_prefill(cfg, w, st, L, B, n_init, eot, mask_first, mask_always, stream);
+    };
+    hipStream_t s = (hipStream_t)stream;
+    if (!use_graph || s == nullptr) return enqueue();
+    hipGraphExec_t exec = nullptr;
+    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype, 1);
+    {
+        std::lock_guard<std::mutex> lk(g_graph_mu);
+        auto it = g_graphs.find(key);
+        if (it != g_graphs.end()) exec = it->second;
+    }
+    if (!exec) {
+        hipGraph_t graph = nullptr;
+        WIPA_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+        const int rc = enqueue();
+        const hipError_t ee = hipStreamEndCapture(s, &graph);
+        if (rc != WIPA_OK) {
+            if (graph) hipGraphDestroy(graph);
+            return rc;
+        }
+        WIPA_CHECK_HIP(ee);
+        WIPA_CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        WIPA_CHECK_HIP(hipGraphDestroy(graph));
+        std::lock_guard<std::mutex> lk(g_graph_mu);
+        g_graphs[key] = exec;
+    }
+    WIPA_CHECK_HIP(hipGraphLaunch(exec, s));
+    return WIPA_OK;
 }
 
 extern "C" int wipa_decoder_release(void* state) {

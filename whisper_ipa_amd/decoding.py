@@ -174,7 +174,7 @@ def greedy_launch(model, audio_features: torch.Tensor, initial_tokens: Sequence[
         rest = total
         if _use_prefill(n_init, total):  # the prompt positions and the first new token in one batched pass
             _lib.check(L.wipa_decoder_prefill(C.byref(pk["cfg"]), pk["dec_tab"], ptr(st.blob), B, n_init, eot, ptr(m_first),
-                                              ptr(m_always), sptr(s)), "wipa_decoder_prefill")
+                                              ptr(m_always), int(use_graph), sptr(s)), "wipa_decoder_prefill")
             rest = total - n_init
         _lib.check(L.wipa_decoder_run(C.byref(pk["cfg"]), pk["dec_tab"], ptr(st.blob), B, n_init, eot, ptr(m_first),
                                       ptr(m_always), rest, int(use_graph), sptr(s)), "wipa_decoder_run")
@@ -215,7 +215,7 @@ def greedy_decode_tokens(model, audio_features: torch.Tensor, initial_tokens: Se
         _lib.check(L.wipa_decoder_begin(C.byref(pk["cfg"]), ptr(st.blob), B, init, n_init, sptr(s)), "wipa_decoder_begin")
         if _use_prefill(n_init, total):
             _lib.check(L.wipa_decoder_prefill(C.byref(pk["cfg"]), pk["dec_tab"], ptr(st.blob), B, n_init, eot, ptr(m_first),
-                                              ptr(m_always), sptr(s)), "wipa_decoder_prefill")
+                                              ptr(m_always), int(use_graph), sptr(s)), "wipa_decoder_prefill")
             done_steps = n_init
         while done_steps < total:
             n = min(check_every if stop_on_eot else total, total - done_steps)
