@@ -187,7 +187,7 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, const f32x4& a, c
 // 16 output bytes of one row and 8 (bf16) / 16 (f32) consecutive lanes cover a whole 128/256-byte row
 // segment -> half / equal the store instructions, all full-line, and bias / residual / positional
 // operands are read with the same coalesced shape.
-template <typename OutT, int MTILES, int J0 = 0, int NJ = MTILES>  // row slices J0 .. J0+NJ-1 of the MTILES the wave holds
+template <typename OutT, int MTILES, int J0 = 0, int NJ = MTILES, bool ACT = true>  // row slices J0 .. J0+NJ-1; ACT: GELU path compiled in
 __device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x4 (&acc)[4][MTILES], char* scratch, int m_base,
                                                 int n_base, int64_t coff_dev, int lane) {
     constexpr int EPC = 16 / (int)sizeof(OutT);  // output elements per lane per store (8 bf16 / 4 f32)
@@ -254,12 +254,14 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x4
             const int64_t off = R.roff + coff;
 #pragma unroll
             for (int e = 0; e < EPC; ++e) v[e] = (v[e] + bias[e] + R.bm) * sc;
-            if (p.act == 1) {
+            if constexpr (ACT) {
+                if (p.act == 1) {
 #pragma unroll
-                for (int e = 0; e < EPC; e += 2) {
-                    const f32x2 g = gelu_erf2(f32x2{v[e], v[e + 1]});
-                    v[e] = g.x;
-                    v[e + 1] = g.y;
+                    for (int e = 0; e < EPC; e += 2) {
+                        const f32x2 g = gelu_erf2(f32x2{v[e], v[e + 1]});
+                        v[e] = g.x;
+                        v[e + 1] = g.y;
+                    }
                 }
             }
             if (p.pos) {
@@ -780,7 +782,7 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmParams p) {
     int64_t coff_dev = p.c_offset;
     if (p.c_offset_dev) coff_dev += *p.c_offset_dev;
     if (p.stage_ok) {
-        epilogue_staged<OutT, 12>(p, acc, smem + wave * 4096, m0 + wm * 192, n0 + wn * 64, coff_dev, lane);
+        epilogue_staged<OutT, 12, 0, 12, false>(p, acc, smem + wave * 4096, m0 + wm * 192, n0 + wn * 64, coff_dev, lane);  // no GELU here
         return;
     }
     EpiCol cols[4];
@@ -934,16 +936,16 @@ extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
     const bool big = pitch_ok && p.k_slices == 1 && (  // split-K beyond the skinny rows lives in the 128x128 kernel
                      force_tile >= 256 ||  // WIPA_GEMM_TILE=256: the 256x256 kernel for every shape
                                   (force_tile != 128 && d->M >= 512 && d->N >= 256 && (int64_t)d->M * d->N >= (1 << 20)));
-    // 384 x 256 tile (fewer staged bytes per FLOP, 2.93 instead of 4.39 rounds at N = 768) where it measured faster:
-    // f32 outputs (no spills in that instantiation), long K, or a 256-tile grid that wastes > 10 % of its last round.
-    bool use384 = force_tile == 384;
-    if (big && force_tile == 0) {
+    // 384 x 256 tile (fewer staged bytes per FLOP, 2.93 instead of 4.39 rounds at N = 768): measured faster on every encoder
+    // shape without an activation (its instantiations are compiled without the GELU path, which is what keeps 192
+    // accumulators + the epilogue under 256 registers), unless its grid quantises clearly worse than the 256-tile grid.
+    bool use384 = force_tile == 384 && d->act == 0;
+    if (big && force_tile == 0 && d->act == 0 && d->M >= 2 * XBM) {
         const int64_t t256 = (int64_t)((d->M + LBM - 1) / LBM) * ((d->N + LBN - 1) / LBN);
         const int64_t t384 = (int64_t)((d->M + XBM - 1) / XBM) * ((d->N + LBN - 1) / LBN);
         const double e256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);
         const double e384 = (double)t384 / (double)(((t384 + 255) / 256) * 256);
-        use384 = d->M >= 2 * XBM && e384 >= 0.9 * e256 &&
-                 (d->out_dtype == WIPA_F32 || d->K * esz >= 4096 || (e256 < 0.9 && e384 >= 0.95));
+        use384 = e384 >= 0.95 * e256;
     }
     if (big && use384) {
         if (d->in_dtype == WIPA_BF16)
