@@ -699,7 +699,7 @@ constexpr int XA_TILE = XBM * ROWB;        // 48 KiB
 constexpr int XSTAGE = XW_TILE + XA_TILE;  // 80 KiB
 constexpr int XSMEM = 2 * XSTAGE;          // 160 KiB
 
-template <typename T, typename OutT>
+template <typename T, typename OutT, bool ACT>
 __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][W tile 256 rows | A tile 384 rows]
     const int tid = threadIdx.x;
@@ -782,7 +782,27 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmParams p) {
     int64_t coff_dev = p.c_offset;
     if (p.c_offset_dev) coff_dev += *p.c_offset_dev;
     if (p.stage_ok) {
-        epilogue_staged<OutT, 12, 0, 12, false>(p, acc, smem + wave * 4096, m0 + wm * 192, n0 + wn * 64, coff_dev, lane);  // no GELU here
+        if constexpr (ACT) {
+            // GELU on the MFMA layout, in place and BEFORE the transposing epilogue (which is compiled without its GELU path:
+            // 192 accumulators + those temporaries would spill).  A lane holds columns n0 + 64 wn + 16 i + 4 fq + (0..3).
+            // The dispatcher sends an activation here only with a plain column bias and no column scale.
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = n0 + wn * 64 + 16 * i + 4 * fq;
+                float b4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b4[e] = (p.bias && n + e < p.N) ? p.bias[n + e] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 12; ++j) {
+                    const f32x2 g0 = gelu_erf2(f32x2{acc[i][j][0] + b4[0], acc[i][j][1] + b4[1]});
+                    const f32x2 g1 = gelu_erf2(f32x2{acc[i][j][2] + b4[2], acc[i][j][3] + b4[3]});
+                    acc[i][j] = f32x4{g0.x, g0.y, g1.x, g1.y};
+                    __builtin_amdgcn_sched_barrier(0);  // one tile at a time: the scheduler would otherwise overlap all 48 and spill
+                }
+            }
+            p.bias = nullptr;
+        }
+        epilogue_staged<OutT, 12, 0, 12, false>(p, acc, smem + wave * 4096, m0 + wm * 192, n0 + wn * 64, coff_dev, lane);
         return;
     }
     EpiCol cols[4];
@@ -800,7 +820,10 @@ template <typename T, typename OutT>
 int launch384(GemmParams p, hipStream_t s) {
     p.tiles_m = (p.M + XBM - 1) / XBM;
     p.tiles_n = (p.N + LBN - 1) / LBN;
-    hipLaunchKernelGGL((gemm_nt384_kernel<T, OutT>), dim3(p.tiles_m * p.tiles_n), dim3(512), XSMEM, s, p);
+    if (p.act == 1 && p.stage_ok)
+        hipLaunchKernelGGL((gemm_nt384_kernel<T, OutT, true>), dim3(p.tiles_m * p.tiles_n), dim3(512), XSMEM, s, p);
+    else
+        hipLaunchKernelGGL((gemm_nt384_kernel<T, OutT, false>), dim3(p.tiles_m * p.tiles_n), dim3(512), XSMEM, s, p);
     WIPA_LAUNCH_CHECK();
     return WIPA_OK;
 }
@@ -837,10 +860,14 @@ int init_attrs() {
             const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LSMEM);
             if (e != hipSuccess) err = e;
         }
-        const void* wide[4] = {reinterpret_cast<const void*>(&gemm_nt384_kernel<__bf16, __bf16>),
-                               reinterpret_cast<const void*>(&gemm_nt384_kernel<__bf16, float>),
-                               reinterpret_cast<const void*>(&gemm_nt384_kernel<float, __bf16>),
-                               reinterpret_cast<const void*>(&gemm_nt384_kernel<float, float>)};
+        const void* wide[8] = {reinterpret_cast<const void*>(&gemm_nt384_kernel<__bf16, __bf16, false>),
+                               reinterpret_cast<const void*>(&gemm_nt384_kernel<__bf16, float, false>),
+                               reinterpret_cast<const void*>(&gemm_nt384_kernel<float, __bf16, false>),
+                               reinterpret_cast<const void*>(&gemm_nt384_kernel<float, float, false>),
+                               reinterpret_cast<const void*>(&gemm_nt384_kernel<__bf16, __bf16, true>),
+                               reinterpret_cast<const void*>(&gemm_nt384_kernel<__bf16, float, true>),
+                               reinterpret_cast<const void*>(&gemm_nt384_kernel<float, __bf16, true>),
+                               reinterpret_cast<const void*>(&gemm_nt384_kernel<float, float, true>)};
         for (const void* f : wide) {
             const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, XSMEM);
             if (e != hipSuccess) err = e;
@@ -939,8 +966,11 @@ extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
     // 384 x 256 tile (fewer staged bytes per FLOP, 2.93 instead of 4.39 rounds at N = 768): measured faster on every encoder
     // shape without an activation (its instantiations are compiled without the GELU path, which is what keeps 192
     // accumulators + the epilogue under 256 registers), unless its grid quantises clearly worse than the 256-tile grid.
-    bool use384 = force_tile == 384 && d->act == 0;
-    if (big && force_tile == 0 && d->act == 0 && d->M >= 2 * XBM) {
+    // an activation is applied before the epilogue there, which is only equivalent for: column bias, no column scale, no
+    // positional term, no residual ordering issue (act precedes pos/residual in epilogue order anyway)
+    const bool act384_ok = d->act == 0 || (p.stage_ok && !d->bias_along_m && d->col_scale_n == 0);
+    bool use384 = force_tile == 384 && act384_ok;
+    if (big && force_tile == 0 && act384_ok && d->M >= 2 * XBM) {
         const int64_t t256 = (int64_t)((d->M + LBM - 1) / LBM) * ((d->N + LBN - 1) / LBN);
         const int64_t t384 = (int64_t)((d->M + XBM - 1) / XBM) * ((d->N + LBN - 1) / LBN);
         const double e256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);
