@@ -187,7 +187,8 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, const f32x4& a, c
 // 16 output bytes of one row and 8 (bf16) / 16 (f32) consecutive lanes cover a whole 128/256-byte row
 // segment -> half / equal the store instructions, all full-line, and bias / residual / positional
 // operands are read with the same coalesced shape.
-template <typename OutT, int MTILES, int J0 = 0, int NJ = MTILES, bool ACT = true>  // row slices J0 .. J0+NJ-1; ACT: GELU path compiled in
+// row slices J0 .. J0+NJ-1 of the MTILES the wave holds; ACT: GELU path compiled in; RES_EARLY: residual fetched ahead
+template <typename OutT, int MTILES, int J0 = 0, int NJ = MTILES, bool ACT = true, bool RES_EARLY = true>
 __device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x4 (&acc)[4][MTILES], char* scratch, int m_base,
                                                 int n_base, int64_t coff_dev, int lane) {
     constexpr int EPC = 16 / (int)sizeof(OutT);  // output elements per lane per store (8 bf16 / 4 f32)
@@ -213,7 +214,10 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x4
     // The residual of slice j+1 is fetched while slice j goes through the LDS transpose: without this each pass issued its
     // own dependent 16-byte load and the f32-residual epilogue ran at ~1.7x its HBM time.
     constexpr int NPASS = 16 / RPP;
-    constexpr bool PREFETCH = MTILES <= 8;  // with 12 row slices (192 accumulators) the prefetch registers would spill
+    // with 12 row slices (192 accumulators) a slice-ahead prefetch would spill: there the residual of a slice is issued at the
+    // START of that slice instead, so it at least overlaps the slice's LDS round trip
+    constexpr bool PREFETCH = RES_EARLY;  // (the GELU instantiation of the 12-slice tile has no registers to spare)
+    constexpr bool AHEAD = MTILES <= 8;
     const bool res_vec = PREFETCH && p.residual != nullptr && col_ok && nvalid == EPC;
     Vec16<OutT> rnext[NPASS];
     auto fetch_residual = [&](int j, Vec16<OutT> (&dst)[NPASS]) {
@@ -226,14 +230,18 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x4
             }
         }
     };
-    if (res_vec) fetch_residual(J0, rnext);
+    if (AHEAD && res_vec) fetch_residual(J0, rnext);
 #pragma unroll
     for (int j = J0; j < J0 + NJ; ++j) {
         Vec16<OutT> rcur[NPASS];
         if (res_vec) {
+            if constexpr (AHEAD) {
 #pragma unroll
-            for (int pass = 0; pass < NPASS; ++pass) rcur[pass] = rnext[pass];
-            if (j + 1 < J0 + NJ) fetch_residual(j + 1, rnext);
+                for (int pass = 0; pass < NPASS; ++pass) rcur[pass] = rnext[pass];
+                if (j + 1 < J0 + NJ) fetch_residual(j + 1, rnext);
+            } else {
+                fetch_residual(j, rcur);
+            }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -802,7 +810,7 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmParams p) {
             }
             p.bias = nullptr;
         }
-        epilogue_staged<OutT, 12, 0, 12, false>(p, acc, smem + wave * 4096, m0 + wm * 192, n0 + wn * 64, coff_dev, lane);
+        epilogue_staged<OutT, 12, 0, 12, false, !ACT>(p, acc, smem + wave * 4096, m0 + wm * 192, n0 + wn * 64, coff_dev, lane);
         return;
     }
     EpiCol cols[4];
