@@ -544,6 +544,9 @@ __global__ __launch_bounds__(512) void flash_enc_bf16_kernel(const __bf16* __res
                     const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + (((c0 + 1) ^ rsw) << 4));
                     const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, O[dt], 0, 0, 0);
+                    // keep the dt = 0 / dt = 1 reads apart: merged into ds_read2st64_b64 their halves land in the wrong
+                    // register pairs and cost 24 v_mov per tile on the (busier) VALU
+                    asm volatile("" ::: "memory");
                 }
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
