@@ -5,7 +5,8 @@ Metric (BASELINE.json): audio-seconds/sec transcribed, whisper-small, 30 s clips
 Workload at every N: configs[1] = "whisper-small bf16 batched inference, batch=64 x 30 s
 synthetic clips" per GPU.  One "step" = one pass of the hot path over one batch already
 resident in HBM: log-mel -> encoder -> cross-K/V -> prompt + 64 greedy decode positions
-(KV cached, EOT latch on, no early stop so the work is fixed) -> token ids on the host.
+(KV cached, EOT latch on, no early stop so the work is fixed; the 4 prompt positions run as one batched
+prefill pass, as the reference's decoder does) -> token ids on the host.
 N > 1: clips are sharded data-parallel, one process per GPU, no data-path collective
 (weak scaling); the only collective is the barrier / max-reduce of the timing itself.
 Consecutive passes are software-pipelined: up to `--pipeline` (default 4) passes are in flight on
