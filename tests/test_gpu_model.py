@@ -343,6 +343,11 @@ def test_full_size_bench_workload_properties():
     f96, t96 = run(audio96)
     assert torch.equal(f96[:64], f64) and (t96[:64] == t64).all()
     assert len({tuple(r) for r in t96[64:, 4:].tolist()}) > 4
+    # cross-batch decode grouping (bench.py --decode-group): two batches decoded as one group of 128 rows give each
+    # clip the tokens it gets in its own batch
+    grouped = bench.pass_collect(bench.group_launch(m, audio, (init, always, first, eot), 0, 2))
+    assert grouped.shape[0] == 128 and (grouped[:64] == grouped[64:]).all()
+    assert (grouped[:64, : 4 + 16] == t64).all()
 
 
 def test_small_width_bf16_close_and_tokens_match_where_margin_allows(small2):
