@@ -97,6 +97,12 @@ typedef struct wipa_gemm_desc {
                              * 4 rows per clip rounds exactly like the single-row steps (batch invariance) */
 } wipa_gemm_desc;
 int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t s);
+/* float32 inputs in the tile kernels (M > 256 rows): by default every product a*w is taken as three bf16 MFMA terms on
+ * operands split into hi + lo (a_hi*w_lo + a_lo*w_hi + a_hi*w_hi, f32 accumulation): about twice the rate of the f32 MFMA
+ * at ~5e-6 relative error of a K = 768 dot product (the f32 MFMA path itself: ~1.5e-6).  on != 0 selects the f32 MFMA
+ * (exact f32 products); the initial mode is "exact" iff the environment has WIPA_F32_GEMM=exact.  Returns the previous mode.
+ * Process-wide; set it before launching work.  The weight-streaming kernel of the decode steps always uses the f32 MFMA. */
+int wipa_set_f32_gemm_exact(int on);
 
 /* ------------------------------------------------------------------ K3 LayerNorm
  * nn.LayerNorm(eps=1e-5) rows of width D (attn_ln, cross_attn_ln, mlp_ln, ln_post, ln). */

@@ -54,3 +54,14 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(params=["split", "exact"])
+def f32_mode(request):
+    """float32 tile GEMMs: three-term bf16 split (default) or the f32 MFMA (wipa_set_f32_gemm_exact)."""
+    from whisper_ipa_amd import _lib
+
+    L = _lib.lib()
+    prev = L.wipa_set_f32_gemm_exact(1 if request.param == "exact" else 0)
+    yield request.param
+    L.wipa_set_f32_gemm_exact(prev)

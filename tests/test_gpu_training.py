@@ -210,8 +210,11 @@ def test_loss_and_every_decoder_gradient_match_oracle(setup):
     assert set(tr.names) == set(ref)
 
 
-def test_train_step_matches_oracle_clip_and_adamw(setup):
-    """two full steps: clipped gradients and updated parameters equal the oracle's."""
+def test_train_step_matches_oracle_clip_and_adamw(setup, f32_mode):
+    """two full steps: clipped gradients and updated parameters equal the oracle's.  The parameter bound is the sensitive one:
+    without bias correction an element with |g| ~ eps moves by lr * m / (sqrt(v) + eps), which amplifies a 1e-5 relative
+    gradient difference; 2e-4 holds with exact f32 GEMMs, 5e-4 with the three-term bf16 split."""
+    p_tol = 2e-4 if f32_mode == "exact" else 5e-4
     from whisper_ipa_amd.training import DecoderTrainer
     from whisper_ipa_amd.whisper import ModelDimensions, Whisper
 
@@ -239,7 +242,7 @@ def test_train_step_matches_oracle_clip_and_adamw(setup):
             # without bias correction an element with |g| ~ eps moves by lr*0.1*g/eps: 1e-9 of gradient
             # round-off is 1e-5 of parameter, so the end-to-end bound is loose; the exact update rule
             # is pinned by test_clip_adamw_kernel_exact below
-            assert (tr.p(n).cpu() - Wo[n]).abs().max() < 2e-4, (step, "param", n)
+            assert (tr.p(n).cpu() - Wo[n]).abs().max() < p_tol, (step, "param", n)
     # the model's inference tables see the updated weights
     lg = m.logits(tokens[:, :-1].cuda(), xa.cuda())
     with torch.no_grad():

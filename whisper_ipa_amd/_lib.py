@@ -105,6 +105,7 @@ SIGNATURES = {
     "wipa_masked_ce": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                c_void_p]),
     "wipa_transpose": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "wipa_set_f32_gemm_exact": (c_int, [c_int]),
     "wipa_sum_slabs": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int64, c_int, c_void_p]),
     "wipa_colsum": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
     "wipa_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,

@@ -13,7 +13,9 @@
 // four K=4 steps with a consistent K permutation on both operands.
 // Global->register->LDS staging, double buffered, one barrier per K-step; loads for
 // step k+1 are issued before the MFMAs of step k (async-STAGE split).
+#include <atomic>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 
 #include "wipa_common.h"
@@ -21,6 +23,7 @@
 namespace {
 
 struct GemmParams {
+    int f32_split = 0;  // f32 inputs: every product as three bf16 MFMA terms (split_bf16x2) instead of the f32 MFMA
     const char* A;
     const char* W;
     char* C;
@@ -59,6 +62,20 @@ struct Mma<float> {
         for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[e], x[e], acc, 0, 0, 0);
     }
 };
+
+// f32 operands as two bf16 terms: x = hi + lo + O(2^-17 |x|).  Eight consecutive-in-k floats of a lane (two 16-byte LDS
+// chunks) become the hi and lo fragments of one bf16 MFMA K-step; a product a*w is then taken as
+// a_hi*w_lo + a_lo*w_hi + a_hi*w_hi (the dropped a_lo*w_lo and the representation residuals are ~2^-16 relative), each
+// term accumulated in f32 by the matrix pipe at 16x the rate of the f32 MFMA.
+__device__ __forceinline__ void split_bf16x2(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 h = (__bf16)x[e];
+        hi[e] = h;
+        lo[e] = (__bf16)(x[e] - (float)h);
+    }
+}
 
 template <typename OutT>
 __device__ __forceinline__ void store4(char* C, int64_t off, const float (&v)[4], int nvalid, bool vec) {
@@ -407,19 +424,45 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
         if (kt + 1 < nk) gload(kt + 1);
         const char* wb = smem + (kt & 1) * (2 * TILE_BYTES) + (wn * 64 + frow) * ROWB;
         const char* ab = smem + (kt & 1) * (2 * TILE_BYTES) + TILE_BYTES + (wm * 64 + frow) * ROWB;
+        bool done = false;
+        if constexpr (sizeof(T) == 4) {
+            if (p.f32_split) {  // same element order as the 256 / 384 kernels: results do not depend on the tile chosen
+                const int c0 = (fq ^ fsw) << 4, c1 = ((fq + 4) ^ fsw) << 4;
+                bf16x8 wh[4], wl[4];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int coff = ((fq + 4 * kk) ^ fsw) << 4;
-            typename Mma<T>::Frag fw[4], fx[4];
+                for (int i = 0; i < 4; ++i)
+                    split_bf16x2(*reinterpret_cast<const f32x4*>(wb + i * 16 * ROWB + c0),
+                                 *reinterpret_cast<const f32x4*>(wb + i * 16 * ROWB + c1), wh[i], wl[i]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                fw[i] = *reinterpret_cast<const typename Mma<T>::Frag*>(wb + i * 16 * ROWB + coff);
-                fx[i] = *reinterpret_cast<const typename Mma<T>::Frag*>(ab + i * 16 * ROWB + coff);
+                for (int j = 0; j < 4; ++j) {
+                    bf16x8 xh, xl;
+                    split_bf16x2(*reinterpret_cast<const f32x4*>(ab + j * 16 * ROWB + c0),
+                                 *reinterpret_cast<const f32x4*>(ab + j * 16 * ROWB + c1), xh, xl);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xl, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], xh, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xh, acc[i][j], 0, 0, 0);
+                    }
+                }
+                done = true;
             }
+        }
+        if (!done) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int kk = 0; kk < 2; ++kk) {
+                const int coff = ((fq + 4 * kk) ^ fsw) << 4;
+                typename Mma<T>::Frag fw[4], fx[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) Mma<T>::run(fw[i], fx[j], acc[i][j]);
+                for (int i = 0; i < 4; ++i) {
+                    fw[i] = *reinterpret_cast<const typename Mma<T>::Frag*>(wb + i * 16 * ROWB + coff);
+                    fx[i] = *reinterpret_cast<const typename Mma<T>::Frag*>(ab + i * 16 * ROWB + coff);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) Mma<T>::run(fw[i], fx[j], acc[i][j]);
+            }
         }
         if (kt + 1 < nk) swrite((kt + 1) & 1);
         __syncthreads();
@@ -596,7 +639,7 @@ constexpr int LSMEM = 4 * LTILE;   // 128 KiB
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-template <typename T, typename OutT>
+template <typename T, typename OutT, bool SPLIT>  // SPLIT: f32 products as three bf16 MFMA terms
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][W tile | A tile]
     const int tid = threadIdx.x;
@@ -662,18 +705,44 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
         if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
         const char* wb = smem + (kt & 1) * (2 * LTILE) + (wn * 64 + frow) * ROWB;
         const char* ab = smem + (kt & 1) * (2 * LTILE) + LTILE + (wm * 128 + frow) * ROWB;
+        bool done = false;
+        if constexpr (sizeof(T) == 4 && SPLIT) {
+            {
+                const int c0 = (fq ^ fsw) << 4, c1 = ((fq + 4) ^ fsw) << 4;
+                bf16x8 wh[4], wl[4];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int coff = ((fq + 4 * kk) ^ fsw) << 4;
-            typename Mma<T>::Frag fw[4], fx[8];
+                for (int i = 0; i < 4; ++i)
+                    split_bf16x2(*reinterpret_cast<const f32x4*>(wb + i * 16 * ROWB + c0),
+                                 *reinterpret_cast<const f32x4*>(wb + i * 16 * ROWB + c1), wh[i], wl[i]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fw[i] = *reinterpret_cast<const typename Mma<T>::Frag*>(wb + i * 16 * ROWB + coff);
+                for (int j = 0; j < 8; ++j) {
+                    bf16x8 xh, xl;
+                    split_bf16x2(*reinterpret_cast<const f32x4*>(ab + j * 16 * ROWB + c0),
+                                 *reinterpret_cast<const f32x4*>(ab + j * 16 * ROWB + c1), xh, xl);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) fx[j] = *reinterpret_cast<const typename Mma<T>::Frag*>(ab + j * 16 * ROWB + coff);
+                    for (int i = 0; i < 4; ++i) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xl, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], xh, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xh, acc[i][j], 0, 0, 0);
+                    }
+                }
+                done = true;
+            }
+        }
+        if (!done) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int kk = 0; kk < 2; ++kk) {
+                const int coff = ((fq + 4 * kk) ^ fsw) << 4;
+                typename Mma<T>::Frag fw[4], fx[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) Mma<T>::run(fw[i], fx[j], acc[i][j]);
+                for (int i = 0; i < 4; ++i) fw[i] = *reinterpret_cast<const typename Mma<T>::Frag*>(wb + i * 16 * ROWB + coff);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) fx[j] = *reinterpret_cast<const typename Mma<T>::Frag*>(ab + j * 16 * ROWB + coff);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) Mma<T>::run(fw[i], fx[j], acc[i][j]);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -707,7 +776,7 @@ constexpr int XA_TILE = XBM * ROWB;        // 48 KiB
 constexpr int XSTAGE = XW_TILE + XA_TILE;  // 80 KiB
 constexpr int XSMEM = 2 * XSTAGE;          // 160 KiB
 
-template <typename T, typename OutT, bool ACT>
+template <typename T, typename OutT, bool ACT, bool SPLIT>  // SPLIT (f32 inputs only): products as three bf16 MFMA terms
 __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][W tile 256 rows | A tile 384 rows]
     const int tid = threadIdx.x;
@@ -766,6 +835,27 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmParams p) {
         if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
         const char* wb = smem + (kt & 1) * XSTAGE + (wn * 64 + frow) * ROWB;
         const char* ab = smem + (kt & 1) * XSTAGE + XW_TILE + (wm * 192 + frow) * ROWB;
+        if constexpr (SPLIT && sizeof(T) == 4) {
+            // one bf16 MFMA K-step per stage: the lane's floats 4fq..4fq+3 and 16+4fq..19+4fq of every row
+            const int c0 = (fq ^ fsw) << 4, c1 = ((fq + 4) ^ fsw) << 4;
+            bf16x8 wh[4], wl[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                split_bf16x2(*reinterpret_cast<const f32x4*>(wb + i * 16 * ROWB + c0), *reinterpret_cast<const f32x4*>(wb + i * 16 * ROWB + c1),
+                             wh[i], wl[i]);
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                bf16x8 xh, xl;
+                split_bf16x2(*reinterpret_cast<const f32x4*>(ab + j * 16 * ROWB + c0), *reinterpret_cast<const f32x4*>(ab + j * 16 * ROWB + c1),
+                             xh, xl);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xl, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], xh, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xh, acc[i][j], 0, 0, 0);
+                }
+            }
+        } else {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int coff = ((fq + 4 * kk) ^ fsw) << 4;
@@ -783,6 +873,7 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmParams p) {
                     for (int j = 0; j < 4; ++j) Mma<T>::run(fw[i], fx[j], acc[i][4 * jg + j]);
             }
         }
+        }  // exact path
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -828,10 +919,20 @@ template <typename T, typename OutT>
 int launch384(GemmParams p, hipStream_t s) {
     p.tiles_m = (p.M + XBM - 1) / XBM;
     p.tiles_n = (p.N + LBN - 1) / LBN;
-    if (p.act == 1 && p.stage_ok)
-        hipLaunchKernelGGL((gemm_nt384_kernel<T, OutT, true>), dim3(p.tiles_m * p.tiles_n), dim3(512), XSMEM, s, p);
+    const dim3 grid(p.tiles_m * p.tiles_n);
+    const bool act = p.act == 1 && p.stage_ok;
+    if constexpr (sizeof(T) == 4) {
+        if (p.f32_split) {
+            if (act) hipLaunchKernelGGL((gemm_nt384_kernel<T, OutT, true, true>), grid, dim3(512), XSMEM, s, p);
+            else hipLaunchKernelGGL((gemm_nt384_kernel<T, OutT, false, true>), grid, dim3(512), XSMEM, s, p);
+            WIPA_LAUNCH_CHECK();
+            return WIPA_OK;
+        }
+    }
+    if (act)
+        hipLaunchKernelGGL((gemm_nt384_kernel<T, OutT, true, false>), grid, dim3(512), XSMEM, s, p);
     else
-        hipLaunchKernelGGL((gemm_nt384_kernel<T, OutT, false>), dim3(p.tiles_m * p.tiles_n), dim3(512), XSMEM, s, p);
+        hipLaunchKernelGGL((gemm_nt384_kernel<T, OutT, false, false>), grid, dim3(512), XSMEM, s, p);
     WIPA_LAUNCH_CHECK();
     return WIPA_OK;
 }
@@ -840,7 +941,10 @@ template <typename T, typename OutT>
 int launch256(GemmParams p, hipStream_t s) {
     p.tiles_m = (p.M + LBM - 1) / LBM;
     p.tiles_n = (p.N + LBN - 1) / LBN;
-    hipLaunchKernelGGL((gemm_nt256_kernel<T, OutT>), dim3(p.tiles_m * p.tiles_n), dim3(512), LSMEM, s, p);
+    if (sizeof(T) == 4 && p.f32_split)
+        hipLaunchKernelGGL((gemm_nt256_kernel<T, OutT, sizeof(T) == 4>), dim3(p.tiles_m * p.tiles_n), dim3(512), LSMEM, s, p);
+    else
+        hipLaunchKernelGGL((gemm_nt256_kernel<T, OutT, false>), dim3(p.tiles_m * p.tiles_n), dim3(512), LSMEM, s, p);
     WIPA_LAUNCH_CHECK();
     return WIPA_OK;
 }
@@ -860,22 +964,28 @@ int init_attrs() {
             const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
             if (e != hipSuccess) err = e;
         }
-        const void* big[4] = {reinterpret_cast<const void*>(&gemm_nt256_kernel<__bf16, __bf16>),
-                              reinterpret_cast<const void*>(&gemm_nt256_kernel<__bf16, float>),
-                              reinterpret_cast<const void*>(&gemm_nt256_kernel<float, __bf16>),
-                              reinterpret_cast<const void*>(&gemm_nt256_kernel<float, float>)};
+        const void* big[6] = {reinterpret_cast<const void*>(&gemm_nt256_kernel<__bf16, __bf16, false>),
+                              reinterpret_cast<const void*>(&gemm_nt256_kernel<__bf16, float, false>),
+                              reinterpret_cast<const void*>(&gemm_nt256_kernel<float, __bf16, false>),
+                              reinterpret_cast<const void*>(&gemm_nt256_kernel<float, float, false>),
+                              reinterpret_cast<const void*>(&gemm_nt256_kernel<float, __bf16, true>),
+                              reinterpret_cast<const void*>(&gemm_nt256_kernel<float, float, true>)};
         for (const void* f : big) {
             const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LSMEM);
             if (e != hipSuccess) err = e;
         }
-        const void* wide[8] = {reinterpret_cast<const void*>(&gemm_nt384_kernel<__bf16, __bf16, false>),
-                               reinterpret_cast<const void*>(&gemm_nt384_kernel<__bf16, float, false>),
-                               reinterpret_cast<const void*>(&gemm_nt384_kernel<float, __bf16, false>),
-                               reinterpret_cast<const void*>(&gemm_nt384_kernel<float, float, false>),
-                               reinterpret_cast<const void*>(&gemm_nt384_kernel<__bf16, __bf16, true>),
-                               reinterpret_cast<const void*>(&gemm_nt384_kernel<__bf16, float, true>),
-                               reinterpret_cast<const void*>(&gemm_nt384_kernel<float, __bf16, true>),
-                               reinterpret_cast<const void*>(&gemm_nt384_kernel<float, float, true>)};
+        const void* wide[12] = {reinterpret_cast<const void*>(&gemm_nt384_kernel<__bf16, __bf16, false, false>),
+                                reinterpret_cast<const void*>(&gemm_nt384_kernel<__bf16, float, false, false>),
+                                reinterpret_cast<const void*>(&gemm_nt384_kernel<float, __bf16, false, false>),
+                                reinterpret_cast<const void*>(&gemm_nt384_kernel<float, float, false, false>),
+                                reinterpret_cast<const void*>(&gemm_nt384_kernel<__bf16, __bf16, true, false>),
+                                reinterpret_cast<const void*>(&gemm_nt384_kernel<__bf16, float, true, false>),
+                                reinterpret_cast<const void*>(&gemm_nt384_kernel<float, __bf16, true, false>),
+                                reinterpret_cast<const void*>(&gemm_nt384_kernel<float, float, true, false>),
+                                reinterpret_cast<const void*>(&gemm_nt384_kernel<float, __bf16, false, true>),
+                                reinterpret_cast<const void*>(&gemm_nt384_kernel<float, float, false, true>),
+                                reinterpret_cast<const void*>(&gemm_nt384_kernel<float, __bf16, true, true>),
+                                reinterpret_cast<const void*>(&gemm_nt384_kernel<float, float, true, true>)};
         for (const void* f : wide) {
             const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, XSMEM);
             if (e != hipSuccess) err = e;
@@ -893,6 +1003,15 @@ int launch(const GemmParams& p, hipStream_t s) {
 }
 
 }  // namespace
+
+namespace {
+std::atomic<int>& f32_exact_mode() {
+    static std::atomic<int> mode([] { const char* e = getenv("WIPA_F32_GEMM"); return (e && !strcmp(e, "exact")) ? 1 : 0; }());
+    return mode;
+}
+}  // namespace
+
+extern "C" int wipa_set_f32_gemm_exact(int on) { return f32_exact_mode().exchange(on ? 1 : 0); }
 
 extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
     WIPA_REQUIRE(d && d->A && d->W && d->C, "wipa_gemm: null operand");
@@ -951,6 +1070,11 @@ extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
                      (!d->residual || ((uintptr_t)d->residual) % 16 == 0);
     }
     hipStream_t s = (hipStream_t)stream;
+    {
+        // f32 inputs in the tile kernels: three bf16 MFMA terms per product (2x the f32-MFMA rate, ~3e-6 relative error)
+        // unless WIPA_F32_GEMM=exact asks for the f32 MFMA.  The weight-streaming kernel (decode steps) stays exact.
+        p.f32_split = (d->in_dtype == WIPA_F32 && !f32_exact_mode().load()) ? 1 : 0;
+    }
     {
         const int rc = init_attrs();
         if (rc != WIPA_OK) return rc;
