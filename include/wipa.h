@@ -101,7 +101,7 @@ int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t s);
  * operands split into hi + lo (a_hi*w_lo + a_lo*w_hi + a_hi*w_hi, f32 accumulation): about twice the rate of the f32 MFMA
  * at ~5e-6 relative error of a K = 768 dot product (the f32 MFMA path itself: ~1.5e-6).  on != 0 selects the f32 MFMA
  * (exact f32 products); the initial mode is "exact" iff the environment has WIPA_F32_GEMM=exact.  Returns the previous mode.
- * Process-wide; set it before launching work.  The weight-streaming kernel of the decode steps always uses the f32 MFMA. */
+ * on < 0 only queries.  Process-wide (it also selects the f32 flash-attention kernel); set it before launching work.  The weight-streaming kernel of the decode steps always uses the f32 MFMA. */
 int wipa_set_f32_gemm_exact(int on);
 
 /* ------------------------------------------------------------------ K3 LayerNorm

@@ -189,9 +189,11 @@ def test_decode_cross_attention_multi_query(dtype, n_q):
 
 
 @pytest.mark.parametrize("T", [1500, 200, 64, 37])
-def test_flash_attention_encoder_f32(ops, T):
-    """f32 MFMA flash attention (the reference's own dtype) against softmax(QK^T)V in float64; ragged last key tile,
-    partial query block, and spiked scores that move the running maximum between tiles."""
+def test_flash_attention_encoder_f32(ops, T, f32_mode):
+    """float32 flash attention (the reference's own dtype) against softmax(QK^T)V in float64; ragged last key tile,
+    partial query block, and spiked scores that move the running maximum between tiles.  Exact mode: f32 MFMA kernel;
+    default: three-term bf16 split of every product (score errors of ~1e-5 relative pass through the exponential)."""
+    tol = 2e-5 if f32_mode == "exact" else 1e-4
     g = torch.Generator().manual_seed(T)
     B, H = 2, 3
     D = H * 64
@@ -205,7 +207,7 @@ def test_flash_attention_encoder_f32(ops, T):
     torch.cuda.synchronize()
     s = torch.einsum("bqhd,bkhd->bhqk", q.double(), k.double())
     ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1), v.double()).reshape(B * T, D).float()
-    assert _rel(out, ref) < 2e-5
+    assert _rel(out, ref) < tol
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -723,6 +723,160 @@ __global__ __launch_bounds__(256, 2) void flash_enc_f32_kernel(const float* __re
     }
 }
 
+// K5 in f32, fast form: every product on the bf16 MFMA (32x32x16) with the f32 operands split in registers.  The scores
+// S^T = K Q^T use THREE terms per operand and the six largest cross products (error ~2^-24: an error eps in a score is a
+// relative error eps*|s| in its probability, and scores can be large); O^T += V^T P^T -- probabilities in [0, 1] against
+// values -- uses two terms per operand and three products, as the f32 tile GEMMs do.  9 bf16 MFMAs replace 16 f32-MFMA
+// equivalents that run 16x slower; the conversions (VALU) set the pace.  K tile [key][64 d], V^T tile [d][64 keys], f32.
+__global__ __launch_bounds__(256, 2) void flash_enc_f32s_kernel(const float* __restrict__ q, int64_t ldq,
+                                                                const float* __restrict__ k, int64_t ldk,
+                                                                const float* __restrict__ v, int64_t ldv,
+                                                                float* __restrict__ out, int64_t ldo, int T) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * FF_TILE];  // [buf][K tile | V^T tile]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int nkt = (T + 63) / 64;
+
+    // Q fragments (B operand): lane (r, hh) holds Q[q0+r][16s + 8hh + 0..7], split once
+    bf16x8 qh[4], qm[4], ql[4];
+    {
+        const float* qp = q + ((int64_t)b * T + min(q0 + r, T - 1)) * ldq + h * 64 + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            split_bf16x3(*reinterpret_cast<const f32x4*>(qp + 16 * s), *reinterpret_cast<const f32x4*>(qp + 16 * s + 4), qh[s], qm[s], ql[s]);
+    }
+    const int krow = tid >> 2, kseg = tid & 3;
+    const int vkey = tid & 63, vseg = tid >> 6;
+    const float* kg = k + (int64_t)b * T * ldk + h * 64 + 16 * kseg;
+    const float* vg = v + (int64_t)b * T * ldv + h * 64 + 16 * vseg;
+    f32x4 rk[4], rv[4];
+    auto gload = [&](int kt) {
+        const float* kp = kg + (int64_t)min(kt * 64 + krow, T - 1) * ldk;
+        const float* vp = vg + (int64_t)min(kt * 64 + vkey, T - 1) * ldv;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            rk[c] = *reinterpret_cast<const f32x4*>(kp + 4 * c);
+            rv[c] = *reinterpret_cast<const f32x4*>(vp + 4 * c);
+        }
+    };
+    auto swrite = [&](int buf) {
+        float* kt = smem + buf * 2 * FF_TILE + krow * FF_LD + 16 * kseg;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(kt + 4 * c) = rk[c];
+        float* vt = smem + buf * 2 * FF_TILE + FF_TILE + (16 * vseg) * FF_LD + vkey;  // V^T[d][key]
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vt[(4 * c + e) * FF_LD] = rv[c][e];
+    };
+
+    f32x16 O[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) O[0][i] = O[1][i] = 0.f;
+    float m = NEG_BIG, l = 0.f;  // m in the log2 domain
+
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) gload(kt + 1);
+        const float* kbuf = smem + (kt & 1) * 2 * FF_TILE;
+        const float* vbuf = kbuf + FF_TILE;
+        f32x16 S[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) S[u][i] = 0.f;
+            const float* kr = kbuf + (32 * u + r) * FF_LD + 8 * hh;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                bf16x8 kh, km, kl;
+                split_bf16x3(*reinterpret_cast<const f32x4*>(kr + 16 * s), *reinterpret_cast<const f32x4*>(kr + 16 * s + 4), kh, km, kl);
+                S[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[s], S[u], 0, 0, 0);  // smallest terms first
+                S[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(km, qm[s], S[u], 0, 0, 0);
+                S[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[s], S[u], 0, 0, 0);
+                S[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(km, qh[s], S[u], 0, 0, 0);
+                S[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qm[s], S[u], 0, 0, 0);
+                S[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[s], S[u], 0, 0, 0);
+            }
+        }
+        if (kt * 64 + 64 > T) {  // ragged last tile: a scalar branch
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kt * 64 + 32 * u + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    if (key >= T) S[u][i] = NEG_BIG;
+                }
+        }
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, S[u][i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m, mx * LOG2E);
+        f32x2 psum2 = {0.f, 0.f};
+        const f32x2 l2e = {LOG2E, LOG2E}, mneg = {-m_new, -m_new};
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                const f32x2 x = __builtin_elementwise_fma(f32x2{S[u][i], S[u][i + 1]}, l2e, mneg);
+                const f32x2 pv = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+                S[u][i] = pv.x;
+                S[u][i + 1] = pv.y;
+                psum2 += pv;
+            }
+        if (__any(m_new > m)) {
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+            l *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                O[0][i] *= alpha;
+                O[1][i] *= alpha;
+            }
+            m = m_new;
+        }
+        l += psum2.x + psum2.y;
+        // O^T += V^T P^T; MFMA k slot j of half hh is key 16 sp + 8 (j>>2) + 4 hh + (j&3) of the 32-key block u
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                bf16x8 ph, pl;
+                split_bf16x2(f32x4{S[u][8 * sp], S[u][8 * sp + 1], S[u][8 * sp + 2], S[u][8 * sp + 3]},
+                             f32x4{S[u][8 * sp + 4], S[u][8 * sp + 5], S[u][8 * sp + 6], S[u][8 * sp + 7]}, ph, pl);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const float* vr = vbuf + (32 * dt + r) * FF_LD + 32 * u + 16 * sp + 4 * hh;
+                    bf16x8 vh, vl;
+                    split_bf16x2(*reinterpret_cast<const f32x4*>(vr), *reinterpret_cast<const f32x4*>(vr + 8), vh, vl);
+                    O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, O[dt], 0, 0, 0);
+                    O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, O[dt], 0, 0, 0);
+                    O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, O[dt], 0, 0, 0);
+                }
+            }
+        if (kt + 1 < nkt) swrite((kt + 1) & 1);
+        __syncthreads();
+    }
+    l += __shfl_xor(l, 32, 64);
+    const int qrow = q0 + r;
+    if (qrow < T) {
+        const float inv = 1.f / l;
+        float* op = out + ((int64_t)b * T + qrow) * ldo + h * 64 + 4 * hh;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                *reinterpret_cast<f32x4*>(op + 32 * dt + 8 * g4) =
+                    f32x4{O[dt][4 * g4] * inv, O[dt][4 * g4 + 1] * inv, O[dt][4 * g4 + 2] * inv, O[dt][4 * g4 + 3] * inv};
+    }
+}
+
 }  // namespace
 
 extern "C" int wipa_attention(const wipa_attn_desc* d, wipa_stream_t stream) {
@@ -780,7 +934,11 @@ extern "C" int wipa_flash_attn_enc_f32(const float* q, int64_t ldq, const float*
                  "wipa_flash_attn_enc_f32: operands must be 16-byte aligned");
     WIPA_REQUIRE(B > 0 && H > 0 && T > 0, "wipa_flash_attn_enc_f32: bad shape");
     dim3 grid((T + 127) / 128, H, B);
-    hipLaunchKernelGGL(flash_enc_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, ldq, k, ldk, v, ldv, out, ldo, T);
+    // three-term bf16 split unless the process asked for exact f32 products (wipa_set_f32_gemm_exact / WIPA_F32_GEMM=exact)
+    if (wipa_set_f32_gemm_exact(-1))
+        hipLaunchKernelGGL(flash_enc_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, ldq, k, ldk, v, ldv, out, ldo, T);
+    else
+        hipLaunchKernelGGL(flash_enc_f32s_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, ldq, k, ldk, v, ldv, out, ldo, T);
     WIPA_LAUNCH_CHECK();
     return WIPA_OK;
 }

@@ -63,20 +63,6 @@ struct Mma<float> {
     }
 };
 
-// f32 operands as two bf16 terms: x = hi + lo + O(2^-17 |x|).  Eight consecutive-in-k floats of a lane (two 16-byte LDS
-// chunks) become the hi and lo fragments of one bf16 MFMA K-step; a product a*w is then taken as
-// a_hi*w_lo + a_lo*w_hi + a_hi*w_hi (the dropped a_lo*w_lo and the representation residuals are ~2^-16 relative), each
-// term accumulated in f32 by the matrix pipe at 16x the rate of the f32 MFMA.
-__device__ __forceinline__ void split_bf16x2(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
-    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const __bf16 h = (__bf16)x[e];
-        hi[e] = h;
-        lo[e] = (__bf16)(x[e] - (float)h);
-    }
-}
-
 template <typename OutT>
 __device__ __forceinline__ void store4(char* C, int64_t off, const float (&v)[4], int nvalid, bool vec) {
     OutT* p = reinterpret_cast<OutT*>(C) + off;
@@ -1011,7 +997,7 @@ std::atomic<int>& f32_exact_mode() {
 }
 }  // namespace
 
-extern "C" int wipa_set_f32_gemm_exact(int on) { return f32_exact_mode().exchange(on ? 1 : 0); }
+extern "C" int wipa_set_f32_gemm_exact(int on) { return on < 0 ? f32_exact_mode().load() : f32_exact_mode().exchange(on ? 1 : 0); }
 
 extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
     WIPA_REQUIRE(d && d->A && d->W && d->C, "wipa_gemm: null operand");

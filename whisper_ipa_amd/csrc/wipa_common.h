@@ -126,4 +126,34 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
     const f32x2 e = {__builtin_amdgcn_exp2f(-s2.x), __builtin_amdgcn_exp2f(-s2.y)};
     return __builtin_elementwise_fma(-ax, p * e, __builtin_elementwise_max(x, f32x2{0.f, 0.f}));
 }
+// f32 operands as two bf16 terms: x = hi + lo + O(2^-17 |x|).  Eight consecutive-in-k floats of a lane (two 16-byte LDS
+// chunks) become the hi and lo fragments of one bf16 MFMA K-step; a product a*w is then taken as
+// a_hi*w_lo + a_lo*w_hi + a_hi*w_hi (the dropped a_lo*w_lo and the representation residuals are ~2^-16 relative), each
+// term accumulated in f32 by the matrix pipe at 16x the rate of the f32 MFMA.
+__device__ __forceinline__ void split_bf16x2(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 h = (__bf16)x[e];
+        hi[e] = h;
+        lo[e] = (__bf16)(x[e] - (float)h);
+    }
+}
+
+
+// Three bf16 terms: x = hi + mid + lo + O(2^-25 |x|) -- f32-exact for practical purposes (used where a product feeds an
+// exponential: attention scores).
+__device__ __forceinline__ void split_bf16x3(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 h = (__bf16)x[e];
+        const float r1 = x[e] - (float)h;
+        const __bf16 m = (__bf16)r1;
+        hi[e] = h;
+        mid[e] = m;
+        lo[e] = (__bf16)(r1 - (float)m);
+    }
+}
+
 #endif
