@@ -818,22 +818,45 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
+        if constexpr (SPLIT && sizeof(T) == 4) {
+            // The stage is converted ONCE, in place, by all 512 threads: every 16-byte chunk of four floats becomes
+            // [h0 h1 h2 h3 | l0 l1 l2 l3] (bf16), so the eight waves no longer repeat the hi/lo split of the rows they share
+            // and a fragment is put together from the dwords of two chunks without any arithmetic.
+            char* st = smem + (kt & 1) * XSTAGE;
+#pragma unroll
+            for (int i = 0; i < XSTAGE / 16 / 512; ++i) {
+                f32x4* cp = reinterpret_cast<f32x4*>(st + (tid + 512 * i) * 16);
+                const f32x4 x = *cp;
+                bf16x8 hl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const __bf16 hbits = (__bf16)x[e];
+                    hl[e] = hbits;
+                    hl[4 + e] = (__bf16)(x[e] - (float)hbits);
+                }
+                *reinterpret_cast<bf16x8*>(cp) = hl;
+            }
+            __syncthreads();
+        }
         if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
         const char* wb = smem + (kt & 1) * XSTAGE + (wn * 64 + frow) * ROWB;
         const char* ab = smem + (kt & 1) * XSTAGE + XW_TILE + (wm * 192 + frow) * ROWB;
         if constexpr (SPLIT && sizeof(T) == 4) {
             // one bf16 MFMA K-step per stage: the lane's floats 4fq..4fq+3 and 16+4fq..19+4fq of every row
             const int c0 = (fq ^ fsw) << 4, c1 = ((fq + 4) ^ fsw) << 4;
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            auto frag = [&](const char* row, bf16x8& hi, bf16x8& lo) {
+                const u32x4 a = *reinterpret_cast<const u32x4*>(row + c0), b = *reinterpret_cast<const u32x4*>(row + c1);
+                hi = __builtin_bit_cast(bf16x8, u32x4{a[0], a[1], b[0], b[1]});
+                lo = __builtin_bit_cast(bf16x8, u32x4{a[2], a[3], b[2], b[3]});
+            };
             bf16x8 wh[4], wl[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                split_bf16x2(*reinterpret_cast<const f32x4*>(wb + i * 16 * ROWB + c0), *reinterpret_cast<const f32x4*>(wb + i * 16 * ROWB + c1),
-                             wh[i], wl[i]);
+            for (int i = 0; i < 4; ++i) frag(wb + i * 16 * ROWB, wh[i], wl[i]);
 #pragma unroll
             for (int j = 0; j < 12; ++j) {
                 bf16x8 xh, xl;
-                split_bf16x2(*reinterpret_cast<const f32x4*>(ab + j * 16 * ROWB + c0), *reinterpret_cast<const f32x4*>(ab + j * 16 * ROWB + c1),
-                             xh, xl);
+                frag(ab + j * 16 * ROWB, xh, xl);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xl, acc[i][j], 0, 0, 0);
