@@ -160,10 +160,6 @@ def one_pass(model, audio_chunks, setup):
     log-mel -> encoder -> cross-KV -> decode loop are enqueued asynchronously per sub-batch, so the
     MFMA-bound encoder of one sub-batch overlaps the HBM/latency-bound decode loop of another.
     Returns the token matrix of the whole batch (host), i.e. the pass ends when all ids are on the host."""
-    from whisper_ipa_amd import audio as A
-    from whisper_ipa_amd.decoding import greedy_collect, greedy_launch
-    from whisper_ipa_amd.runtime import use_stream
-
     return pass_collect(pass_launch(model, audio_chunks, setup, 0))
 
 
