@@ -14,9 +14,19 @@ separate HIP streams with separate workspaces / KV caches, each doing ALL of its
 timed region, so the encoder of one batch overlaps the decode loop of the previous one
 (`ms_per_step` = timed wall time / steps, i.e. the steady-state time per 64-clip batch).
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed on the launch
-stream) and `cpu_baseline` (the CPU oracle = a port, timed on this box's host cores on a
-bounded sample, rank 0 at N=1 only).
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment makes this process a LAUNCHER: it starts N rank processes
+(one per GPU, RCCL rendezvous on 127.0.0.1) without touching the GPU itself and relays rank 0's JSON line.  Under
+`torch.distributed.run` (WORLD_SIZE set) it is a rank and WORLD_SIZE must equal --gpus.
+
+Prints ONE JSON line (rank 0) with
+  `roofline`       dominant HBM-bound kernel (decode-step cross-attention), HIP-event timed on its launch stream;
+  `roofline_mfma`  the encoder + cross-K/V GEMM set (19.4 TFLOP algorithmic per 64-clip pass) against the dense bf16 MFMA
+                   peak, from HIP events around every GEMM launch of a real pass (wipa_profile_begin/end);
+  `decode_step`    one whole decode step (graph replay, ONE pass in flight) against the HBM peak: SURVEY section 8d bytes
+                   (B x cross-K/V + self-K/V + decoder weights) / event-timed step;
+  `parity_vs_cpu`  token ids of clips 0..7 against the CPU oracle's ids for the same weights and clips;
+  `cpu_baseline`   the CPU oracle (a port) timed on this box's host cores on a bounded sample (rank 0, N = 1 only).
+`--mode train` times the decoder fine-tune step instead (one rank's share of BASELINE.json configs[2]).
 """
 from __future__ import annotations
 
@@ -138,10 +148,12 @@ def synthetic_weights_small(seed: int = 0, name: str = "small"):
 
 
 def synthetic_audio(first_clip: int, n: int) -> np.ndarray:
-    """default_rng(1234 + clip), 0.1 * N(0,1) f32, 480 000 samples."""
+    """default_rng(1234 + clip), 0.1 * N(0,1), 480 000 samples, stored as f32 -- sample for sample
+    the clips the CPU oracle generates (oracle.whisper_ref.synthetic_clip; tests/test_host_logic.py checks the equality),
+    so `parity_vs_cpu` compares like with like."""
     out = np.empty((n, 480000), dtype=np.float32)
     for i in range(n):
-        out[i] = 0.1 * np.random.default_rng(1234 + first_clip + i).standard_normal(480000, dtype=np.float32)
+        out[i] = (0.1 * np.random.default_rng(1234 + first_clip + i).standard_normal(480000)).astype(np.float32)
     return out
 
 
@@ -260,9 +272,103 @@ def roofline_cross_attn(model, B: int, iters: int = 48):
             "algorithmic_bytes_per_launch": bytes_alg, "avg_launch_ms": round(ms, 5)}
 
 
+def roofline_mfma(model, audio, pmc_file: str = "r02_pmc_encoder_gemm.json"):
+    """The MFMA-bound kernel set: every GEMM / conv-as-GEMM of one encoder pass plus the cross-K/V projection.
+    Algorithmic FLOPs per clip are SURVEY.md App. B's (whisper-small: 261.2 + 42.5 GFLOP); the time is the sum of HIP-event
+    spans around each GEMM launch of a real pass on the library stream (wipa_profile_begin / wipa_profile_end)."""
+    import ctypes as C
+
+    from whisper_ipa_amd import _lib, audio as A
+    from whisper_ipa_amd.decoding import _state_for
+    from whisper_ipa_amd.runtime import on_stream, ptr, sptr
+
+    d = model.dims
+    B, Ta, de, dd = audio.shape[0], d.n_audio_ctx, d.n_audio_state, d.n_text_state
+    # 2*M*N*K of: conv1 (K = 3 n_mels, 3000 frames), conv2 (K = 3 d, 1500 frames), per layer q,k,v,out (4 d^2) + MLP (8 d^2),
+    # and the decoder's cross key / value projections of the encoder output (2 d^2 per decoder layer)
+    enc = 2.0 * (3000 * de * 3 * d.n_mels + Ta * de * 3 * de + d.n_audio_layer * Ta * 12 * de * de)
+    ckv = 2.0 * d.n_text_layer * Ta * 2 * dd * dd
+    flops = B * (enc + ckv)
+    L = _lib.lib()
+    pk = model.packed()
+    ms = (C.c_float * 4)()
+    cnt = (C.c_int * 4)()
+    best = None
+    for _ in range(3):
+        with on_stream() as s:
+            st = _state_for(model, B)
+            _lib.check(L.wipa_profile_begin(sptr(s)), "wipa_profile_begin")
+            try:
+                mel = A.log_mel_padded(audio, d.n_mels, model.dtype)
+                feats = model.encode_padded(mel, B)
+                _lib.check(L.wipa_decoder_set_audio(C.byref(pk["cfg"]), pk["dec_tab"], ptr(feats), ptr(st.blob), B, sptr(s)),
+                           "wipa_decoder_set_audio")
+            finally:
+                _lib.check(L.wipa_profile_end(ms, cnt), "wipa_profile_end")
+        if best is None or ms[0] < best[0]:
+            best = (float(ms[0]), int(cnt[0]), float(ms[1]), float(ms[2]))
+    gemm_ms, n_gemm, attn_ms, norm_ms = best
+    achieved = flops / (gemm_ms * 1e-3) / 1e12
+    attn_flops = B * d.n_audio_layer * 4.0 * Ta * Ta * de
+    out = {"kernel": "gemm_nt384/gemm_nt256 (encoder GEMM + conv + cross-K/V projection set)", "bound": "mfma",
+           "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "algorithmic_tflop_per_pass": round(flops / 1e12, 3),
+           "gemm_ms_per_pass": round(gemm_ms, 3), "gemm_launches": n_gemm,
+           "flash_attention": {"ms_per_pass": round(attn_ms, 3), "achieved": round(attn_flops / (attn_ms * 1e-3) / 1e12, 1),
+                               "frac": round(attn_flops / (attn_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)},
+           "layernorm_ms_per_pass": round(norm_ms, 3), "mfma_busy_pmc": None}
+    try:  # SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE per GEMM shape, separate rocprofv3 --pmc passes (profiles/)
+        out["mfma_busy_pmc"] = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
+    except Exception:
+        pass
+    return out
+
+
+def decode_step_roofline(model, B: int, n_steps: int = 48):
+    """One WHOLE decode step (all layers + logits + greedy update: the captured hipGraph the decode loop replays) with one
+    pass in flight, against the HBM peak.  Bytes per step as SURVEY.md section 8d counts them: B x cross-K/V (every cached
+    key and value once) + B x self-K/V of the positions filled so far + the decoder weights once."""
+    import ctypes as C
+
+    from whisper_ipa_amd import _lib
+    from whisper_ipa_amd.decoding import _mask, _state_for
+    from whisper_ipa_amd.runtime import on_stream, ptr, sptr
+
+    L = _lib.lib()
+    pk = model.packed()
+    d = model.dims
+    e = 2 if model.dtype == torch.bfloat16 else 4
+    init, always, first, eot = decode_setup()
+    m_always, m_first = _mask(model, always), _mask(model, list(always) + list(first))
+    with on_stream() as s:
+        st = _state_for(model, B)  # holds the caches of the last pass on library stream 0
+        p0 = int(st.pos.cpu())
+        n_steps = max(1, min(n_steps, d.n_text_ctx - 2 - p0))
+        args = (C.byref(pk["cfg"]), pk["dec_tab"], ptr(st.blob), B, len(init), eot, ptr(m_first), ptr(m_always))
+        _lib.check(L.wipa_decoder_run(*args, 2, 1, sptr(s)), "wipa_decoder_run")
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(s)
+        _lib.check(L.wipa_decoder_run(*args, n_steps, 1, sptr(s)), "wipa_decoder_run")
+        ev1.record(s)
+        ev1.synchronize()
+    ms = ev0.elapsed_time(ev1) / n_steps
+    t_mean = p0 + 2 + n_steps / 2.0
+    dd, Ld = d.n_text_state, d.n_text_layer
+    cross = B * Ld * 2 * d.n_audio_ctx * dd * e
+    self_kv = B * Ld * 2 * t_mean * dd * e
+    dec_params = d.n_vocab * dd + d.n_text_ctx * dd + Ld * (4 * dd * dd + 4 * dd * dd + 8 * dd * dd) + Ld * 11 * dd + 2 * dd
+    weights = dec_params * e
+    total = cross + self_kv + weights
+    achieved = total / (ms * 1e-3) / 1e9
+    return {"what": "one decode step, hipGraph replay, one pass in flight", "bound": "hbm", "ms_per_step": round(ms, 4),
+            "bytes_per_step": int(total), "cross_kv_bytes": int(cross), "self_kv_bytes": int(self_kv), "weight_bytes": int(weights),
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4)}
+
+
 def cpu_baseline(n_clips: int = 1):
     """The CPU oracle (a torch-CPU port of the reference semantics; the reference's own MLX path
-    cannot run here) on a bounded sample of the same workload: n_clips clips, full pipeline."""
+    cannot run here) on a bounded sample of the same workload: n_clips clips, full pipeline.
+    Returns (baseline dict, the oracle's GreedyResult) -- the ids feed `parity_vs_cpu`."""
     from oracle import whisper_ref as R
 
     cores = host_cores()
@@ -276,11 +382,196 @@ def cpu_baseline(n_clips: int = 1):
     with torch.no_grad():
         mels = np.stack([R.log_mel_spectrogram(a) for a in audio])
         xa = R.encoder_forward(W, dims, torch.from_numpy(mels))
-        R.greedy_decode(W, dims, xa, sp.sot_sequence_including_notimestamps(0), always, first, sp.eot,
-                        sample_len=NEW_TOKENS, stop_on_eot=False)
+        ref = R.greedy_decode(W, dims, xa, sp.sot_sequence_including_notimestamps(0), always, first, sp.eot,
+                              sample_len=NEW_TOKENS, stop_on_eot=False)
     dt = time.time() - t0
     return {"value": round(n_clips * 30.0 / dt, 2), "unit": "audio-s/s", "cores": cores, "kind": "port",
-            "sample": f"{n_clips} clip(s) x 30 s, whisper-small fp32, mel+encoder+{NEW_TOKENS} greedy steps, torch-CPU oracle, {dt:.1f} s"}
+            "sample": f"{n_clips} clip(s) x 30 s, whisper-small fp32, mel+encoder+{NEW_TOKENS} greedy steps, torch-CPU oracle, {dt:.1f} s"}, ref
+
+
+def parity_vs_cpu(gpu_tokens: np.ndarray, ref, n_init: int):
+    """The bench's own token ids (bf16 on the GPU) against the CPU oracle's (f32) for the same clips and weights:
+    overall match rate, the matching prefix (ids after a row's first divergence follow another history), and per clip the
+    first differing step with the oracle's top-1 margin at that step (near-ties are where bf16 and f32 may part)."""
+    n = ref.tokens.shape[0]
+    got, want = gpu_tokens[:n, n_init:], ref.tokens[:, n_init:]
+    steps = min(got.shape[1], want.shape[1])
+    eq = got[:, :steps] == want[:, :steps]
+    firsts, prefix = [], 0
+    for b in range(n):
+        bad = np.flatnonzero(~eq[b])
+        if bad.size:
+            firsts.append({"clip": b, "step": int(bad[0]), "oracle_margin": round(float(ref.margins[b, bad[0]]), 5)})
+            prefix += int(bad[0])
+        else:
+            prefix += steps
+    return {"clips": int(n), "steps": int(steps), "token_match": round(float(eq.mean()), 4),
+            "prefix_match": round(prefix / float(eq.size), 4), "rows_identical": int(eq.all(axis=1).sum()),
+            "first_divergence": firsts, "oracle_median_margin": round(float(np.median(ref.margins)), 4),
+            "note": "GPU path bf16 vs CPU oracle f32; the f32 GPU path is bit-exact at this depth (tests/test_gpu_full_depth.py)"}
+
+
+# --------------------------------------------------------------------------------------------------------- multi-rank
+def launch_ranks(n: int, argv) -> int:
+    """--gpus N without a launcher: start N rank processes of this script (one per GPU) and relay rank 0's stdout.
+    This parent never initialises HIP (children are fresh processes, no exec after GPU init anywhere)."""
+    import socket
+    import subprocess
+
+    n_dev = torch.cuda.device_count()  # does not initialise the runtime
+    share = os.environ.get("WIPA_BENCH_SHARE_GPU") == "1"
+    if n_dev < n and not share:
+        print(f"bench.py: --gpus {n} but only {n_dev} GPU(s) visible (WIPA_BENCH_SHARE_GPU=1 rehearses on one GPU over gloo)",
+              file=sys.stderr)
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+def init_ranks(args):
+    """(rank, world, dist-or-None, device index).  Asserts that the world is what --gpus says and, on real multi-GPU
+    runs, that every rank sits on its own device."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}: launch with --nproc-per-node {args.gpus}"
+    # Rehearsal on a one-GPU box: WIPA_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo for the timing
+    # collectives (RCCL refuses two ranks on one device); real runs use one GPU per rank and RCCL.
+    share_gpu = os.environ.get("WIPA_BENCH_SHARE_GPU") == "1"
+    device_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(device_index)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+        assert dist.get_world_size() == args.gpus
+        if not share_gpu:
+            ids = [None] * world
+            props = torch.cuda.get_device_properties(device_index)
+            dist.all_gather_object(ids, (os.uname().nodename, device_index, str(getattr(props, "uuid", ""))))
+            assert len(set(ids)) == world, f"ranks share a device: {ids}"
+    return rank, world, dist, device_index
+
+
+def timed_barrier(dist):
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(dist, elapsed: float) -> float:
+    if dist is None:
+        return elapsed
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+# --------------------------------------------------------------------------------------------------------- fine-tune
+def run_train(args):
+    """--mode train: the step the reference times (scripts/train_whisper_ipa.py:552-555 -> train_step :266-311): frozen
+    encoder forward, teacher-forced decoder, masked CE, backward w.r.t. the decoder, per-tensor clip, AdamW -- float32 as
+    the reference trains (:505), one rank's share of BASELINE.json configs[2] (32 clips, 64 target tokens) per GPU; under
+    N > 1 the decoder gradients (614 MB) are all-reduced per block over RCCL, overlapped with the backward."""
+    rank, world, dist, _ = init_ranks(args)
+    from whisper_ipa_amd.training import DecoderTrainer
+    from whisper_ipa_amd.whisper import Whisper
+
+    B, T = args.train_batch, args.train_tokens
+    dims, W = synthetic_weights_small(0, args.model)
+    model = Whisper(dims, dtype=torch.float32, f32_split=(args.f32 == "split"))
+    model.load_weights(W)
+    del W
+    tr = DecoderTrainer(model, lr=1e-5)
+    g = torch.Generator().manual_seed(1000 + rank)
+    mel = (torch.randn(B, 3000, dims.n_mels, generator=g) * 0.5).cuda()
+    eot = 50257
+    tok = torch.randint(0, 50000, (B, T + 1), generator=g)
+    tok[:, :4] = torch.tensor([50258, 50259, 50359, 50363])
+    for b in range(B):  # ragged targets: EOT-padded tails like ipa_data_loader.py:124-131
+        tok[b, T + 1 - (b % 9):] = eot
+    tok[:, -1] = eot
+    tok = tok.cuda()
+    log(f"train: rank {rank}/{world}, {B} clips x {T} target tokens, f32 products: {args.f32}")
+    for _ in range(max(1, args.warmup)):
+        loss, _ = tr.train_step(mel, tok, eot)
+    timed_barrier(dist)
+    t0 = time.perf_counter()
+    exposed = 0.0
+    for _ in range(args.steps):
+        loss, _ = tr.train_step(mel, tok, eot)
+        exposed += tr.last_allreduce_exposed_ms
+    timed_barrier(dist)
+    elapsed = max_over_ranks(dist, time.perf_counter() - t0)
+    # stage split (rank 0, after the timed region): encoder / loss+grads / update, median of 3
+    stages = {}
+    if rank == 0 or dist is not None:
+        for name in ("encoder", "loss_and_grads", "update"):
+            ts = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                if name == "encoder":
+                    feats = model.embed_audio(mel)
+                elif name == "loss_and_grads":
+                    tr.loss_and_grads(feats, tok, eot)
+                else:
+                    tr.apply_update()
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t1) * 1e3)
+            stages[name + "_ms"] = round(sorted(ts)[1], 2)
+    if rank == 0:
+        d, L, V, Ta = dims.n_text_state, dims.n_text_layer, dims.n_vocab, dims.n_audio_ctx
+        M = B * T
+        # dense contractions of the step: decoder fwd + dgrad + wgrad (3x) on M token rows, cross K/V projection fwd + wgrad
+        # (2x, no dgrad: the encoder is frozen) on B*1500 rows, logits 3x; encoder forward once
+        dec = 3 * 2.0 * M * L * (4 * d * d + 2 * d * d + 8 * d * d) + 3 * 2.0 * M * V * d
+        ckv = 2 * 2.0 * B * Ta * L * 2 * d * d
+        de = dims.n_audio_state
+        enc = B * (2.0 * (3000 * de * 3 * dims.n_mels + Ta * de * 3 * de + dims.n_audio_layer * Ta * 12 * de * de)
+                   + dims.n_audio_layer * 4.0 * Ta * Ta * de)
+        f32_peak = 157.3  # TFLOP/s, f32 MFMA (MI355X_MICROARCH.md)
+        ms = 1000.0 * elapsed / args.steps
+        out = {
+            "metric": f"fine-tune clips/sec (whisper-{args.model} decoder-only, f32, {B} clips x {T} tokens per GPU)",
+            "value": round(world * B * args.steps / elapsed, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": f"synthetic (seeded mel + token rows, random-init whisper-{args.model} weights)",
+            "config": {"workload": f"whisper-{args.model} decoder fine-tune step (frozen encoder fwd + decoder fwd/bwd + masked CE + "
+                                   f"per-tensor clip + AdamW), {B} clips x 30 s, {T} target tokens per GPU",
+                       "clips_per_gpu": B, "target_tokens": T, "f32_products": args.f32,
+                       "parallelism": f"dp{world} (per-block async all-reduce of 614 MB decoder gradients)" if world > 1 else "dp1"},
+            "loss": round(float(loss), 4),
+            "stages": stages,
+            "roofline": {"kernel": "f32 GEMM set of the step (decoder fwd/dgrad/wgrad + cross-K/V + encoder)", "bound": "mfma",
+                         "achieved": round((dec + ckv + enc) / (ms * 1e-3) / 1e12, 1), "peak": f32_peak, "unit": "TFLOP/s",
+                         "frac": round((dec + ckv + enc) / (ms * 1e-3) / 1e12 / f32_peak, 4), "traffic": None,
+                         "note": "whole-step FLOPs / whole-step time (includes attention backward, CE, optimiser); f32 MFMA peak"},
+            "allreduce_exposed_ms_per_step": round(exposed / args.steps, 3) if world > 1 else 0.0,
+            "grad_bytes": tr.n_params * 4,
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -288,6 +579,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+                    help="infer: the headline metric (BASELINE.json); train: the decoder fine-tune step (configs[2] share)")
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--streams", type=int, default=N_STREAMS, help="clip sub-batches run on this many HIP streams")
     ap.add_argument("--pipeline", type=int, default=N_PIPELINE, help="consecutive passes kept in flight on separate HIP streams")
@@ -298,26 +591,18 @@ def main():
                     help="sizing runs only: the benchmark metric is quoted in bf16 (f32 is what the reference's scripts set)")
     ap.add_argument("--model", default="small", choices=["tiny", "base", "small", "medium", "large-v3"],
                     help="sizing runs only: the benchmark metric is quoted on whisper-small")
+    ap.add_argument("--f32", default="exact", choices=["exact", "split"],
+                    help="float32 runs: exact f32 MFMA products (default, as the reference computes) or the split-bf16 opt-in")
+    ap.add_argument("--train-batch", type=int, default=32)
+    ap.add_argument("--train-tokens", type=int, default=64)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     torch.set_num_threads(host_cores())
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    # Rehearsal on a one-GPU box: WIPA_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo for the two timing
-    # collectives (RCCL refuses two ranks on one device); the driver's real runs use one GPU per rank and RCCL.
-    share_gpu = os.environ.get("WIPA_BENCH_SHARE_GPU") == "1"
-    device_index = 0 if share_gpu else local_rank
-    torch.cuda.set_device(device_index)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist  # RCCL: only for the timing barrier / max-reduce
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+    if args.mode == "train":
+        return run_train(args)
+    rank, world, dist, device_index = init_ranks(args)
 
     from whisper_ipa_amd.whisper import Whisper
 
@@ -325,7 +610,7 @@ def main():
     log(f"start: rank {rank}/{world}, host cores {host_cores()}")
     dims, W = synthetic_weights_small(0, args.model)
     log("weights generated")
-    model = Whisper(dims, dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    model = Whisper(dims, dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32, f32_split=(args.f32 == "split"))
     model.load_weights(W)
     del W
     audio_dev = torch.from_numpy(synthetic_audio(rank * B, B)).cuda()
@@ -343,10 +628,7 @@ def main():
                 pass_collect(pass_launch(model, audio_chunks, setup, pset * args.streams))
         torch.cuda.synchronize()
         log(f"warmup pass {i} done")
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+    timed_barrier(dist)
     t0 = time.perf_counter()
     # --pipeline P > 1: pass i runs on stream set (i % P) and is only collected when its stream set is needed
     # again, so the encoder of pass i+1 can overlap the decode loop of pass i (each pass still does all its work
@@ -368,15 +650,8 @@ def main():
             inflight.append(pass_launch(model, audio_chunks, setup, (i % args.pipeline) * args.streams))
     while inflight:
         tokens = pass_collect(inflight.pop(0))
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    timed_barrier(dist)
+    elapsed = max_over_ranks(dist, time.perf_counter() - t0)
 
     out = None
     if rank == 0:
@@ -402,11 +677,22 @@ def main():
             "tokens_checksum": int(tokens.sum() % 1000003),
         }
         log(f"timed region done: {elapsed:.3f} s for {args.steps} passes")
+        # ---- everything below is OUTSIDE the timed region, one pass in flight
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        single = one_pass(model, audio_chunks, setup)
+        out["ms_per_pass_single_in_flight"] = round((time.perf_counter() - t1) * 1e3, 2)
+        assert args.decode_group > 1 or (single == tokens).all(), "the pipelined and the single pass disagree on the ids"
         out["roofline"] = roofline_cross_attn(model, audio_chunks[0].shape[0])
-        log("roofline microbench done")
-        if world == 1 and not args.no_cpu_baseline and args.model == "small":
-            out["cpu_baseline"] = cpu_baseline(8)  # ~20 s of host work
-            log("cpu baseline done")
+        if args.streams == 1:
+            out["decode_step"] = decode_step_roofline(model, audio_chunks[0].shape[0])
+            if args.dtype == "bf16":
+                out["roofline_mfma"] = roofline_mfma(model, audio_chunks[0])
+        log("roofline microbenches done")
+        if world == 1 and not args.no_cpu_baseline and args.model == "small" and B >= 8:
+            out["cpu_baseline"], ref = cpu_baseline(8)  # ~25 s of host work
+            out["parity_vs_cpu"] = parity_vs_cpu(single, ref, len(setup[0]))
+            log("cpu baseline + parity done")
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

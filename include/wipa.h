@@ -92,17 +92,15 @@ typedef struct wipa_gemm_desc {
                        * slice 0 only, no act/pos/residual) to C + z*slab_stride -- to be summed in a
                        * fixed order by wipa_add_slabs_layernorm or wipa_sum_slabs (deterministic split-K).  M <= 1024
                        * runs in the weight-streaming kernel, larger M in the 128x128 tile kernel. */
+    int32_t f32_split; /* float32 inputs in the tile kernels (M > 256 rows).  0 (default): exact f32 products on the f32 MFMA.
+                        * 1: every product a*w is taken as three bf16 MFMA terms on operands split into hi + lo
+                        * (a_hi*w_lo + a_lo*w_hi + a_hi*w_hi, f32 accumulation): about twice the rate at ~5e-6 relative error
+                        * of a K = 768 dot product (f32 MFMA: ~1.5e-6).  The weight-streaming kernel always multiplies exactly. */
     int32_t stream_weights; /* 1: the rows are decode rows (one or a few per clip) and W is a weight matrix: use the
                              * weight-streaming kernel up to M = 1024 instead of 256, so that a prompt prefill of
                              * 4 rows per clip rounds exactly like the single-row steps (batch invariance) */
 } wipa_gemm_desc;
 int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t s);
-/* float32 inputs in the tile kernels (M > 256 rows): by default every product a*w is taken as three bf16 MFMA terms on
- * operands split into hi + lo (a_hi*w_lo + a_lo*w_hi + a_hi*w_hi, f32 accumulation): about twice the rate of the f32 MFMA
- * at ~5e-6 relative error of a K = 768 dot product (the f32 MFMA path itself: ~1.5e-6).  on != 0 selects the f32 MFMA
- * (exact f32 products); the initial mode is "exact" iff the environment has WIPA_F32_GEMM=exact.  Returns the previous mode.
- * on < 0 only queries.  Process-wide (it also selects the f32 flash-attention kernel); set it before launching work.  The weight-streaming kernel of the decode steps always uses the f32 MFMA. */
-int wipa_set_f32_gemm_exact(int on);
 
 /* ------------------------------------------------------------------ K3 LayerNorm
  * nn.LayerNorm(eps=1e-5) rows of width D (attn_ln, cross_attn_ln, mlp_ln, ln_post, ln). */
@@ -155,9 +153,11 @@ int wipa_flash_attn_enc_bf16(const void* qk, int64_t ldqk, const void* vt, int64
                              int B, int H, int T, wipa_stream_t s);
 /* K5 in f32: the same encoder attention on the f32 MFMA (exact f32 products) for models kept in float32, as the
  * reference's scripts do (transcribe_single.py:13, train_whisper_ipa.py:505).  q, k, v: [B*T, ld*] f32 with head h at
- * column h*64 (q and k pre-scaled by 64^-0.25 each); out [B*T, ldo].  Row strides multiples of 4, pointers 16-byte aligned. */
+ * column h*64 (q and k pre-scaled by 64^-0.25 each); out [B*T, ldo].  Row strides multiples of 4, pointers 16-byte aligned.
+ * f32_split != 0: scores on a three-way and P*V on a two-way bf16 split of the operands (bf16 MFMA, error ~2^-24 of a
+ * score) instead of exact f32 products -- the same opt-in as wipa_gemm_desc.f32_split. */
 int wipa_flash_attn_enc_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, float* out,
-                            int64_t ldo, int B, int H, int T, wipa_stream_t s);
+                            int64_t ldo, int B, int H, int T, int f32_split, wipa_stream_t s);
 
 /* K11/K12 decode-step attention (HBM-bound): ONE query row per (b,h) (Tq must be 1) against
  * cached K/V with the strides of wipa_attn_desc; 8 (bf16) / 16 (f32) lanes stream one 64-dim key
@@ -193,7 +193,10 @@ typedef struct wipa_model_cfg {
     int32_t n_mels, n_audio_ctx, n_audio_state, n_audio_head, n_audio_layer;
     int32_t n_vocab, n_text_ctx, n_text_state, n_text_head, n_text_layer;
     int32_t dtype; /* WIPA_F32 or WIPA_BF16: matrices, activations, KV caches */
-    int32_t reserved;
+    int32_t f32_split; /* dtype == WIPA_F32 only: 1 lets the encoder / teacher-forced GEMMs and the encoder flash attention
+                        * use split-bf16 products (see wipa_gemm_desc.f32_split); 0 = exact f32 products (default) */
+    int32_t weights_generation; /* bumped by the caller whenever any pointer of a weight table changes: part of the key of
+                                 * the cached decode-step graphs (a freed table's host address may be reused) */
 } wipa_model_cfg;
 
 /* Encoder weight table (const void* [WIPA_ENC_GLOBAL + WIPA_ENC_PER_LAYER * n_layer]):
@@ -219,6 +222,14 @@ typedef struct wipa_model_cfg {
 size_t wipa_encoder_workspace_bytes(const wipa_model_cfg* cfg, int B);
 int wipa_encoder_forward(const wipa_model_cfg* cfg, const void* const* weights, const void* mel_padded, void* out,
                          void* workspace, size_t workspace_bytes, int B, wipa_stream_t s);
+
+/* Stage timing (measurement aid, bench.py's MFMA roofline): between wipa_profile_begin(stream) and wipa_profile_end every
+ * launch that wipa_encoder_forward and wipa_decoder_set_audio enqueue from THIS host thread on `stream` is bracketed by a
+ * pair of HIP events.  wipa_profile_end synchronises the stream and returns the summed kernel time (ms) and launch count per
+ * class: [0] GEMM / conv-as-GEMM (MFMA), [1] encoder flash attention, [2] LayerNorm, [3] other. */
+#define WIPA_PROFILE_CLASSES 4
+int wipa_profile_begin(wipa_stream_t s);
+int wipa_profile_end(float* ms_by_class, int* launches_by_class);
 
 /* KV-cached greedy decoding: mlx_whisper.decoding.decode / DecodingTask.run
  * (transcribe_single.py:55, train_whisper_ipa.py:356, evaluate_model.py:200).

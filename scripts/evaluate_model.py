@@ -29,7 +29,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-from evaluate_ipa import evaluate_batch, phone_error_rate, phone_feature_error_rate  # noqa: E402
+from evaluate_ipa import evaluate_batch  # noqa: E402
 from whisper_ipa_amd import parallel  # noqa: E402
 from whisper_ipa_amd.audio import load_audio, log_mel_spectrogram, pad_or_trim  # noqa: E402
 from whisper_ipa_amd.decoding import DecodingOptions, decode  # noqa: E402
@@ -113,16 +113,16 @@ def evaluate_model(model_path: str, test_data_path: str, num_samples: Optional[i
         hypotheses = [h for part in parts for h in part]
     references = [s["ipa_transcription"] for s in test_data]
 
+    results = evaluate_batch(references, hypotheses)  # per-sample scores included (reference evaluate_ipa.py:370-378)
     for i in range(min(3, len(references))):
         say(f"\nSample {i + 1}:")
         say(f"  Reference:  {references[i]}")
         say(f"  Hypothesis: {hypotheses[i]}")
-        say(f"  PER:  {phone_error_rate(references[i], hypotheses[i]):.2f}%")
-        say(f"  PFER: {phone_feature_error_rate(references[i], hypotheses[i]):.2f}%")
+        say(f"  PER:  {results['per_scores'][i]:.2f}%")
+        say(f"  PFER: {results['pfer_scores'][i]:.2f}%" + ("  (PER: no feature table)" if results["pfer_is_per_fallback"] else ""))
     say("\n" + "=" * 70)
     say(f"{model_name} - Overall Results")
     say("=" * 70)
-    results = evaluate_batch(references, hypotheses)
     say(f"\nPER (Phone Error Rate):         {results['per']:.2f}% (±{results['per_std']:.2f}%)")
     say(f"PFER (Phone Feature Error Rate): {results['pfer']:.2f}% (±{results['pfer_std']:.2f}%)")
     say(f"Number of samples: {results['num_samples']}")
@@ -172,7 +172,13 @@ def main(argv=None) -> Dict:
     ap.add_argument("--n-mels", type=int, default=128, help="Number of mel bins (80 for small/medium, 128 for large)")
     ap.add_argument("--batch-size", type=int, default=64, help="clips decoded together per GPU")
     ap.add_argument("--results-json", type=str, default=None, help="also write both result dicts here (rank 0)")
+    ap.add_argument("--allow-byte-fallback", action="store_true",
+                    help="run without the Whisper vocabulary (WIPA_TIKTOKEN unset): hypotheses render ids >= 256 as <|idN|>; "
+                         "synthetic weights only")
     args = ap.parse_args(argv)
+    from whisper_ipa_amd.tokenizer import get_tokenizer, require_real_vocabulary
+
+    require_real_vocabulary(get_tokenizer(True), args.allow_byte_fallback, "scoring a model's transcriptions")
 
     if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
         import torch.distributed as dist

@@ -73,10 +73,12 @@ class IPADataset:
         }
 
 
-def create_data_loader(json_path: str, multilingual: bool = True, n_mels: int = 80, audio_root: str = "") -> IPADataset:
+def create_data_loader(json_path: str, multilingual: bool = True, n_mels: int = 80, audio_root: str = "",
+                       allow_byte_fallback: bool = False) -> IPADataset:
     from whisper_ipa_amd import tokenizer as tok
 
     print(f"Loading Whisper tokenizer (multilingual={multilingual})...")
-    tokenizer = tok.get_tokenizer(multilingual=multilingual)
+    tokenizer = tok.require_real_vocabulary(tok.get_tokenizer(multilingual=multilingual), allow_byte_fallback,
+                                            "building IPA training / evaluation batches")
     tokenizer.language = "en"  # reference :152 (does not change the frozen sot_sequence)
     return IPADataset(json_path, tokenizer, n_mels=n_mels, audio_root=audio_root)

@@ -66,9 +66,10 @@ def get_hardware_info() -> Dict:
     return info
 
 
-def save_training_config(output_dir: Path, config: Dict) -> None:
+def save_training_config(output_dir: Path, args_dict: Dict, hardware: Dict) -> None:
+    """training_config.json with the reference's schema (:91-99): training_args / hardware / start_time."""
     with open(output_dir / "training_config.json", "w") as f:
-        json.dump({"config": config, "hardware": get_hardware_info(), "start_time": datetime.now().isoformat()}, f, indent=2)
+        json.dump({"training_args": args_dict, "hardware": hardware, "start_time": datetime.now().isoformat()}, f, indent=2)
 
 
 class TrainingLogger:
@@ -192,16 +193,23 @@ def _init_distributed():
 
 def train(model_name: str, train_data_path: str, test_data_path: str, output_dir: str, num_steps: int = 1000,
           batch_size: int = 4, learning_rate: float = 1e-5, validate_every: int = 100, save_every: int = 500,
-          test_run: bool = False, audio_root: str = "", seed: Optional[int] = None):
+          test_run: bool = False, audio_root: str = "", seed: Optional[int] = None, fast_f32: bool = False,
+          allow_byte_fallback: bool = False):
     rank, world = _init_distributed()
+    try:
+        parallel.require_even_shards(batch_size, world)  # every rank gets clips; no mismatched collectives
+    except ValueError as e:
+        raise SystemExit(f"--batch-size: {e}")
     main = rank == 0
     output_dir = Path(output_dir)
     if main:
         output_dir.mkdir(parents=True, exist_ok=True)
-        save_training_config(output_dir, dict(model=model_name, train_data=train_data_path, test_data=test_data_path,
-                                              steps=num_steps, batch_size=batch_size, lr=learning_rate,
-                                              validate_every=validate_every, save_every=save_every, test_run=test_run,
-                                              world_size=world))
+        # the reference's nine keys (:477-487), in its order; what this platform adds comes after them
+        args_dict = {"model_name": model_name, "train_data_path": train_data_path, "test_data_path": test_data_path,
+                     "num_steps": num_steps, "batch_size": batch_size, "learning_rate": learning_rate,
+                     "validate_every": validate_every, "save_every": save_every, "test_run": test_run,
+                     "world_size": world, "f32_products": "split" if fast_f32 else "exact"}
+        save_training_config(output_dir, args_dict, get_hardware_info())
     logger = TrainingLogger(output_dir) if main else None
     print(f"Loading model: {model_name}")
     t0 = time.time()
@@ -209,12 +217,14 @@ def train(model_name: str, train_data_path: str, test_data_path: str, output_dir
     model.set_dtype(torch.float32)
     print(f"  ✓ Model loaded in {time.time() - t0:.1f}s")
     freeze_encoder(model)
-    trainer = DecoderTrainer(model, lr=learning_rate)  # mlx AdamW defaults (reference :513)
+    trainer = DecoderTrainer(model, lr=learning_rate, f32_split=fast_f32)  # mlx AdamW defaults (reference :513)
     n_mels = 128 if "large" in model_name else 80  # reference :517
     if model.dims.n_mels != n_mels:
         n_mels = model.dims.n_mels
-    train_dataset = create_data_loader(train_data_path, multilingual=True, n_mels=n_mels, audio_root=audio_root)
-    test_dataset = create_data_loader(test_data_path, multilingual=True, n_mels=n_mels, audio_root=audio_root)
+    train_dataset = create_data_loader(train_data_path, multilingual=True, n_mels=n_mels, audio_root=audio_root,
+                                       allow_byte_fallback=allow_byte_fallback)
+    test_dataset = create_data_loader(test_data_path, multilingual=True, n_mels=n_mels, audio_root=audio_root,
+                                      allow_byte_fallback=allow_byte_fallback)
     tokenizer = train_dataset.tokenizer
     if test_run:
         train_dataset.data = train_dataset.data[:100]
@@ -229,16 +239,24 @@ def train(model_name: str, train_data_path: str, test_data_path: str, output_dir
         try:
             draw = rng.choice(len(train_dataset), size=batch_size, replace=False)  # one shared draw (reference :548)
             mine = parallel.shard_indices(draw.tolist(), world, rank)
-            batch = train_dataset.get_batch(mine)
-            # all ranks must use one token width: pad to the global maximum with EOT
+            batch, local_error = None, None
+            try:
+                batch = train_dataset.get_batch(mine)
+            except Exception as e:  # e.g. an unreadable clip on ONE rank
+                local_error = e
+            # Failure must be collective: a rank that left the loop alone would leave the others waiting in the step's
+            # all-reduces until the RCCL timeout.  One MAX all-reduce carries (error flag, token width); every rank
+            # sees the flag and breaks in the same step.
             if world > 1:
-                import torch.distributed as dist
-
-                w = torch.tensor([batch["tokens"].shape[1]], device="cuda")
-                dist.all_reduce(w, op=dist.ReduceOp.MAX)
-                pad = int(w.item()) - batch["tokens"].shape[1]
-                if pad:
+                width = parallel.agree_on_step(0 if batch is None else batch["tokens"].shape[1], failed=local_error is not None)
+                if width < 0:
+                    raise RuntimeError(f"a data-parallel rank failed to build its batch at step {step}"
+                                       + (f" (this rank: {local_error})" if local_error else ""))
+                pad = width - batch["tokens"].shape[1]
+                if pad:  # all ranks must use one token width: pad to the global maximum with EOT
                     batch["tokens"] = torch.nn.functional.pad(batch["tokens"], (0, pad), value=tokenizer.eot)
+            elif local_error is not None:
+                raise local_error
             step_start = time.time()
             loss, _ = train_step(trainer, batch, tokenizer)
             loss_value = float(loss.item())  # device sync, like mx.eval(loss) (reference :309)
@@ -267,6 +285,10 @@ def train(model_name: str, train_data_path: str, test_data_path: str, output_dir
             print(f"\n✗ Error at step {step}: {e}")
             import traceback
             traceback.print_exc()
+            if world > 1:
+                # exit non-zero so the launcher tears the whole job down: a lone `break` would leave the other ranks
+                # inside this step's collectives until the RCCL timeout
+                raise SystemExit(1)
             break
 
     if main:
@@ -285,7 +307,8 @@ def train(model_name: str, train_data_path: str, test_data_path: str, output_dir
                            "best_pfer_step": logger.best_pfer_step, "end_time": datetime.now().isoformat()}, f, indent=2)
             print(f"\n✓ Training complete in {total / 60:.1f} minutes")
             print(f"  Final loss: {float(latest_loss.item()):.4f}\n  Final PER: {metrics['per']:.2f}%\n"
-                  f"  Final PFER: {metrics['pfer']:.2f}%\n  Model saved to: {output_dir}")
+                  f"  Final PFER: {metrics['pfer']:.2f}%\n  Best PFER: {logger.best_pfer:.2f}% (step {logger.best_pfer_step})\n"
+                  f"  Model saved to: {output_dir}")
         else:
             print("\n✗ Training failed - no loss computed")
     if world > 1:
@@ -309,10 +332,16 @@ def main():
     p.add_argument("--save-every", type=int, default=1000, help="Save checkpoint every N steps")
     p.add_argument("--test-run", action="store_true", help="Test run with only 100 samples")
     p.add_argument("--audio-root", type=str, default="", help="prefix for the relative audio_path entries of the JSON")
+    p.add_argument("--fast-f32", action="store_true",
+                   help="take the float32 products of the large GEMMs as split-bf16 MFMA terms (~2x faster, ~5e-6 relative); "
+                        "default: exact f32 products, as the reference trains")
+    p.add_argument("--allow-byte-fallback", action="store_true",
+                   help="run without the Whisper vocabulary (WIPA_TIKTOKEN unset): raw-byte text ids; synthetic weights only")
     a = p.parse_args()
     train(model_name=a.model, train_data_path=a.train_data, test_data_path=a.test_data, output_dir=a.output_dir,
           num_steps=a.steps, batch_size=a.batch_size, learning_rate=a.lr, validate_every=a.validate_every,
-          save_every=a.save_every, test_run=a.test_run, audio_root=a.audio_root)
+          save_every=a.save_every, test_run=a.test_run, audio_root=a.audio_root, fast_f32=a.fast_f32,
+          allow_byte_fallback=a.allow_byte_fallback)
 
 
 if __name__ == "__main__":

@@ -54,7 +54,12 @@ def main(argv=None):
     ap.add_argument("--audio", default="4.wav")
     ap.add_argument("--base-model", default="mlx-community/whisper-large-v3-mlx",
                     help="local directory with config.json + weights.safetensors (hub names cannot resolve offline)")
+    ap.add_argument("--allow-byte-fallback", action="store_true",
+                    help="run without the Whisper vocabulary (WIPA_TIKTOKEN unset): ids >= 256 print as <|idN|>; synthetic weights only")
     args = ap.parse_args(argv)
+    from whisper_ipa_amd.tokenizer import get_tokenizer, require_real_vocabulary
+
+    require_real_vocabulary(get_tokenizer(True), args.allow_byte_fallback, "transcribing with a trained checkpoint")
     model = load_checkpoint_model(args.checkpoint, args.base_model)
     text = transcribe_file(model, args.audio)
     print("\n" + "=" * 50)

@@ -56,12 +56,8 @@ def golden_dir():
     return GOLDEN
 
 
-@pytest.fixture(params=["split", "exact"])
+@pytest.fixture(params=["exact", "split"])
 def f32_mode(request):
-    """float32 tile GEMMs: three-term bf16 split (default) or the f32 MFMA (wipa_set_f32_gemm_exact)."""
-    from whisper_ipa_amd import _lib
-
-    L = _lib.lib()
-    prev = L.wipa_set_f32_gemm_exact(1 if request.param == "exact" else 0)
-    yield request.param
-    L.wipa_set_f32_gemm_exact(prev)
+    """float32 tile GEMMs: exact f32 products on the f32 MFMA (default) or the opt-in three-term bf16 split
+    (wipa_gemm_desc.f32_split / wipa_model_cfg.f32_split).  Tests pass ``f32_split=(f32_mode == "split")``."""
+    return request.param

@@ -1,0 +1,62 @@
+"""bench.py as the driver runs it, on small models so it takes seconds: the JSON contract, the `--gpus N` launcher
+(rehearsed on ONE GPU: WIPA_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and moves the timing collectives over gloo --
+RCCL refuses two ranks on one device) and `--mode train`.  ``pytest -m gpu``."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, share_gpu=False, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    if share_gpu:
+        env["WIPA_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout,
+                       env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout  # ONE JSON line on stdout
+    return json.loads(lines[0])
+
+
+CONTRACT = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config"}
+
+
+def test_bench_single_rank_contract_and_rooflines():
+    out = _run(["--steps", "3", "--warmup", "1", "--model", "tiny", "--batch", "8", "--pipeline", "2"])
+    assert CONTRACT <= set(out)
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["unit"] == "audio-s/s" and out["value"] > 0
+    assert abs(out["value"] - 8 * 30.0 * 3 / (out["ms_per_step"] * 3e-3)) / out["value"] < 0.02
+    assert "workload" in out["config"] and "model" not in out["config"]
+    for key in ("roofline", "roofline_mfma", "decode_step"):
+        r = out[key]
+        assert r["bound"] in ("hbm", "mfma") and r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3, key
+    assert out["roofline_mfma"]["gemm_launches"] == 2 + 5 * 4 + 4  # convs + 5 GEMMs x 4 encoder layers + 4 cross-K/V
+    assert out["decode_step"]["bytes_per_step"] > out["decode_step"]["cross_kv_bytes"] > 0
+
+
+def test_bench_gpus_2_launches_two_ranks():
+    """`python bench.py --gpus 2` (no launcher, no WORLD_SIZE): the parent starts two ranks and relays rank 0's line."""
+    out = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--model", "tiny", "--batch", "8", "--pipeline", "2",
+                "--no-cpu-baseline"], share_gpu=True)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["parallelism"].startswith("dp2")
+    # whole-job aggregate: both ranks' clips over the max-over-ranks time
+    assert abs(out["value"] - 2 * 8 * 30.0 * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 0.02
+
+
+def test_bench_train_mode_single_and_two_ranks():
+    args = ["--mode", "train", "--model", "tiny", "--train-batch", "4", "--train-tokens", "16", "--steps", "2", "--warmup", "1"]
+    one = _run(args)
+    assert CONTRACT <= set(one) and one["unit"] == "clips/s" and one["dtype"] == "f32" and one["n_gpus"] == 1
+    assert one["allreduce_exposed_ms_per_step"] == 0.0 and one["roofline"]["bound"] == "mfma"
+    assert {"encoder_ms", "loss_and_grads_ms", "update_ms"} <= set(one["stages"])
+    two = _run(["--gpus", "2"] + args, share_gpu=True)
+    assert two["n_gpus"] == 2 and two["allreduce_exposed_ms_per_step"] >= 0.0 and two["grad_bytes"] == one["grad_bytes"]

@@ -29,7 +29,7 @@ def test_gemm_f32_plain(ops, M, N, K, f32_mode):
     W = torch.randn(N, K, generator=g)
     ldc = (N + 7) // 8 * 8
     out = torch.full((M, ldc), 7.0, device="cuda")
-    ops.gemm(A.cuda(), W.cuda(), out, M=M, N=N, K=K, lda=K, ldw=K, ldc=ldc)
+    ops.gemm(A.cuda(), W.cuda(), out, M=M, N=N, K=K, lda=K, ldw=K, ldc=ldc, f32_split=(f32_mode == "split"))
     torch.cuda.synchronize()
     ref = A.double() @ W.double().T
     assert _rel(out[:, :N], ref) < tol
@@ -191,8 +191,8 @@ def test_decode_cross_attention_multi_query(dtype, n_q):
 @pytest.mark.parametrize("T", [1500, 200, 64, 37])
 def test_flash_attention_encoder_f32(ops, T, f32_mode):
     """float32 flash attention (the reference's own dtype) against softmax(QK^T)V in float64; ragged last key tile,
-    partial query block, and spiked scores that move the running maximum between tiles.  Exact mode: f32 MFMA kernel;
-    default: three-term bf16 split of every product (score errors of ~1e-5 relative pass through the exponential)."""
+    partial query block, and spiked scores that move the running maximum between tiles.  Exact mode (default): f32 MFMA kernel;
+    opt-in: three-term bf16 split of every product (score errors of ~1e-5 relative pass through the exponential)."""
     tol = 2e-5 if f32_mode == "exact" else 1e-4
     g = torch.Generator().manual_seed(T)
     B, H = 2, 3
@@ -203,7 +203,7 @@ def test_flash_attention_encoder_f32(ops, T, f32_mode):
     for t in range(5, T, 61):
         k[0, t, 1] = q[0, t % 29, 1] * (1.0 + t / 40.0)
     qk = torch.cat([q.reshape(B * T, D), k.reshape(B * T, D)], dim=1).contiguous()
-    out = ops.flash_attn_enc_f32(qk.cuda(), v.reshape(B * T, D).contiguous().cuda(), B, H, T)
+    out = ops.flash_attn_enc_f32(qk.cuda(), v.reshape(B * T, D).contiguous().cuda(), B, H, T, f32_split=(f32_mode == "split"))
     torch.cuda.synchronize()
     s = torch.einsum("bqhd,bkhd->bhqk", q.double(), k.double())
     ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1), v.double()).reshape(B * T, D).float()

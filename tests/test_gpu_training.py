@@ -222,7 +222,7 @@ def test_train_step_matches_oracle_clip_and_adamw(setup, f32_mode):
     Wo = {k: v.clone() for k, v in W.items()}
     m = Whisper(ModelDimensions(**MICRO.__dict__), dtype=torch.float32)
     m.load_weights(W)
-    tr = DecoderTrainer(m, lr=1e-3)
+    tr = DecoderTrainer(m, lr=1e-3, f32_split=(f32_mode == "split"))
     state = {}
     for step in range(2):
         loss, _, _ = tr.loss_and_grads(xa.cuda(), tokens.cuda(), EOT)
@@ -236,7 +236,7 @@ def test_train_step_matches_oracle_clip_and_adamw(setup, f32_mode):
             state[k] = (mm, vv)
             g[k] = gk
         torch.cuda.synchronize()
-        assert abs(float(loss) - ref_loss) < 2e-3, (step, float(loss), ref_loss)
+        assert abs(float(loss) - ref_loss) < 1e-3, (step, float(loss), ref_loss)  # north_star: loss within 1e-3 in fp32
         for n in tr.names:
             assert _rel(tr.g(n), g[n]) < 3e-3, (step, "clipped grad", n)
             # without bias correction an element with |g| ~ eps moves by lr*0.1*g/eps: 1e-9 of gradient
@@ -283,7 +283,7 @@ def test_train_script_end_to_end_artefacts(tmp_path, capsys):
     (tmp_path / "test.json").write_text(json.dumps(entries[:4]))
     out = tmp_path / "out"
     T.train(str(model_dir), str(tmp_path / "train.json"), str(tmp_path / "test.json"), str(out), num_steps=3, batch_size=2,
-            learning_rate=1e-4, validate_every=2, save_every=2, seed=0)
+            learning_rate=1e-4, validate_every=2, save_every=2, seed=0, allow_byte_fallback=True)
     text = capsys.readouterr().out
     import re
     assert re.search(r"Step 1/3 \| Loss: \d+\.\d{4} \| Time: \d+\.\d{3}s \| Samples/sec: \d+\.\d", text)
@@ -296,7 +296,12 @@ def test_train_script_end_to_end_artefacts(tmp_path, capsys):
     st = json.load(open(out / "checkpoint-3" / "training_state.json"))
     assert st["step"] == 3 and {"loss", "wall_clock_sec", "learning_rate", "best_pfer", "timestamp"} <= set(st)
     assert {"final_loss", "final_per", "final_pfer", "best_pfer_step"} <= set(json.load(open(out / "training_summary.json")))
-    assert "config" in json.load(open(out / "training_config.json"))
+    cfg = json.load(open(out / "training_config.json"))  # the reference's schema (train_whisper_ipa.py:91-99,477-487)
+    assert set(cfg) == {"training_args", "hardware", "start_time"}
+    ref_keys = ["model_name", "train_data_path", "test_data_path", "num_steps", "batch_size", "learning_rate", "validate_every",
+                "save_every", "test_run"]
+    assert list(cfg["training_args"])[:9] == ref_keys and cfg["training_args"]["num_steps"] == 3
+    assert re.search(r"Best PFER: \d+\.\d{2}% \(step \d+\)", text)  # final console block (:642)
     saved = load_safetensors(str(out / "checkpoint-3" / "model.safetensors"))
     assert any(k.startswith("encoder.") for k in saved) and any(k.startswith("decoder.") for k in saved)
     # the decoder moved, the frozen encoder did not
@@ -311,7 +316,8 @@ def test_train_script_end_to_end_artefacts(tmp_path, capsys):
     # evaluate_model flow (reference evaluate_model.py:127-232): batched decode == clip-by-clip decode
     import evaluate_model as EM
     res = EM.main(["--checkpoint", str(out / "checkpoint-3"), "--base-model", str(model_dir), "--test-data", str(tmp_path / "test.json"),
-                   "--num-samples", "0", "--n-mels", "80", "--batch-size", "3", "--results-json", str(tmp_path / "res.json")])
+                   "--num-samples", "0", "--n-mels", "80", "--batch-size", "3", "--results-json", str(tmp_path / "res.json"),
+                   "--allow-byte-fallback"])
     text = capsys.readouterr().out
     assert "Base Whisper Model - Overall Results" in text and "Model Comparison" in text and "Evaluation Complete" in text
     assert res["trained"]["num_samples"] == 4 and {"per", "pfer", "per_std", "pfer_std"} <= set(res["base"])
@@ -320,6 +326,48 @@ def test_train_script_end_to_end_artefacts(tmp_path, capsys):
     paths = [e["audio_path"] for e in entries[:4]]
     assert EM.transcribe_batch(model2, paths, 80, opts) == [EM.transcribe_batch(model2, [p], 80, opts)[0] for p in paths]
     assert EM.transcribe_batch(model2, [paths[0], str(tmp_path / "missing.wav")], 80, opts)[1] == ""
+
+
+def test_decode_after_weight_update_uses_the_new_weights(setup):
+    """the decode-step hipGraph cache must not survive a weight update.  Decode at a fixed batch, take an
+    optimiser step (which frees and rebuilds the fused q|k|v tables), decode again at the SAME batch / prompt / masks: the
+    ids must equal those of a fresh model built from the updated weights, and the cached graphs of the old tables are gone."""
+    from whisper_ipa_amd.decoding import greedy_decode_tokens
+    from whisper_ipa_amd.training import DecoderTrainer
+    from whisper_ipa_amd.whisper import ModelDimensions, Whisper
+
+    W, xa, tokens = setup
+    sp = R.SpecialTokens.multilingual()
+    always, first = R.suppress_lists(sp)
+    init = list(sp.sot_sequence_including_notimestamps(0))
+    m = Whisper(ModelDimensions(**MICRO.__dict__), dtype=torch.float32)
+    m.load_weights(W)
+    tr = DecoderTrainer(m, lr=5e-2)  # a large step: the ids must visibly change
+    feats = xa.cuda()
+
+    def ids(model):
+        return greedy_decode_tokens(model, feats, init, always, first, sp.eot, max_new_tokens=12, stop_on_eot=False).tokens
+
+    before = ids(m)
+    gen0 = m.packed()["cfg"].weights_generation
+    for _ in range(3):
+        tr.loss_and_grads(feats, tokens.cuda(), EOT)
+        tr.apply_update()
+        # allocate and free between the steps, like a real training loop: the freed tables' addresses get reused
+        junk = [torch.randn(1 << 18, device="cuda") for _ in range(8)]
+        del junk
+    after = ids(m)
+    assert m.packed()["cfg"].weights_generation > gen0
+    fresh = Whisper(ModelDimensions(**MICRO.__dict__), dtype=torch.float32)
+    fresh.load_weights({k: v.clone() for k, v in m.flat_parameters().items()})
+    want = ids(fresh)
+    assert (after == want).all(), (after.tolist(), want.tolist())
+    assert not (after == before).all(), "the optimiser steps did not change the greedy ids: the test is vacuous"
+    with torch.no_grad():
+        Wn = {k: v.float().cpu() for k, v in m.flat_parameters().items()}
+        ref = R.greedy_decode(Wn, MICRO, xa, init, always, first, sp.eot, sample_len=12, stop_on_eot=False)
+    gate = np.cumprod(ref.margins > 1e-3, axis=1).astype(bool)
+    assert (after[:, 4:][gate] == ref.tokens[:, 4:][gate]).all()
 
 
 def _dp_worker(rank, world, port, q):
@@ -415,6 +463,6 @@ def test_small_width_gradients_match_oracle():
     tr = DecoderTrainer(m)
     loss, _, _ = tr.loss_and_grads(xa.cuda(), tokens.cuda(), EOT)
     torch.cuda.synchronize()
-    assert abs(float(loss) - float(ref_loss)) < 2e-3
+    assert abs(float(loss) - float(ref_loss)) < 1e-3  # north_star: loss within 1e-3 in fp32
     worst = max(((_rel(tr.g(n), ref[n]), n) for n in tr.names))
     assert worst[0] < 3e-3, worst

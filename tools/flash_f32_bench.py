@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Encoder flash attention in float32 (B = 32, H = 12, T = 1500): time and error against float64 on one (b, h), in the
-three-term bf16 split mode (default) and with exact f32 products (wipa_set_f32_gemm_exact)."""
+three-term bf16 split mode (opt-in, f32_split=1) and with exact f32 products (default)."""
 import os
 import sys
 
@@ -21,15 +21,15 @@ k1 = qk.view(B, T, 2 * D)[b, :, D + h * 64:D + (h + 1) * 64].double()
 v1 = v.view(B, T, D)[b, :, h * 64:(h + 1) * 64].double()
 ref = torch.softmax(q1 @ k1.t(), dim=-1) @ v1
 for mode in ("split", "exact"):
-    _lib.lib().wipa_set_f32_gemm_exact(1 if mode == "exact" else 0)
-    out = ops.flash_attn_enc_f32(qk, v, B, H, T)
+    split = mode == "split"
+    out = ops.flash_attn_enc_f32(qk, v, B, H, T, f32_split=split)
     err = (out.view(B, T, D)[b, :, h * 64:(h + 1) * 64].double() - ref).abs().max().item()
     s = stream()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     with torch.cuda.stream(s):
         e0.record(s)
         for _ in range(4):
-            ops.flash_attn_enc_f32(qk, v, B, H, T)
+            ops.flash_attn_enc_f32(qk, v, B, H, T, f32_split=split)
         e1.record(s)
     e1.synchronize()
     us = e0.elapsed_time(e1) / 4 * 1e3

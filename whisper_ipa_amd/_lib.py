@@ -31,7 +31,7 @@ class GemmDesc(C.Structure):
         ("rg_in", C.c_int32), ("rg_valid", C.c_int32), ("cg_in", C.c_int32),
         ("zero_invalid_rows", C.c_int32), ("bias_along_m", C.c_int32), ("act", C.c_int32),
         ("col_scale_n", C.c_int32), ("col_scale", c_float), ("k_slices", C.c_int32),
-        ("stream_weights", C.c_int32),
+        ("f32_split", C.c_int32), ("stream_weights", C.c_int32),
     ]
 
 
@@ -51,7 +51,7 @@ class AttnDesc(C.Structure):
 class ModelCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n_mels", "n_audio_ctx", "n_audio_state", "n_audio_head", "n_audio_layer",
-        "n_vocab", "n_text_ctx", "n_text_state", "n_text_head", "n_text_layer", "dtype", "reserved")]
+        "n_vocab", "n_text_ctx", "n_text_state", "n_text_head", "n_text_layer", "dtype", "f32_split", "weights_generation")]
 
 
 class DecLayout(C.Structure):
@@ -80,7 +80,7 @@ SIGNATURES = {
                                   c_int, c_void_p]),
     "wipa_attention": (c_int, [_P(AttnDesc), c_void_p]),
     "wipa_flash_attn_enc_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int,
-                                       c_int, c_void_p]),
+                                       c_int, c_int, c_void_p]),
     "wipa_flash_attn_enc_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
                                          c_void_p]),
     "wipa_decode_attn": (c_int, [_P(AttnDesc), c_void_p]),
@@ -88,6 +88,8 @@ SIGNATURES = {
     "wipa_greedy_step": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int,
                                  c_int, c_void_p, c_void_p, c_void_p]),
     "wipa_add_i32": (c_int, [c_void_p, C.c_int32, c_void_p]),
+    "wipa_profile_begin": (c_int, [c_void_p]),
+    "wipa_profile_end": (c_int, [_P(c_float), _P(c_int)]),
     "wipa_encoder_workspace_bytes": (c_size_t, [_P(ModelCfg), c_int]),
     "wipa_encoder_forward": (c_int, [_P(ModelCfg), _P(c_void_p), c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "wipa_decoder_layout": (c_int, [_P(ModelCfg), c_int, _P(DecLayout)]),
@@ -105,7 +107,6 @@ SIGNATURES = {
     "wipa_masked_ce": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                c_void_p]),
     "wipa_transpose": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
-    "wipa_set_f32_gemm_exact": (c_int, [c_int]),
     "wipa_sum_slabs": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int64, c_int, c_void_p]),
     "wipa_colsum": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
     "wipa_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,

@@ -927,15 +927,15 @@ extern "C" int wipa_flash_attn_enc_bf16(const void* qk, int64_t ldqk, const void
 }
 
 extern "C" int wipa_flash_attn_enc_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
-                                       float* out, int64_t ldo, int B, int H, int T, wipa_stream_t stream) {
+                                       float* out, int64_t ldo, int B, int H, int T, int f32_split, wipa_stream_t stream) {
     WIPA_REQUIRE(q && k && v && out, "wipa_flash_attn_enc_f32: null pointer");
     WIPA_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0, "wipa_flash_attn_enc_f32: row strides must be multiples of 4");
     WIPA_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 && ((uintptr_t)out % 16) == 0,
                  "wipa_flash_attn_enc_f32: operands must be 16-byte aligned");
     WIPA_REQUIRE(B > 0 && H > 0 && T > 0, "wipa_flash_attn_enc_f32: bad shape");
     dim3 grid((T + 127) / 128, H, B);
-    // three-term bf16 split unless the process asked for exact f32 products (wipa_set_f32_gemm_exact / WIPA_F32_GEMM=exact)
-    if (wipa_set_f32_gemm_exact(-1))
+    // exact f32 products unless the caller opted into the split-bf16 kernel
+    if (!f32_split)
         hipLaunchKernelGGL(flash_enc_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, ldq, k, ldk, v, ldv, out, ldo, T);
     else
         hipLaunchKernelGGL(flash_enc_f32s_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, ldq, k, ldk, v, ldv, out, ldo, T);

@@ -1013,15 +1013,6 @@ int launch(const GemmParams& p, hipStream_t s) {
 
 }  // namespace
 
-namespace {
-std::atomic<int>& f32_exact_mode() {
-    static std::atomic<int> mode([] { const char* e = getenv("WIPA_F32_GEMM"); return (e && !strcmp(e, "exact")) ? 1 : 0; }());
-    return mode;
-}
-}  // namespace
-
-extern "C" int wipa_set_f32_gemm_exact(int on) { return on < 0 ? f32_exact_mode().load() : f32_exact_mode().exchange(on ? 1 : 0); }
-
 extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
     WIPA_REQUIRE(d && d->A && d->W && d->C, "wipa_gemm: null operand");
     WIPA_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "wipa_gemm: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
@@ -1080,9 +1071,9 @@ extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
     }
     hipStream_t s = (hipStream_t)stream;
     {
-        // f32 inputs in the tile kernels: three bf16 MFMA terms per product (2x the f32-MFMA rate, ~3e-6 relative error)
-        // unless WIPA_F32_GEMM=exact asks for the f32 MFMA.  The weight-streaming kernel (decode steps) stays exact.
-        p.f32_split = (d->in_dtype == WIPA_F32 && !f32_exact_mode().load()) ? 1 : 0;
+        // f32 inputs in the tile kernels: exact f32 products on the f32 MFMA unless the caller opted into three bf16 MFMA
+        // terms per product (desc.f32_split: 2x the rate, ~5e-6 relative error).  The weight-streaming kernel stays exact.
+        p.f32_split = (d->in_dtype == WIPA_F32 && d->f32_split) ? 1 : 0;
     }
     {
         const int rc = init_attrs();

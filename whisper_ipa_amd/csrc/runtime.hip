@@ -11,6 +11,7 @@
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <vector>
 
 #include "wipa_common.h"
 
@@ -51,6 +52,42 @@ int cfg_check(const wipa_model_cfg* c) {
     return WIPA_OK;
 }
 
+// ---- stage profiler (wipa_profile_begin / wipa_profile_end): HIP events around every launch of the encoder forward and
+// the cross-K/V projection, summed per kernel class.  Host-thread local; inactive (one pointer test) otherwise.
+enum { PROF_GEMM = 0, PROF_ATTN = 1, PROF_NORM = 2, PROF_OTHER = 3, PROF_CLASSES = 4 };
+struct Profiler {
+    hipStream_t stream;
+    std::vector<std::tuple<int, hipEvent_t, hipEvent_t>> spans;
+};
+thread_local Profiler* t_prof = nullptr;
+struct ProfSpan {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int cls;
+    explicit ProfSpan(int c) : cls(c) {
+        if (!t_prof) return;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }
+        hipEventRecord(e0, t_prof->stream);
+    }
+    ~ProfSpan() {
+        if (!t_prof || !e0) return;
+        hipEventRecord(e1, t_prof->stream);
+        t_prof->spans.emplace_back(cls, e0, e1);
+    }
+};
+#define PROF(cls, call)        \
+    do {                       \
+        ProfSpan _span(cls);   \
+        RT_CALL(call);         \
+    } while (0)
+
+// wipa_model_cfg.f32_split of the runtime call in progress on this host thread (set by the entry points below)
+thread_local int t_f32_split = 0;
+struct SplitScope {
+    int prev;
+    explicit SplitScope(const wipa_model_cfg* c) : prev(t_f32_split) { t_f32_split = (c && c->dtype == WIPA_F32 && c->f32_split) ? 1 : 0; }
+    ~SplitScope() { t_f32_split = prev; }
+};
+
 int gemm(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int M, int N, int K, int in_dt,
          int out_dt, const float* bias, int act, const void* residual, wipa_stream_t s, wipa_gemm_desc* extra = nullptr) {
     wipa_gemm_desc g;
@@ -58,6 +95,7 @@ int gemm(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc;
     g.M = M; g.N = N; g.K = K; g.in_dtype = in_dt; g.out_dtype = out_dt;
     g.bias = bias; g.act = act; g.residual = residual;
+    g.f32_split = t_f32_split;
     return wipa_gemm(&g, s);
 }
 
@@ -90,6 +128,7 @@ extern "C" size_t wipa_encoder_workspace_bytes(const wipa_model_cfg* cfg, int B)
 extern "C" int wipa_encoder_forward(const wipa_model_cfg* cfg, const void* const* w, const void* mel_padded, void* out,
                                     void* workspace, size_t workspace_bytes, int B, wipa_stream_t stream) {
     RT_CALL(cfg_check(cfg));
+    SplitScope split_scope(cfg);
     WIPA_REQUIRE(w && mel_padded && out && workspace && B > 0, "wipa_encoder_forward: null pointer / bad batch");
     const EncWs L = enc_ws(cfg, B);
     WIPA_REQUIRE(workspace_bytes >= L.total, "wipa_encoder_forward: workspace too small (%zu < %zu)", workspace_bytes, L.total);
@@ -115,7 +154,7 @@ extern "C" int wipa_encoder_forward(const wipa_model_cfg* cfg, const void* const
         memset(&g, 0, sizeof(g));
         g.rg_in = ROWS_IN; g.rg_valid = WIPA_N_FRAMES; g.rg_stride = (int64_t)ROWS_IN * d; g.zero_invalid_rows = 1;
         g.c_offset = d;
-        RT_CALL(gemm(mel_padded, cfg->n_mels, w[0], K1, c1, d, B * ROWS_IN, d, K1, dt, dt, (const float*)w[1], 1, nullptr,
+        PROF(PROF_GEMM, gemm(mel_padded, cfg->n_mels, w[0], K1, c1, d, B * ROWS_IN, d, K1, dt, dt, (const float*)w[1], 1, nullptr,
                      stream, &g));
     }
     // conv2 (k3,s2,p1) + GELU + positional embedding -> residual stream x (f32)
@@ -124,37 +163,37 @@ extern "C" int wipa_encoder_forward(const wipa_model_cfg* cfg, const void* const
         memset(&g, 0, sizeof(g));
         g.rg_in = T + 1; g.rg_valid = T; g.rg_stride = (int64_t)T * d;
         g.pos = (const float*)w[4]; g.ldpos = d;
-        RT_CALL(gemm(c1, 2 * d, w[2], 3 * d, x, d, B * (T + 1), d, 3 * d, dt, WIPA_F32, (const float*)w[3], 1, nullptr,
+        PROF(PROF_GEMM, gemm(c1, 2 * d, w[2], 3 * d, x, d, B * (T + 1), d, 3 * d, dt, WIPA_F32, (const float*)w[3], 1, nullptr,
                      stream, &g));
     }
     if (dt == WIPA_BF16) WIPA_CHECK_HIP(hipMemsetAsync(vb, 0, (size_t)B * d * T_ENC_PAD * e, s));
     for (int l = 0; l < cfg->n_audio_layer; ++l) {
         const void* const* lw = w + WIPA_ENC_GLOBAL + WIPA_ENC_PER_LAYER * l;
-        RT_CALL(wipa_layernorm(x, WIPA_F32, d, ln, dt, d, (const float*)lw[0], (const float*)lw[1], M, d, 1e-5f, stream));
+        PROF(PROF_NORM, wipa_layernorm(x, WIPA_F32, d, ln, dt, d, (const float*)lw[0], (const float*)lw[1], M, d, 1e-5f, stream));
         {
             wipa_gemm_desc g;
             memset(&g, 0, sizeof(g));
             g.col_scale_n = 2 * d; g.col_scale = QK_SCALE;
-            RT_CALL(gemm(ln, d, lw[2], d, qk, 2 * d, M, 2 * d, d, dt, dt, (const float*)lw[3], 0, nullptr, stream, &g));
+            PROF(PROF_GEMM, gemm(ln, d, lw[2], d, qk, 2 * d, M, 2 * d, d, dt, dt, (const float*)lw[3], 0, nullptr, stream, &g));
         }
         if (dt == WIPA_BF16) {
             // V^T per clip: swap the operand roles so the GEMM writes [d][t] directly
             wipa_gemm_desc g;
             memset(&g, 0, sizeof(g));
             g.bias_along_m = 1; g.cg_in = T; g.cg_stride = (int64_t)d * T_ENC_PAD;
-            RT_CALL(gemm(lw[4], d, ln, d, vb, T_ENC_PAD, d, M, d, dt, dt, (const float*)lw[5], 0, nullptr, stream, &g));
-            RT_CALL(wipa_flash_attn_enc_bf16(qk, 2 * d, vb, T_ENC_PAD, ao, d, B, H, T, stream));
+            PROF(PROF_GEMM, gemm(lw[4], d, ln, d, vb, T_ENC_PAD, d, M, d, dt, dt, (const float*)lw[5], 0, nullptr, stream, &g));
+            PROF(PROF_ATTN, wipa_flash_attn_enc_bf16(qk, 2 * d, vb, T_ENC_PAD, ao, d, B, H, T, stream));
         } else {
-            RT_CALL(gemm(ln, d, lw[4], d, vb, d, M, d, d, dt, dt, (const float*)lw[5], 0, nullptr, stream));
-            RT_CALL(wipa_flash_attn_enc_f32((const float*)qk, 2 * d, (const float*)qk + d, 2 * d, (const float*)vb, d, (float*)ao, d,
-                                            B, H, T, stream));
+            PROF(PROF_GEMM, gemm(ln, d, lw[4], d, vb, d, M, d, d, dt, dt, (const float*)lw[5], 0, nullptr, stream));
+            PROF(PROF_ATTN, wipa_flash_attn_enc_f32((const float*)qk, 2 * d, (const float*)qk + d, 2 * d, (const float*)vb, d, (float*)ao, d,
+                                            B, H, T, t_f32_split, stream));
         }
-        RT_CALL(gemm(ao, d, lw[6], d, x, d, M, d, d, dt, WIPA_F32, (const float*)lw[7], 0, x, stream));
-        RT_CALL(wipa_layernorm(x, WIPA_F32, d, ln, dt, d, (const float*)lw[8], (const float*)lw[9], M, d, 1e-5f, stream));
-        RT_CALL(gemm(ln, d, lw[10], d, hb, 4 * d, M, 4 * d, d, dt, dt, (const float*)lw[11], 1, nullptr, stream));
-        RT_CALL(gemm(hb, 4 * d, lw[12], 4 * d, x, d, M, d, 4 * d, dt, WIPA_F32, (const float*)lw[13], 0, x, stream));
+        PROF(PROF_GEMM, gemm(ao, d, lw[6], d, x, d, M, d, d, dt, WIPA_F32, (const float*)lw[7], 0, x, stream));
+        PROF(PROF_NORM, wipa_layernorm(x, WIPA_F32, d, ln, dt, d, (const float*)lw[8], (const float*)lw[9], M, d, 1e-5f, stream));
+        PROF(PROF_GEMM, gemm(ln, d, lw[10], d, hb, 4 * d, M, 4 * d, d, dt, dt, (const float*)lw[11], 1, nullptr, stream));
+        PROF(PROF_GEMM, gemm(hb, 4 * d, lw[12], 4 * d, x, d, M, d, 4 * d, dt, WIPA_F32, (const float*)lw[13], 0, x, stream));
     }
-    RT_CALL(wipa_layernorm(x, WIPA_F32, d, out, dt, d, (const float*)w[5], (const float*)w[6], M, d, 1e-5f, stream));
+    PROF(PROF_NORM, wipa_layernorm(x, WIPA_F32, d, out, dt, d, (const float*)w[5], (const float*)w[6], M, d, 1e-5f, stream));
     return WIPA_OK;
 }
 
@@ -416,14 +455,46 @@ int enqueue_prefill(const wipa_model_cfg* cfg, const void* const* w, char* st, c
 }
 
 // graph cache: one captured step per (state blob, weights, masks, shape)
-typedef std::tuple<const void*, const void*, const void*, const void*, int, int, int, int, int> GraphKey;  // ..., kind: 0 step, 1 prefill
+// The key carries cfg->weights_generation: the host address of a weight table can be reused by a NEW table after the old
+// one was freed, so the address alone does not identify the device pointers baked into a captured graph.
+typedef std::tuple<const void*, const void*, const void*, const void*, int, int, int, int, int, int> GraphKey;  // ..., generation, kind: 0 step, 1 prefill
 std::mutex g_graph_mu;
 std::map<GraphKey, hipGraphExec_t> g_graphs;
 
 }  // namespace
 
+extern "C" int wipa_profile_begin(wipa_stream_t stream) {
+    WIPA_REQUIRE(!t_prof, "wipa_profile_begin: a profile is already open on this thread");
+    t_prof = new Profiler{(hipStream_t)stream, {}};
+    return WIPA_OK;
+}
+
+extern "C" int wipa_profile_end(float* ms_by_class, int* launches_by_class) {
+    WIPA_REQUIRE(t_prof, "wipa_profile_end: no open profile");
+    Profiler* p = t_prof;
+    t_prof = nullptr;
+    const hipError_t se = hipStreamSynchronize(p->stream);
+    for (int c = 0; c < PROF_CLASSES; ++c) {
+        if (ms_by_class) ms_by_class[c] = 0.f;
+        if (launches_by_class) launches_by_class[c] = 0;
+    }
+    for (auto& sp : p->spans) {
+        float ms = 0.f;
+        if (se == hipSuccess && hipEventElapsedTime(&ms, std::get<1>(sp), std::get<2>(sp)) == hipSuccess) {
+            if (ms_by_class) ms_by_class[std::get<0>(sp)] += ms;
+            if (launches_by_class) launches_by_class[std::get<0>(sp)] += 1;
+        }
+        hipEventDestroy(std::get<1>(sp));
+        hipEventDestroy(std::get<2>(sp));
+    }
+    delete p;
+    WIPA_CHECK_HIP(se);
+    return WIPA_OK;
+}
+
 extern "C" int wipa_decoder_layout(const wipa_model_cfg* cfg, int B, wipa_dec_layout* out) {
     RT_CALL(cfg_check(cfg));
+    SplitScope split_scope(cfg);
     WIPA_REQUIRE(out && B > 0, "wipa_decoder_layout: bad arguments");
     *out = dec_layout(cfg, B);
     return WIPA_OK;
@@ -432,6 +503,7 @@ extern "C" int wipa_decoder_layout(const wipa_model_cfg* cfg, int B, wipa_dec_la
 extern "C" int wipa_decoder_set_audio(const wipa_model_cfg* cfg, const void* const* w, const void* features, void* state,
                                       int B, wipa_stream_t stream) {
     RT_CALL(cfg_check(cfg));
+    SplitScope split_scope(cfg);
     WIPA_REQUIRE(w && features && state && B > 0, "wipa_decoder_set_audio: null pointer / bad batch");
     const wipa_dec_layout L = dec_layout(cfg, B);
     const int dt = cfg->dtype;
@@ -446,7 +518,7 @@ extern "C" int wipa_decoder_set_audio(const wipa_model_cfg* cfg, const void* con
         g.col_scale_n = d; g.col_scale = QK_SCALE;  // the key half; values stay unscaled
         g.rg_in = Ta; g.rg_valid = Ta; g.rg_stride = (int64_t)2 * H * Ta * 64;
         g.cg_in = 64; g.cg_stride = (int64_t)Ta * 64;
-        RT_CALL(gemm(features, d, lw[10], d, ckv, 64, B * Ta, 2 * d, d, dt, dt, (const float*)lw[11], 0, nullptr, stream, &g));
+        PROF(PROF_GEMM, gemm(features, d, lw[10], d, ckv, 64, B * Ta, 2 * d, d, dt, dt, (const float*)lw[11], 0, nullptr, stream, &g));
     }
     return WIPA_OK;
 }
@@ -454,6 +526,7 @@ extern "C" int wipa_decoder_set_audio(const wipa_model_cfg* cfg, const void* con
 extern "C" int wipa_decoder_begin(const wipa_model_cfg* cfg, void* state, int B, const int32_t* initial_tokens_host,
                                   int n_init, wipa_stream_t stream) {
     RT_CALL(cfg_check(cfg));
+    SplitScope split_scope(cfg);
     WIPA_REQUIRE(state && initial_tokens_host && n_init >= 1 && n_init <= 4 && B > 0,
                  "wipa_decoder_begin: need 1..4 prompt tokens (got %d)", n_init);
     const wipa_dec_layout L = dec_layout(cfg, B);
@@ -476,6 +549,7 @@ extern "C" int wipa_decoder_run(const wipa_model_cfg* cfg, const void* const* w,
                                 const float* mask_first, const float* mask_always, int n_steps, int use_graph,
                                 wipa_stream_t stream) {
     RT_CALL(cfg_check(cfg));
+    SplitScope split_scope(cfg);
     WIPA_REQUIRE(w && state && mask_first && mask_always && B > 0 && n_steps >= 0, "wipa_decoder_run: bad arguments");
     const wipa_dec_layout L = dec_layout(cfg, B);
     char* st = (char*)state;
@@ -487,7 +561,7 @@ extern "C" int wipa_decoder_run(const wipa_model_cfg* cfg, const void* const* w,
     }
     WIPA_REQUIRE(s != nullptr, "wipa_decoder_run: graph capture needs a non-default stream");
     hipGraphExec_t exec = nullptr;
-    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype, 0);
+    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split, cfg->weights_generation, 0);
     {
         std::lock_guard<std::mutex> lk(g_graph_mu);
         auto it = g_graphs.find(key);
@@ -515,6 +589,7 @@ extern "C" int wipa_decoder_run(const wipa_model_cfg* cfg, const void* const* w,
 extern "C" int wipa_decoder_prefill(const wipa_model_cfg* cfg, const void* const* w, void* state, int B, int n_init, int eot,
                                     const float* mask_first, const float* mask_always, int use_graph, wipa_stream_t stream) {
     RT_CALL(cfg_check(cfg));
+    SplitScope split_scope(cfg);
     WIPA_REQUIRE(w && state && mask_first && mask_always && B > 0, "wipa_decoder_prefill: bad arguments");
     WIPA_REQUIRE(n_init >= 1 && n_init <= MAX_PROMPT, "wipa_decoder_prefill: 1..%d prompt tokens (got %d)", MAX_PROMPT, n_init);
     const wipa_dec_layout L = dec_layout(cfg, B);
@@ -526,7 +601,7 @@ extern "C" int wipa_decoder_prefill(const wipa_model_cfg* cfg, const void* const
     hipStream_t s = (hipStream_t)stream;
     if (!use_graph || s == nullptr) return enqueue();
     hipGraphExec_t exec = nullptr;
-    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype, 1);
+    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split, cfg->weights_generation, 1);
     {
         std::lock_guard<std::mutex> lk(g_graph_mu);
         auto it = g_graphs.find(key);
@@ -594,6 +669,7 @@ extern "C" int wipa_decoder_logits(const wipa_model_cfg* cfg, const void* const*
                                    float* logits, int64_t ld_logits, void* workspace, size_t workspace_bytes, int B, int T,
                                    wipa_stream_t stream) {
     RT_CALL(cfg_check(cfg));
+    SplitScope split_scope(cfg);
     WIPA_REQUIRE(w && tokens && features && logits && workspace && B > 0 && T > 0, "wipa_decoder_logits: bad arguments");
     WIPA_REQUIRE(T <= cfg->n_text_ctx, "wipa_decoder_logits: T=%d exceeds n_text_ctx=%d", T, cfg->n_text_ctx);
     const TfWs L = tf_ws(cfg, B, T);

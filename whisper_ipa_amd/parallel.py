@@ -31,6 +31,15 @@ def shard_bounds(n_items: int, world_size: int, rank: int) -> Tuple[int, int]:
     return lo, min(lo + per, n_items)
 
 
+def require_even_shards(n_items: int, world_size: int) -> int:
+    """Items per rank of a data-parallel training batch.  The batch must split evenly: with ceil(n/world) shards the last
+    ranks of e.g. 12 clips on 8 GPUs would get nothing, fail to build a batch and leave the step's collectives mismatched."""
+    if world_size < 1 or n_items < world_size or n_items % world_size != 0:
+        lo, hi = max(world_size, n_items // world_size * world_size), (n_items // world_size + 1) * world_size
+        raise ValueError(f"batch size {n_items} must be a positive multiple of the {world_size} data-parallel ranks (e.g. {lo} or {hi})")
+    return n_items // world_size
+
+
 def shard_indices(indices: Sequence[int], world_size: int, rank: int) -> List[int]:
     """Rank r takes slice r of ONE shared draw (every rank must pass the same ``indices``), which keeps a
     DP step equivalent to the single-process ``np.random.choice`` batch (train_whisper_ipa.py:548)."""
@@ -59,33 +68,47 @@ def allreduce_loss_stats(sum_ce: torch.Tensor, n_valid: torch.Tensor, group=None
     return both[0], both[1]
 
 
-def bucketed(named: Dict[str, torch.Tensor], bucket_bytes: int = 64 << 20) -> Iterable[List[str]]:
-    """Group gradient tensors (insertion order = decoder block order) into buckets of about
-    ``bucket_bytes``: one RCCL call per bucket keeps each xGMI ring transfer large (7 links x ~153 GB/s,
-    per-link bound) while letting a bucket start as soon as its block's backward is done."""
-    cur, size = [], 0
-    for name, t in named.items():
-        nbytes = t.numel() * t.element_size()
-        if cur and size + nbytes > bucket_bytes:
-            yield cur
-            cur, size = [], 0
-        cur.append(name)
-        size += nbytes
-    if cur:
-        yield cur
+def _collective_device(group=None) -> torch.device:
+    import torch.distributed as dist
+
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
 
 
-def allreduce_grads(grads: Dict[str, torch.Tensor], bucket_bytes: int = 64 << 20, group=None) -> None:
-    """In-place SUM all-reduce of every gradient, one flat buffer per bucket."""
+def agree_on_step(token_width: int, failed: bool = False, group=None) -> int:
+    """One MAX all-reduce per training step that carries (a) whether ANY rank failed to build its batch and (b) the widest
+    token matrix.  Returns the global width, or -1 when some rank failed -- every rank gets the same answer, so all of
+    them leave the step loop together instead of one rank abandoning the others inside the gradient all-reduce."""
     import torch.distributed as dist
 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return
-    for names in bucketed(grads, bucket_bytes):
-        flat = torch.cat([grads[n].reshape(-1) for n in names])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        off = 0
-        for n in names:
-            k = grads[n].numel()
-            grads[n].copy_(flat[off:off + k].view_as(grads[n]))
-            off += k
+        return -1 if failed else int(token_width)
+    t = torch.tensor([1 if failed else 0, int(token_width)], dtype=torch.int64, device=_collective_device(group))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    flag, width = (int(v) for v in t.tolist())
+    return -1 if flag else width
+
+
+class SegmentReducer:
+    """Asynchronous SUM all-reduce of finished segments of ONE flat gradient buffer.
+
+    The backward pass of the decoder finishes its gradient segments from the back ([final ln], block L-1, ..., block 0,
+    [embeddings]); each is handed to ``reduce(lo, hi)`` as soon as it is complete and travels over RCCL while the earlier
+    blocks are still computing.  Segments are large and contiguous (one decoder block = 7.1 M .. 28 M floats), which is
+    what a ring over point-to-point xGMI links wants.  ``wait()`` joins them in issue order.  Single process: no-ops."""
+
+    def __init__(self, flat: torch.Tensor, group=None):
+        self.flat, self.group, self.pending = flat, group, []
+        self.active = world()[1] > 1
+
+    def reduce(self, lo: int, hi: int) -> None:
+        if self.active and hi > lo:
+            import torch.distributed as dist
+
+            self.pending.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self) -> int:
+        n = len(self.pending)
+        for work in self.pending:
+            work.wait()
+        self.pending = []
+        return n

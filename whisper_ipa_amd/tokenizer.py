@@ -8,8 +8,9 @@ The byte-level BPE is implemented here (host side, pure Python).  The rank table
 (``multilingual.tiktoken``: base64 token -> rank per line, 50 257 ranks) is an asset of
 mlx_whisper that is NOT in the reference tree nor in this image; pass its path as
 ``vocab_path`` or set ``WIPA_TIKTOKEN``.  Without it the tokenizer runs in *byte-fallback*
-mode (ranks 0..255 = raw bytes, no merges): framing, special ids and round trips still
-work, real Whisper ids do not.
+mode: the 256 byte-level ranks of the GPT-2 vocabulary family (which are Whisper's ids for every
+character it has no merge for -- most IPA symbols) and no merges: framing, special ids, round trips
+and the unmerged known answers of the reference hold; merged ids ('ə' -> [7250]) do not.
 """
 from __future__ import annotations
 
@@ -191,7 +192,51 @@ def get_tokenizer(multilingual: bool = True, *, num_languages: int = 99, languag
     language = language or "en"
     task = task or "transcribe"
     path = vocab_path or os.environ.get("WIPA_TIKTOKEN")
-    if path and os.path.exists(path):
+    if path:
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"Whisper vocabulary {path!r} (vocab_path / WIPA_TIKTOKEN) does not exist")
         return Tokenizer(load_tiktoken_ranks(path), num_languages, language, task, byte_fallback=False)
-    ranks = {bytes([b]): b for b in range(256)}
-    return Tokenizer(ranks, num_languages, language, task, byte_fallback=True)
+    _warn_byte_fallback()
+    return Tokenizer(gpt2_byte_ranks(), num_languages, language, task, byte_fallback=True)
+
+
+def gpt2_byte_ranks() -> Dict[bytes, int]:
+    """Ranks 0..255 of the byte-level BPE vocabularies of the GPT-2 family (Whisper's multilingual.tiktoken included): the
+    printable non-space Latin-1 bytes first (33..126, 161..172, 174..255 -> 0..187), then the remaining bytes in order
+    (-> 188..255).  These ARE Whisper's ids for every character the vocabulary has no merge for -- which is most of IPA:
+    the reference's known answers 'p' -> [79], 'ɪ' -> [133, 103], 'tʰ' -> [83, 134, 108], 'n̩' -> [77, 136, 102]
+    (WHISPER_IPA_RESEARCH_STANDALONE.md:280-305,498-505) and the blank token ' ' -> 220 follow from this table alone."""
+    order = list(range(33, 127)) + list(range(161, 173)) + list(range(174, 256))
+    order += [b for b in range(256) if b not in set(order)]
+    return {bytes([b]): i for i, b in enumerate(order)}
+
+
+_warned = False
+
+
+def _warn_byte_fallback() -> None:
+    global _warned
+    if not _warned:
+        _warned = True
+        import sys
+
+        print("WARNING: no Whisper vocabulary (set WIPA_TIKTOKEN to mlx_whisper's assets/multilingual.tiktoken): the tokenizer "
+              "runs in BYTE-FALLBACK mode -- text is tokenised byte by byte (Whisper's byte-level ids, no merges: e.g. 'ə' -> "
+              "[133, 247] instead of [7250]); special ids, framing and the decode loop are unaffected.  Fine for synthetic "
+              "weights, WRONG for a pretrained checkpoint.", file=sys.stderr, flush=True)
+
+
+class VocabularyError(RuntimeError):
+    pass
+
+
+def require_real_vocabulary(tok: Tokenizer, allow_byte_fallback: bool = False, what: str = "this run") -> Tokenizer:
+    """Entry points that pair the tokenizer with REAL weights (fine-tuning, evaluation, transcription) call this: a
+    pretrained Whisper must not be trained or scored on byte-fallback ids by accident.  ``allow_byte_fallback`` (the
+    scripts' --allow-byte-fallback, or WIPA_ALLOW_BYTE_FALLBACK=1) is the explicit opt-in for synthetic-weight runs."""
+    if tok.byte_fallback and not (allow_byte_fallback or os.environ.get("WIPA_ALLOW_BYTE_FALLBACK") == "1"):
+        raise VocabularyError(
+            f"{what}: the Whisper vocabulary is missing (WIPA_TIKTOKEN is unset), so text would be tokenised as raw bytes, not "
+            "Whisper BPE ids.  Point WIPA_TIKTOKEN at multilingual.tiktoken, or pass --allow-byte-fallback for a run on "
+            "synthetic weights.")
+    return tok

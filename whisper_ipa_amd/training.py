@@ -34,13 +34,15 @@ def _ceil(x: int, m: int) -> int:
 
 class DecoderTrainer:
     def __init__(self, model: Whisper, lr: float = 1e-5, max_grad_norm: float = 1.0, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 0.01):
+                 weight_decay: float = 0.01, f32_split: Optional[bool] = None):
+        """``f32_split`` (default: the model's setting, i.e. off): split-bf16 products in the large GEMMs of the step."""
         if model.dtype != torch.float32:
             raise _lib.WipaError("DecoderTrainer: the fine-tune step runs in float32 (reference: set_dtype(mx.float32))")
         self.model, self.lr, self.max_grad_norm = model, lr, max_grad_norm
         self.b1, self.b2 = betas
         self.eps, self.wd = eps, weight_decay
         self.L = _lib.lib()
+        self.f32_split = model.f32_split if f32_split is None else bool(f32_split)
         d = model.dims
         self.names = [n for n in parameter_names(d) if n.startswith("decoder.")]
         P = model.flat_parameters()
@@ -102,10 +104,13 @@ class DecoderTrainer:
         return {n: self.g(n) for n in self.names}
 
     # ---- kernel helpers (all on the library stream)
+    def _gemm(self, *a, **kw):
+        return ops.gemm(*a, f32_split=self.f32_split, **kw)
+
     def _lin(self, x, M, K, W, N, bias=None, scale=None, residual=None, out=None):
         """out[M,N] = (x[M,K] W[N,K]^T + bias) * scale (+ residual)"""
         out = torch.empty(x.shape[0], N, dtype=torch.float32, device=x.device) if out is None else out
-        ops.gemm(x, W, out, M=M, N=N, K=K, lda=x.stride(0), ldw=W.stride(0), ldc=out.stride(0), bias=bias,
+        self._gemm(x, W, out, M=M, N=N, K=K, lda=x.stride(0), ldw=W.stride(0), ldc=out.stride(0), bias=bias,
                  residual=residual, col_scale_n=(N if scale is not None else 0), col_scale=(scale or 1.0))
         return out
 
@@ -127,7 +132,7 @@ class DecoderTrainer:
             WT = self._transpose(W, N, K, Np)  # [K, Np]
             out_dx = dx if dx is not None else torch.empty(dy.shape[0], K, dtype=torch.float32, device=dy.device)
             # contraction over n: A = dy (row stride ld, first Np columns must be readable and zero beyond N)
-            ops.gemm(dy, WT, out_dx, M=M, N=K, K=Np, lda=dy.stride(0), ldw=Np, ldc=out_dx.stride(0),
+            self._gemm(dy, WT, out_dx, M=M, N=K, K=Np, lda=dy.stride(0), ldw=Np, ldc=out_dx.stride(0),
                      residual=(out_dx if accumulate_dx else None))
         dyT = self._transpose(dy, M, N, Mp)  # [N, Mp]
         if xT is None:
@@ -140,11 +145,11 @@ class DecoderTrainer:
             need = slices * N * K
             if self._dw_slabs is None or self._dw_slabs.numel() < need:
                 self._dw_slabs = torch.empty(need, dtype=torch.float32, device=dy.device)
-            ops.gemm(dyT, xT, self._dw_slabs, M=N, N=K, K=Mp, lda=Mp, ldw=xT.stride(0), ldc=K, k_slices=slices, slab_stride=N * K)
+            self._gemm(dyT, xT, self._dw_slabs, M=N, N=K, K=Mp, lda=Mp, ldw=xT.stride(0), ldc=K, k_slices=slices, slab_stride=N * K)
             with on_stream() as s:
                 _lib.check(self.L.wipa_sum_slabs(ptr(self._dw_slabs), slices, N * K, ptr(dW), N * K, 0, sptr(s)), "wipa_sum_slabs")
         else:
-            ops.gemm(dyT, xT, dW, M=N, N=K, K=Mp, lda=Mp, ldw=xT.stride(0), ldc=dW.stride(0))
+            self._gemm(dyT, xT, dW, M=N, N=K, K=Mp, lda=Mp, ldw=xT.stride(0), ldc=dW.stride(0))
         if db is not None:
             with on_stream() as s:
                 if self._colsum_ws is None:
@@ -232,7 +237,7 @@ class DecoderTrainer:
             hf = self._ln(x_L, P("decoder.ln.weight"), P("decoder.ln.bias"))
             E = P("decoder.token_embedding.weight")
             logits = torch.zeros(Mp, Vp, dtype=torch.float32, device=dev)  # padding rows/cols stay zero
-            ops.gemm(hf, E, logits, M=M, N=V, K=d, lda=d, ldw=d, ldc=Vp)
+            self._gemm(hf, E, logits, M=M, N=V, K=d, lda=d, ldw=d, ldc=Vp)
             row_buf = torch.empty(2 * M, dtype=torch.float32, device=dev)
             stats = torch.empty(2, dtype=torch.float32, device=dev)
             _lib.check(L.wipa_masked_ce(ptr(logits), Vp, ptr(tok), T1, B, T, V, eot, ptr(row_buf), ptr(stats), sptr(s)),
@@ -250,22 +255,19 @@ class DecoderTrainer:
             # logits = hf E^T : dhf = dlogits E ; dE = dlogits^T hf
             ET = self._transpose(E, V, d, Vp)  # [d, Vp]
             dhf = torch.empty(M, d, dtype=torch.float32, device=dev)
-            ops.gemm(dlogits, ET, dhf, M=M, N=d, K=Vp, lda=Vp, ldw=Vp, ldc=d)
+            self._gemm(dlogits, ET, dhf, M=M, N=d, K=Vp, lda=Vp, ldw=Vp, ldc=d)
             dlT = self._transpose(dlogits, M, V, Mp)  # [V, Mp]
             hfT = self._transpose(hf, M, d, Mp)
-            ops.gemm(dlT, hfT, G("decoder.token_embedding.weight"), M=V, N=d, K=Mp, lda=Mp, ldw=Mp, ldc=d)
+            self._gemm(dlT, hfT, G("decoder.token_embedding.weight"), M=V, N=d, K=Mp, lda=Mp, ldw=Mp, ldc=d)
             del dlT, logits, dlogits
             dx = torch.empty(M, d, dtype=torch.float32, device=dev)
             self._ln_bwd(x_L, dhf, P("decoder.ln.weight"), dx, False, G("decoder.ln.weight"), G("decoder.ln.bias"), M, d)
             # DP: each finished gradient segment is all-reduced (SUM; every rank already divided by the GLOBAL
             # count) asynchronously on RCCL's stream while the earlier blocks are still in their backward
-            pending = []
+            reducer = parallel.SegmentReducer(self.flat_g, group)
 
             def reduce_segment(rng):
-                if parallel.world()[1] > 1 and rng[1] > rng[0]:
-                    import torch.distributed as dist
-
-                    pending.append(dist.all_reduce(self.flat_g[rng[0]:rng[1]], op=dist.ReduceOp.SUM, group=group, async_op=True))
+                reducer.reduce(rng[0], rng[1])
 
             reduce_segment(self.tail_range)
             for l in reversed(range(dm.n_text_layer)):
@@ -314,9 +316,25 @@ class DecoderTrainer:
             if T < dm.n_text_ctx:
                 G("decoder.positional_embedding")[T:].zero_()
             reduce_segment(self.head_range)
-            for work in pending:
-                work.wait()
+            # the time the compute stream stalls here is the all-reduce time the backward did NOT hide
+            self._ar_events = None
+            if reducer.pending:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(s)
+                reducer.wait()
+                e1.record(s)
+                self._ar_events = (e0, e1)
         return loss, sum_ce, n_valid
+
+    @property
+    def last_allreduce_exposed_ms(self) -> float:
+        """Exposed (not overlapped with the backward) gradient all-reduce time of the last step, from HIP events on the
+        compute stream around the final waits; 0 for a single process.  Synchronises."""
+        ev = getattr(self, "_ar_events", None)
+        if not ev:
+            return 0.0
+        ev[1].synchronize()
+        return float(ev[0].elapsed_time(ev[1]))
 
     def apply_update(self) -> None:
         """per-tensor clip + AdamW on the flat buffers (flat_g becomes the clipped gradient)."""

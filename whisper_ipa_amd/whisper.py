@@ -87,9 +87,13 @@ class _Part:
 
 
 class Whisper:
-    def __init__(self, dims: ModelDimensions, dtype: torch.dtype = torch.float32):
+    def __init__(self, dims: ModelDimensions, dtype: torch.dtype = torch.float32, f32_split: bool = False):
+        """``f32_split`` (float32 models only): let the large GEMMs and the encoder attention take every f32 product as
+        split-bf16 MFMA terms (about twice as fast, ~5e-6 relative error per dot product).  Off by default: the reference
+        computes in true float32 (train_whisper_ipa.py:505, transcribe_single.py:13)."""
         self.dims = dims
         self.dtype = dtype
+        self.f32_split = bool(f32_split)
         self.device = device()
         _lib.lib()  # fail now if the extension is missing
         self._params: Dict[str, torch.Tensor] = {}
@@ -161,13 +165,22 @@ class Whisper:
         return self
 
     def _invalidate(self):
+        """The weight tensors changed (load / update / dtype / optimiser step): drop the packed tables AND every decode-step
+        graph captured against them -- a graph holds the device pointers of the fused q|k|v matrices that die with the old
+        tables, and the table's host address alone (part of the graph key) can be reused by the next one."""
+        if self._packed is not None or getattr(self, "_dec_states", None):
+            torch.cuda.synchronize(self.device)  # nothing may still be replaying a graph we are about to destroy
+        for st in getattr(self, "_dec_states", {}).values():
+            st.release()
+        self._generation = (getattr(self, "_generation", 0) + 1) & 0x7FFFFFFF
         self._packed = None
 
     # ---- packing -------------------------------------------------------------------
     def _cfg(self) -> _lib.ModelCfg:
         d = self.dims
         return _lib.ModelCfg(d.n_mels, d.n_audio_ctx, d.n_audio_state, d.n_audio_head, d.n_audio_layer, d.n_vocab,
-                             d.n_text_ctx, d.n_text_state, d.n_text_head, d.n_text_layer, dt_code(self.dtype), 0)
+                             d.n_text_ctx, d.n_text_state, d.n_text_head, d.n_text_layer, dt_code(self.dtype),
+                             int(self.f32_split and self.dtype == torch.float32), getattr(self, "_generation", 0))
 
     def packed(self):
         """(cfg, encoder table, decoder table); fused matrices are rebuilt after any update."""
