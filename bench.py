@@ -435,7 +435,10 @@ def launch_ranks(n: int, argv) -> int:
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out, _ = procs[0].communicate()
     rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    # stdout carries the JSON line only: anything else a rank's libraries printed there (gloo's connection banner in the
+    # one-GPU rehearsal) goes to stderr
+    for line in out.decode().splitlines():
+        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     return max(abs(rc) for rc in rcs)
 
