@@ -96,6 +96,14 @@ typedef struct wipa_gemm_desc {
                         * 1: every product a*w is taken as three bf16 MFMA terms on operands split into hi + lo
                         * (a_hi*w_lo + a_lo*w_hi + a_hi*w_hi, f32 accumulation): about twice the rate at ~5e-6 relative error
                         * of a K = 768 dot product (f32 MFMA: ~1.5e-6).  The weight-streaming kernel always multiplies exactly. */
+    /* LayerNorm prologue (decode step: mlp_ln folded into mlp1).  ln_x != NULL: A is ignored and the A operand is
+     * LayerNorm(ln_x[m, 0:K]; ln_w, ln_b, ln_eps) rounded to the input dtype, computed inside the kernel from the f32 rows
+     * ln_x + m*ln_ldx.  Weight-streaming kernel only: M <= 1024, K a multiple of 64 and <= 1280, no k_slices. */
+    const float* ln_x;
+    const float* ln_w;
+    const float* ln_b;
+    int64_t ln_ldx;
+    float ln_eps;
     int32_t stream_weights; /* 1: the rows are decode rows (one or a few per clip) and W is a weight matrix: use the
                              * weight-streaming kernel up to M = 1024 instead of 256, so that a prompt prefill of
                              * 4 rows per clip rounds exactly like the single-row steps (batch invariance) */
@@ -172,6 +180,54 @@ int wipa_decode_cross_attn(const void* q, const void* kv, void* out, int B, int 
 /* n_q (1..4) query rows per clip against the same cache: q / out [B*n_q, H*64] rows (b, t); every K/V row is read once. */
 int wipa_decode_cross_attn_multi(const void* q, const void* kv, void* out, int B, int H, int Tk, int n_q, int dtype,
                                  wipa_stream_t s);
+
+/* ------------------------------------------------------------------ fused decode-step blocks (K11 / K12)
+ * One decode step of mlx_whisper's ResidualAttentionBlock with a KV cache (DecodingTask._main_loop,
+ * transcribe_single.py:55) in 5 launches per layer instead of 11: see csrc/decode_fused.hip.
+ *
+ * self block, one workgroup per (head, 16 token rows):
+ *   y = LayerNorm(x[b]; ln_w, ln_b) -> (q|k|v)_h = y Wqkv[h]^T + b (q, k scaled by qk_scale, rounded to T) -> k, v appended to
+ *   the caches at position *pos -> o_h = softmax(q_h K_h^T) V_h over positions 0..*pos -> slabs[h][b][:] = o_h Wo[:, h*64:(h+1)*64]^T.
+ * x [B, d] f32; wqkv [3d, d] T (query | key | value rows), bqkv [3d]; wo [d, d] T; kcache / vcache T [B][n_ctx][d]
+ * (kv_batch_stride = n_ctx * d elements); slabs f32 [H][B][d] with slab_stride >= B*d elements.  The residual update
+ * x + bias_o + sum_h slabs[h] is left to wipa_decode_cross_block. */
+typedef struct wipa_self_block_desc {
+    const float* x;
+    const float* ln_w;
+    const float* ln_b;
+    const void* wqkv;
+    const float* bqkv;
+    const void* wo;
+    void* kcache;
+    void* vcache;
+    const int32_t* pos; /* device */
+    float* slabs;
+    int64_t kv_batch_stride, slab_stride;
+    int32_t B, d, H, dtype;
+    float eps, qk_scale;
+} wipa_self_block_desc;
+int wipa_decode_self_block(const wipa_self_block_desc* d, wipa_stream_t s);
+/* cross block, one workgroup per (head, clip):
+ *   r = x_in[b] + bias_o + slabs[0][b] + ... + slabs[n_slabs-1][b] (that order; the h = 0 workgroup stores r to x_out[b]) ->
+ *   y = LayerNorm(r; ln_w, ln_b) -> q_h = (y Wq[h]^T + bq) * qk_scale (rounded to T) -> out[b][h*64:(h+1)*64] =
+ *   softmax(q_h K^T) V over the cached cross keys/values kv [B][2H][Tk][64] T (K heads then V heads; every element read
+ *   once, non-temporal).  x_out must not alias x_in.  n_slabs <= 20. */
+typedef struct wipa_cross_block_desc {
+    const float* x_in;
+    float* x_out;
+    const float* slabs;
+    const float* bias_o;
+    const float* ln_w;
+    const float* ln_b;
+    const void* wq;
+    const float* bq;
+    const void* kv;
+    void* out;
+    int64_t slab_stride;
+    int32_t n_slabs, B, d, H, Tk, dtype;
+    float eps, qk_scale;
+} wipa_cross_block_desc;
+int wipa_decode_cross_block(const wipa_cross_block_desc* d, wipa_stream_t s);
 
 /* ------------------------------------------------------------------ K13 greedy step
  * GreedyDecoder.update + SuppressBlank + SuppressTokens of mlx_whisper.decoding

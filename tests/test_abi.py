@@ -53,6 +53,9 @@ def test_struct_layouts_match_c(built, tmp_path):
         'printf("%zu %zu %zu %zu\\n", sizeof(wipa_gemm_desc), sizeof(wipa_attn_desc), sizeof(wipa_model_cfg), sizeof(wipa_dec_layout));\n'
         'printf("%zu %zu %zu %zu\\n", offsetof(wipa_gemm_desc, lda), offsetof(wipa_gemm_desc, M), offsetof(wipa_gemm_desc, col_scale), offsetof(wipa_gemm_desc, cg_in));\n'
         'printf("%zu %zu %zu\\n", offsetof(wipa_attn_desc, q_bs), offsetof(wipa_attn_desc, B), offsetof(wipa_attn_desc, dtype));\n'
+        'printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(wipa_self_block_desc), sizeof(wipa_cross_block_desc), offsetof(wipa_self_block_desc, B), '
+        'offsetof(wipa_self_block_desc, qk_scale), offsetof(wipa_cross_block_desc, n_slabs), offsetof(wipa_cross_block_desc, qk_scale), '
+        'offsetof(wipa_gemm_desc, ln_eps));\n'
         "return 0;}\n"
     )
     exe = tmp_path / "lay"
@@ -64,6 +67,10 @@ def test_struct_layouts_match_c(built, tmp_path):
     assert g == [built.GemmDesc.lda.offset, built.GemmDesc.M.offset, built.GemmDesc.col_scale.offset, built.GemmDesc.cg_in.offset]
     a = [int(x) for x in out[2].split()]
     assert a == [built.AttnDesc.q_bs.offset, built.AttnDesc.B.offset, built.AttnDesc.dtype.offset]
+    f = [int(x) for x in out[3].split()]
+    assert f == [C.sizeof(built.SelfBlockDesc), C.sizeof(built.CrossBlockDesc), built.SelfBlockDesc.B.offset,
+                 built.SelfBlockDesc.qk_scale.offset, built.CrossBlockDesc.n_slabs.offset, built.CrossBlockDesc.qk_scale.offset,
+                 built.GemmDesc.ln_eps.offset]
 
 
 def test_missing_library_fails_loudly(monkeypatch, built):

@@ -325,3 +325,152 @@ def test_masked_ce(ops):
     ref_sum = float((ce * mask.reshape(-1)).sum())
     assert abs(float(out[0]) - ref_sum) / ref_sum < 1e-5
     assert int(out[1]) == int(mask.sum())
+
+
+# ------------------------------------------------------------------ fused decode-step blocks (csrc/decode_fused.hip)
+def _ln_ref(x, w, b, eps=1e-5):
+    x = x.double()
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * w.double() + b.double()
+
+
+def _rt(x, dtype):
+    """round through the storage dtype, back to float64"""
+    return x.to(torch.float32).to(dtype).double()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,pos", [(5, 2, 0), (16, 2, 7), (37, 3, 70), (64, 12, 200), (3, 20, 447)])
+def test_decode_self_block(dtype, B, H, pos):
+    """LayerNorm -> q|k|v of one head -> cache append -> self-attention -> out-projection slab, against a float64 statement
+    with the same rounding points (LN output, q, k, v and the attention output are stored as T)."""
+    import ctypes as C
+
+    from whisper_ipa_amd import _lib
+    from whisper_ipa_amd.runtime import dt_code, on_stream, ptr, sptr
+
+    L = _lib.lib()
+    d, nctx = H * 64, 448
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + pos)
+    x = torch.randn(B, d, generator=g) * 1.5
+    ln_w, ln_b = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    wqkv = (torch.randn(3 * d, d, generator=g) * 0.06).to(dtype)
+    bqkv = torch.randn(3 * d, generator=g) * 0.1
+    bqkv[d:2 * d] = 0
+    wo = (torch.randn(d, d, generator=g) * 0.06).to(dtype)
+    kc = (torch.randn(B, nctx, d, generator=g) * 0.5).to(dtype)
+    vc = torch.randn(B, nctx, d, generator=g).to(dtype)
+    scale = 64 ** -0.25
+    with on_stream() as s:
+        dev = [t.cuda() for t in (x, ln_w, ln_b, wqkv, bqkv, wo, kc, vc)]
+        xd, lwd, lbd, wqkvd, bqkvd, wod, kcd, vcd = dev
+        posd = torch.tensor([pos], dtype=torch.int32, device="cuda")
+        slabs = torch.full((H, B, d), 7.0, device="cuda")
+        a = _lib.SelfBlockDesc()
+        a.x, a.ln_w, a.ln_b, a.wqkv, a.bqkv, a.wo = ptr(xd), ptr(lwd), ptr(lbd), ptr(wqkvd), ptr(bqkvd), ptr(wod)
+        a.kcache, a.vcache, a.pos, a.slabs = ptr(kcd), ptr(vcd), ptr(posd), ptr(slabs)
+        a.kv_batch_stride, a.slab_stride = nctx * d, B * d
+        a.B, a.d, a.H, a.dtype, a.eps, a.qk_scale = B, d, H, dt_code(dtype), 1e-5, scale
+        _lib.check(L.wipa_decode_self_block(C.byref(a), sptr(s)), "wipa_decode_self_block")
+    torch.cuda.synchronize()
+    y = _rt(_ln_ref(x, ln_w, ln_b), dtype)
+    qkv = y @ wqkv.double().T + bqkv.double()
+    q, k, v = _rt(qkv[:, :d] * scale, dtype), _rt(qkv[:, d:2 * d] * scale, dtype), _rt(qkv[:, 2 * d:], dtype)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    # the new K/V row sits at `pos`, everything else in the caches is untouched
+    assert _rel(kcd[:, pos], k) < tol and _rel(vcd[:, pos], v) < tol
+    keep = torch.ones(nctx, dtype=torch.bool)
+    keep[pos] = False
+    assert torch.equal(kcd.cpu()[:, keep], kc[:, keep]) and torch.equal(vcd.cpu()[:, keep], vc[:, keep])
+    K = torch.cat([kc[:, :pos].double(), k[:, None]], 1).view(B, pos + 1, H, 64)
+    V = torch.cat([vc[:, :pos].double(), v[:, None]], 1).view(B, pos + 1, H, 64)
+    sc = torch.einsum("bhd,bthd->bht", q.view(B, H, 64), K)
+    o = _rt(torch.einsum("bht,bthd->bhd", torch.softmax(sc, -1), V), dtype)  # [B, H, 64]
+    ref = torch.einsum("bhj,hnj->hbn", o, wo.double().view(d, H, 64).permute(1, 0, 2))  # slab h = o_h @ Wo[:, h]^T
+    assert _rel(slabs, ref) < (2e-5 if dtype == torch.float32 else 3e-2), _rel(slabs, ref)
+    # the sum over heads is the whole out projection
+    full = o.reshape(B, d) @ wo.double().T
+    assert _rel(slabs.double().sum(0), full) < (2e-5 if dtype == torch.float32 else 3e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,Tk", [(3, 2, 1500), (64, 12, 1500), (5, 20, 97), (17, 6, 8)])
+def test_decode_cross_block(dtype, B, H, Tk):
+    """residual + bias + head slabs -> LayerNorm -> cross query -> streaming cross-attention, against float64."""
+    import ctypes as C
+
+    from whisper_ipa_amd import _lib
+    from whisper_ipa_amd.runtime import dt_code, on_stream, ptr, sptr
+
+    L = _lib.lib()
+    d = H * 64
+    g = torch.Generator().manual_seed(B * 100 + H + Tk)
+    x = torch.randn(B, d, generator=g)
+    slabs = torch.randn(H, B, d, generator=g) * 0.3
+    bo = torch.randn(d, generator=g) * 0.1
+    ln_w, ln_b = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    wq = (torch.randn(d, d, generator=g) * 0.06).to(dtype)
+    bq = torch.randn(d, generator=g) * 0.1
+    kv = torch.randn(B, 2 * H, Tk, 64, generator=g).to(dtype)
+    kv[:, :H] *= 0.5
+    scale = 64 ** -0.25
+    with on_stream() as s:
+        xd, sd, bod, lwd, lbd, wqd, bqd, kvd = [t.cuda() for t in (x, slabs, bo, ln_w, ln_b, wq, bq, kv)]
+        x_out = torch.full((B, d), 7.0, device="cuda")
+        out = torch.zeros(B, d, device="cuda", dtype=dtype)
+        c = _lib.CrossBlockDesc()
+        c.x_in, c.x_out, c.slabs, c.bias_o, c.ln_w, c.ln_b = ptr(xd), ptr(x_out), ptr(sd), ptr(bod), ptr(lwd), ptr(lbd)
+        c.wq, c.bq, c.kv, c.out = ptr(wqd), ptr(bqd), ptr(kvd), ptr(out)
+        c.slab_stride = B * d
+        c.n_slabs, c.B, c.d, c.H, c.Tk, c.dtype, c.eps, c.qk_scale = H, B, d, H, Tk, dt_code(dtype), 1e-5, scale
+        _lib.check(L.wipa_decode_cross_block(C.byref(c), sptr(s)), "wipa_decode_cross_block")
+        # aliasing the residual buffers is refused (H workgroups read the row that one of them writes)
+        c.x_out = c.x_in
+        assert L.wipa_decode_cross_block(C.byref(c), sptr(s)) != 0
+    torch.cuda.synchronize()
+    r = x.double() + bo.double() + slabs.double().sum(0)
+    assert _rel(x_out, r) < 2e-6
+    y = _rt(_ln_ref(r, ln_w, ln_b), dtype)
+    q = _rt((y @ wq.double().T + bq.double()) * scale, dtype).view(B, H, 64)
+    Kc, Vc = kv[:, :H].double(), kv[:, H:].double()
+    sc = torch.einsum("bhd,bhtd->bht", q, Kc)
+    ref = torch.einsum("bht,bhtd->bhd", torch.softmax(sc, -1), Vc).reshape(B, d)
+    assert _rel(out, ref) < (2e-5 if dtype == torch.float32 else 2e-2), _rel(out, ref)
+
+
+@pytest.mark.parametrize("in_dtype,out_dtype", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16),
+                                                (torch.bfloat16, torch.float32)])
+@pytest.mark.parametrize("M,N,K,act", [(64, 3072, 768, 1), (5, 200, 128, 0), (100, 1536, 384, 1), (256, 4096, 1024, 1),
+                                       (33, 640, 1280, 0)])
+def test_gemm_layernorm_prologue(ops, in_dtype, out_dtype, M, N, K, act):
+    """wipa_gemm with ln_x: A = LayerNorm(rows of the f32 residual stream) computed inside the weight-streaming kernel."""
+    import ctypes as C
+
+    from whisper_ipa_amd import _lib
+    from whisper_ipa_amd.runtime import dt_code, on_stream, ptr, sptr
+
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K + 8, generator=g)[:, :K] * 2 + 0.3  # row stride K + 8
+    ln_w, ln_b = 1 + 0.1 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+    W = (torch.randn(N, K, generator=g) * 0.05).to(in_dtype)
+    bias = torch.randn(N, generator=g) * 0.1
+    with on_stream() as s:
+        xd = torch.empty(M, K + 8, device="cuda")
+        xd[:, :K] = x.cuda()
+        lwd, lbd, Wd, bd = ln_w.cuda(), ln_b.cuda(), W.cuda(), bias.cuda()
+        out = torch.full((M, N), 7.0, device="cuda", dtype=out_dtype)
+        dsc = _lib.GemmDesc()
+        dsc.W, dsc.C, dsc.bias = ptr(Wd), ptr(out), ptr(bd)
+        dsc.ln_x, dsc.ln_w, dsc.ln_b, dsc.ln_ldx, dsc.ln_eps = ptr(xd), ptr(lwd), ptr(lbd), K + 8, 1e-5
+        dsc.lda, dsc.ldw, dsc.ldc = K, K, N
+        dsc.M, dsc.N, dsc.K, dsc.in_dtype, dsc.out_dtype, dsc.act = M, N, K, dt_code(in_dtype), dt_code(out_dtype), act
+        _lib.check(L.wipa_gemm(C.byref(dsc), sptr(s)), "wipa_gemm(ln prologue)")
+    torch.cuda.synchronize()
+    y = _rt(_ln_ref(x, ln_w, ln_b), in_dtype)
+    ref = y @ W.double().T + bias.double()
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    tol = 1e-5 if in_dtype == torch.float32 else (2e-2 if out_dtype == torch.bfloat16 else 5e-3)
+    assert _rel(out, ref) < tol, _rel(out, ref)

@@ -206,6 +206,42 @@ def test_prompt_prefill_equals_stepwise_prompt(micro, monkeypatch, dtype):
         assert (c.tokens == d.tokens).all()
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_decode_step_equals_unfused_step(micro, small2, monkeypatch, dtype):
+    """The fused decode step (csrc/decode_fused.hip: 5 launches per layer) against the unfused one (11 launches per layer,
+    WIPA_DECODE_FUSED=0): same ids, same log-probabilities, same last-step logits up to summation order -- on the micro model
+    and at whisper-small width, graph replay and eager."""
+    from whisper_ipa_amd.decoding import greedy_decode_tokens
+
+    sp = R.SpecialTokens.multilingual()
+    always, first = R.suppress_lists(sp)
+    init = list(sp.sot_sequence_including_notimestamps(0))
+    for dims, (W, mels, xa), n_new in ((MICRO, micro, 40), (SMALL2, small2, 12)):
+        m = _model(dims, W, dtype)
+        feats = xa.cuda().to(dtype)
+        out = {}
+        for fused in ("1", "0"):
+            monkeypatch.setenv("WIPA_DECODE_FUSED", fused)
+            for use_graph in (True, False):
+                r = greedy_decode_tokens(m, feats, init, always, first, sp.eot, max_new_tokens=n_new, stop_on_eot=False,
+                                         use_graph=use_graph)
+                out[(fused, use_graph)] = (r.tokens, r.sum_logprobs.copy(), r.last_logits.float().cpu().clone())
+        monkeypatch.delenv("WIPA_DECODE_FUSED")
+        a, b = out[("1", True)], out[("0", True)]
+        assert (a[0] == out[("1", False)][0]).all() and torch.equal(a[2], out[("1", False)][2])  # graph == eager, bit for bit
+        if dtype == torch.float32:
+            assert (a[0] == b[0]).all(), (a[0].tolist(), b[0].tolist())
+            assert np.abs(a[1] - b[1]).max() < 1e-3 and (a[2] - b[2]).abs().max() < 2e-4
+        else:
+            # bf16 rounding points are the same but the f32 summation order inside a projection differs, which can move a
+            # stored bf16 value by one ulp: ids agree up to the first near-tie
+            same = np.cumprod(a[0] == b[0], axis=1).astype(bool)
+            assert same[:, : 4 + 6].all(), (a[0].tolist(), b[0].tolist())
+            rows = same.all(axis=1)
+            if rows.any():
+                assert (a[2][rows] - b[2][rows]).abs().max() < 0.25
+
+
 def test_detect_language_matches_oracle(micro):
     from whisper_ipa_amd.decoding import detect_language
     from whisper_ipa_amd.tokenizer import get_tokenizer

@@ -31,7 +31,29 @@ class GemmDesc(C.Structure):
         ("rg_in", C.c_int32), ("rg_valid", C.c_int32), ("cg_in", C.c_int32),
         ("zero_invalid_rows", C.c_int32), ("bias_along_m", C.c_int32), ("act", C.c_int32),
         ("col_scale_n", C.c_int32), ("col_scale", c_float), ("k_slices", C.c_int32),
-        ("f32_split", C.c_int32), ("stream_weights", C.c_int32),
+        ("f32_split", C.c_int32),
+        ("ln_x", c_void_p), ("ln_w", c_void_p), ("ln_b", c_void_p), ("ln_ldx", c_int64), ("ln_eps", c_float),
+        ("stream_weights", C.c_int32),
+    ]
+
+
+class SelfBlockDesc(C.Structure):
+    _fields_ = [
+        ("x", c_void_p), ("ln_w", c_void_p), ("ln_b", c_void_p), ("wqkv", c_void_p), ("bqkv", c_void_p), ("wo", c_void_p),
+        ("kcache", c_void_p), ("vcache", c_void_p), ("pos", c_void_p), ("slabs", c_void_p),
+        ("kv_batch_stride", c_int64), ("slab_stride", c_int64),
+        ("B", C.c_int32), ("d", C.c_int32), ("H", C.c_int32), ("dtype", C.c_int32),
+        ("eps", c_float), ("qk_scale", c_float),
+    ]
+
+
+class CrossBlockDesc(C.Structure):
+    _fields_ = [
+        ("x_in", c_void_p), ("x_out", c_void_p), ("slabs", c_void_p), ("bias_o", c_void_p), ("ln_w", c_void_p), ("ln_b", c_void_p),
+        ("wq", c_void_p), ("bq", c_void_p), ("kv", c_void_p), ("out", c_void_p),
+        ("slab_stride", c_int64),
+        ("n_slabs", C.c_int32), ("B", C.c_int32), ("d", C.c_int32), ("H", C.c_int32), ("Tk", C.c_int32), ("dtype", C.c_int32),
+        ("eps", c_float), ("qk_scale", c_float),
     ]
 
 
@@ -85,6 +107,8 @@ SIGNATURES = {
                                          c_void_p]),
     "wipa_decode_attn": (c_int, [_P(AttnDesc), c_void_p]),
     "wipa_decode_cross_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "wipa_decode_self_block": (c_int, [_P(SelfBlockDesc), c_void_p]),
+    "wipa_decode_cross_block": (c_int, [_P(CrossBlockDesc), c_void_p]),
     "wipa_greedy_step": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int,
                                  c_int, c_void_p, c_void_p, c_void_p]),
     "wipa_add_i32": (c_int, [c_void_p, C.c_int32, c_void_p]),

@@ -17,6 +17,8 @@
 //   wipa_gemm (skinny)       mlp2, residual updated in place
 //
 // All reductions run in a fixed order (no float atomics): results do not depend on the batch a row rides in.
+#include <mutex>
+
 #include "wipa_common.h"
 
 namespace {
@@ -330,7 +332,7 @@ struct CrossBlockParams {
 constexpr int MAX_SLABS_X = 20;  // heads of whisper-large
 
 template <typename T>
-__global__ __launch_bounds__(256) void decode_cross_block_kernel(CrossBlockParams p) {
+__global__ __launch_bounds__(256, 6) void decode_cross_block_kernel(CrossBlockParams p) {
     constexpr int EPL = Vec16<T>::EPL;
     constexpr int LPK = 64 / EPL;
     constexpr int G = 64 / LPK;
@@ -353,16 +355,22 @@ __global__ __launch_bounds__(256) void decode_cross_block_kernel(CrossBlockParam
             const int c = tid * 4 + 1024 * i;
             v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (c < d) {
-                f32x4 sl[MAX_SLABS_X];
                 v[i] = *reinterpret_cast<const f32x4*>(p.x_in + (int64_t)b * d + c);
                 const f32x4 bo = *reinterpret_cast<const f32x4*>(p.bias_o + c);
-#pragma unroll
-                for (int s = 0; s < MAX_SLABS_X; ++s)
-                    if (s < p.n_slabs) sl[s] = *reinterpret_cast<const f32x4*>(p.slabs + (int64_t)s * p.slab_stride + (int64_t)b * d + c);
                 v[i] += bo;
+                // slabs in groups of SG loads in flight (all 20 at once cost 80 registers and a third of the occupancy the
+                // streaming phase wants); the additions stay in slab order
+                constexpr int SG = 6;
+                const float* sp = p.slabs + (int64_t)b * d + c;
+                for (int s0 = 0; s0 < p.n_slabs; s0 += SG) {
+                    f32x4 sl[SG];
 #pragma unroll
-                for (int s = 0; s < MAX_SLABS_X; ++s)
-                    if (s < p.n_slabs) v[i] += sl[s];
+                    for (int s = 0; s < SG; ++s)
+                        if (s0 + s < p.n_slabs) sl[s] = *reinterpret_cast<const f32x4*>(sp + (int64_t)(s0 + s) * p.slab_stride);
+#pragma unroll
+                    for (int s = 0; s < SG; ++s)
+                        if (s0 + s < p.n_slabs) v[i] += sl[s];
+                }
                 if (h == 0) *reinterpret_cast<f32x4*>(p.x_out + (int64_t)b * d + c) = v[i];
                 sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
             }
@@ -408,7 +416,7 @@ __global__ __launch_bounds__(256) void decode_cross_block_kernel(CrossBlockParam
         const T* wr = reinterpret_cast<const T*>(p.wq) + (int64_t)(h * 64 + j) * d;
         const int nch = d / EPL;  // 16-byte chunks per weight row
         float a = 0.f;
-        constexpr int UQ = 8;
+        constexpr int UQ = 6;
         int ch = part;
         for (; ch + 4 * (UQ - 1) < nch; ch += 4 * UQ) {
             Vec16<T> wv[UQ];
@@ -519,18 +527,26 @@ size_t self_block_lds(int d) {
     return (size_t)RG * (d * sizeof(T) + 16) + 4 * 12 * 64 * 16 + 3 * RG * 64 * 4 + RG * (64 * sizeof(T) + 16);
 }
 
-template <typename T>
-int set_lds_limit(size_t bytes) {
-    static size_t limit = 0;  // per instantiation; raised only outside stream capture (first eager call)
-    if (bytes > limit) {
-        WIPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_self_block_kernel<T>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        limit = bytes;
-    }
-    return WIPA_OK;
-}
+constexpr int LDS_LIMIT = 160 * 1024;
 
 }  // namespace
+
+// Raise the dynamic-LDS limit of the self-block kernels once.  Called from wipa_decoder_begin (always eager), so the first
+// launch inside a stream capture finds the attribute already set.
+int wipa_decode_fused_init() {
+    static std::once_flag once;
+    static hipError_t err = hipSuccess;
+    std::call_once(once, [] {
+        const void* fns[2] = {reinterpret_cast<const void*>(&decode_self_block_kernel<__bf16>),
+                              reinterpret_cast<const void*>(&decode_self_block_kernel<float>)};
+        for (const void* f : fns) {
+            const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+            if (e != hipSuccess) err = e;
+        }
+    });
+    WIPA_CHECK_HIP(err);
+    return WIPA_OK;
+}
 
 extern "C" int wipa_decode_self_block(const wipa_self_block_desc* d, wipa_stream_t stream) {
     WIPA_REQUIRE(d && d->x && d->ln_w && d->ln_b && d->wqkv && d->bqkv && d->wo && d->kcache && d->vcache && d->pos && d->slabs,
@@ -548,14 +564,12 @@ extern "C" int wipa_decode_self_block(const wipa_self_block_desc* d, wipa_stream
     p.kv_bs = d->kv_batch_stride; p.slab_stride = d->slab_stride;
     p.B = d->B; p.d = d->d; p.H = d->H; p.eps = d->eps; p.qk_scale = d->qk_scale;
     const dim3 grid(d->H, (d->B + RG - 1) / RG);
+    if (wipa_decode_fused_init() != WIPA_OK) return WIPA_ERR_HIP;
     if (d->dtype == WIPA_BF16) {
         const size_t lds = self_block_lds<__bf16>(d->d);
-        RT_LDS:
-        if (set_lds_limit<__bf16>(lds) != WIPA_OK) return WIPA_ERR_HIP;
         hipLaunchKernelGGL(decode_self_block_kernel<__bf16>, grid, dim3(256), lds, (hipStream_t)stream, p);
     } else {
         const size_t lds = self_block_lds<float>(d->d);
-        if (set_lds_limit<float>(lds) != WIPA_OK) return WIPA_ERR_HIP;
         hipLaunchKernelGGL(decode_self_block_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, p);
     }
     WIPA_LAUNCH_CHECK();

@@ -43,24 +43,12 @@ struct GemmParams {
     int stage_ok;  // epilogue_staged may be used (16-byte row-major stores are legal for this output mapping)
     int k_slices;
     int64_t slab_stride;
-};
-
-template <typename T>
-struct Mma;
-template <>
-struct Mma<__bf16> {
-    typedef bf16x8 Frag;
-    static __device__ __forceinline__ void run(const Frag& w, const Frag& x, f32x4& acc) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, acc, 0, 0, 0);
-    }
-};
-template <>
-struct Mma<float> {
-    typedef f32x4 Frag;
-    static __device__ __forceinline__ void run(const Frag& w, const Frag& x, f32x4& acc) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[e], x[e], acc, 0, 0, 0);
-    }
+    // LayerNorm prologue (weight-streaming kernel only): A = LayerNorm(ln_x) computed in the kernel
+    const float* ln_x = nullptr;
+    const float* ln_w = nullptr;
+    const float* ln_b = nullptr;
+    int64_t ln_ldx = 0;
+    float ln_eps = 0.f;
 };
 
 template <typename OutT>
@@ -584,6 +572,137 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p) {
     }
 }
 
+// Skinny GEMM with a LayerNorm prologue (decode step: mlp_ln folded into mlp1, one launch less per layer).  A workgroup
+// owns 16 output columns for 16*MT rows; its 4 waves first LayerNorm those rows of the f32 residual stream (one row per
+// wave at a time, the arithmetic of layernorm_kernel) into LDS as T, then split K exactly like gemm_skinny_kernel, the
+// activation fragments coming from LDS instead of L2.
+constexpr int LNP_NV = 5;  // K <= 1280
+template <typename T, typename OutT, int MT>
+__global__ __launch_bounds__(256) void gemm_skinny_ln_kernel(GemmParams p) {
+    constexpr int NW = 4;
+    extern __shared__ __attribute__((aligned(16))) char ln_smem[];
+    __shared__ f32x4 red[NW][MT][64];
+    typedef typename Mma<T>::Frag Frag;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int m0 = blockIdx.y * (16 * MT);
+    const int pitch = p.K * (int)sizeof(T) + 16;
+    // ---- prologue: rows m0 .. m0 + 16*MT - 1
+    for (int r = wave; r < 16 * MT; r += NW) {
+        const int m = min(m0 + r, p.M - 1);
+        const float* xr = p.ln_x + (int64_t)m * p.ln_ldx;
+        f32x4 v[LNP_NV];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < LNP_NV; ++i) {
+            const int c = lane * 4 + 256 * i;
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < p.K) {
+                v[i] = *reinterpret_cast<const f32x4*>(xr + c);
+                sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+            }
+        }
+        const float mean = wave_reduce_sum(sum) / (float)p.K;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < LNP_NV; ++i) {
+            const int c = lane * 4 + 256 * i;
+            if (c < p.K) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dv = v[i][e] - mean;
+                    sq += dv * dv;
+                }
+            }
+        }
+        const float rstd = rsqrtf(wave_reduce_sum(sq) / (float)p.K + p.ln_eps);
+#pragma unroll
+        for (int i = 0; i < LNP_NV; ++i) {
+            const int c = lane * 4 + 256 * i;
+            if (c < p.K) {
+                const f32x4 ww = *reinterpret_cast<const f32x4*>(p.ln_w + c);
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(p.ln_b + c);
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * ww[e] + bb[e];
+                T* dst = reinterpret_cast<T*>(ln_smem + r * pitch) + c;
+                if constexpr (sizeof(T) == 4) {
+                    *reinterpret_cast<f32x4*>(dst) = f32x4{o[0], o[1], o[2], o[3]};
+                } else {
+                    *reinterpret_cast<bf16x4*>(dst) = bf16x4{(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
+                }
+            }
+        }
+    }
+    // ---- main loop: the NW waves split K (as gemm_skinny_kernel with NT = 1, k_slices = 1)
+    const int ksteps = p.K * (int)sizeof(T) / 64;
+    const int per = ksteps / NW, rem = ksteps % NW;
+    const int kb = wave * per + min(wave, rem);
+    const int ke = kb + per + (wave < rem ? 1 : 0);
+    const char* wp = p.W + (int64_t)min(n0 + frow, p.N - 1) * p.ldw_b + fq * 16;
+    const bool vec = p.vec_ok != 0;
+    int64_t coff_dev = p.c_offset;
+    if (p.c_offset_dev) coff_dev += *p.c_offset_dev;
+    const EpiCol col = epi_col(p, n0 + 4 * fq);
+    f32x4 acc[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int UB = 6;
+    Frag fw[UB];
+    // the weight fragments do not depend on the prologue: issue the first batch before the barrier
+    const int nfirst = min(UB, ke - kb);
+#pragma unroll
+    for (int u = 0; u < UB; ++u)
+        if (u < nfirst) fw[u] = *reinterpret_cast<const Frag*>(wp + (int64_t)(kb + u) * 64);
+    __syncthreads();
+    const char* ap = ln_smem + frow * pitch + fq * 16;
+    for (int ks = kb; ks < ke; ks += UB) {
+        const int n = min(UB, ke - ks);
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            if (u < n) {
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+                    Mma<T>::run(fw[u], *reinterpret_cast<const Frag*>(ap + (16 * j) * pitch + (ks + u) * 64), acc[j]);
+            }
+        }
+        const int nn = min(UB, ke - (ks + UB));
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+            if (u < nn) fw[u] = *reinterpret_cast<const Frag*>(wp + (int64_t)(ks + UB + u) * 64);
+    }
+#pragma unroll
+    for (int j = 0; j < MT; ++j) red[wave][j][lane] = acc[j];
+    __syncthreads();
+    for (int j = wave; j < MT; j += NW) {
+        f32x4 s = red[0][j][lane];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) s += red[w][j][lane];
+        epilogue4<OutT>(p, s, epi_row(p, m0 + 16 * j + frow, coff_dev), col, vec);
+    }
+}
+
+template <typename T, typename OutT, int MT>
+int launch_skinny_ln_mt(const GemmParams& p, hipStream_t s) {
+    const size_t lds = (size_t)16 * MT * (p.K * sizeof(T) + 16);  // <= 128 KiB (launch_skinny_ln); limit raised by init_attrs
+    dim3 grid((p.N + 15) / 16, (p.M + 16 * MT - 1) / (16 * MT));
+    hipLaunchKernelGGL((gemm_skinny_ln_kernel<T, OutT, MT>), grid, dim3(256), lds, s, p);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+template <typename T, typename OutT>
+int launch_skinny_ln(const GemmParams& p, hipStream_t s) {
+    // rows per workgroup: as many 16-row tiles (4, 2, 1) as fit into ~128 KiB of LDS next to the 16 KiB reduction buffer
+    const size_t row = p.K * sizeof(T) + 16;
+    int mt = 4;
+    while (mt > 1 && (16 * mt * row > (size_t)128 * 1024 || 16 * (mt / 2) >= p.M)) mt >>= 1;
+    if (mt == 4) return launch_skinny_ln_mt<T, OutT, 4>(p, s);
+    if (mt == 2) return launch_skinny_ln_mt<T, OutT, 2>(p, s);
+    return launch_skinny_ln_mt<T, OutT, 1>(p, s);
+}
+
 template <typename T, typename OutT, int MT, int NT, int NW>
 int launch_skinny_cfg(const GemmParams& p, hipStream_t s) {
     dim3 grid((p.N + 16 * NT - 1) / (16 * NT), (p.M + 16 * MT - 1) / (16 * MT), p.k_slices);
@@ -999,6 +1118,19 @@ int init_attrs() {
             const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, XSMEM);
             if (e != hipSuccess) err = e;
         }
+        const void* lnk[9] = {reinterpret_cast<const void*>(&gemm_skinny_ln_kernel<__bf16, __bf16, 1>),
+                              reinterpret_cast<const void*>(&gemm_skinny_ln_kernel<__bf16, __bf16, 2>),
+                              reinterpret_cast<const void*>(&gemm_skinny_ln_kernel<__bf16, __bf16, 4>),
+                              reinterpret_cast<const void*>(&gemm_skinny_ln_kernel<__bf16, float, 1>),
+                              reinterpret_cast<const void*>(&gemm_skinny_ln_kernel<__bf16, float, 2>),
+                              reinterpret_cast<const void*>(&gemm_skinny_ln_kernel<__bf16, float, 4>),
+                              reinterpret_cast<const void*>(&gemm_skinny_ln_kernel<float, float, 1>),
+                              reinterpret_cast<const void*>(&gemm_skinny_ln_kernel<float, float, 2>),
+                              reinterpret_cast<const void*>(&gemm_skinny_ln_kernel<float, float, 4>)};
+        for (const void* f : lnk) {
+            const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            if (e != hipSuccess) err = e;
+        }
     });
     WIPA_CHECK_HIP(err);
     return WIPA_OK;
@@ -1013,8 +1145,10 @@ int launch(const GemmParams& p, hipStream_t s) {
 
 }  // namespace
 
+int wipa_gemm_init() { return init_attrs(); }
+
 extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
-    WIPA_REQUIRE(d && d->A && d->W && d->C, "wipa_gemm: null operand");
+    WIPA_REQUIRE(d && (d->A || d->ln_x) && d->W && d->C, "wipa_gemm: null operand");
     WIPA_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "wipa_gemm: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
     WIPA_REQUIRE(d->in_dtype == WIPA_F32 || d->in_dtype == WIPA_BF16, "wipa_gemm: bad in_dtype %d", d->in_dtype);
     WIPA_REQUIRE(d->out_dtype == WIPA_F32 || d->out_dtype == WIPA_BF16, "wipa_gemm: bad out_dtype %d", d->out_dtype);
@@ -1078,6 +1212,18 @@ extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
     {
         const int rc = init_attrs();
         if (rc != WIPA_OK) return rc;
+    }
+    if (d->ln_x) {  // LayerNorm prologue: A is computed in the kernel from the f32 rows ln_x
+        WIPA_REQUIRE(d->ln_w && d->ln_b && d->ln_ldx >= d->K && d->ln_ldx % 4 == 0 && ((uintptr_t)d->ln_x % 16) == 0,
+                     "wipa_gemm: LayerNorm prologue needs ln_w, ln_b and 16-byte aligned rows of at least K floats");
+        WIPA_REQUIRE(d->K % 64 == 0 && d->K <= 256 * LNP_NV && d->M <= SKINNY_STREAM_MAX_M && p.k_slices == 1,
+                     "wipa_gemm: LayerNorm prologue: K=%d must be a multiple of 64 and <= %d, M <= %d, no k_slices", d->K, 256 * LNP_NV,
+                     SKINNY_STREAM_MAX_M);
+        WIPA_REQUIRE(!(d->in_dtype == WIPA_F32 && d->out_dtype == WIPA_BF16), "wipa_gemm: LayerNorm prologue: f32 -> bf16 is not built");
+        p.ln_x = d->ln_x; p.ln_w = d->ln_w; p.ln_b = d->ln_b; p.ln_ldx = d->ln_ldx; p.ln_eps = d->ln_eps;
+        if (d->in_dtype == WIPA_BF16)
+            return d->out_dtype == WIPA_BF16 ? launch_skinny_ln<__bf16, __bf16>(p, s) : launch_skinny_ln<__bf16, float>(p, s);
+        return launch_skinny_ln<float, float>(p, s);
     }
     // weight-streaming kernel: M <= 256 rows, or up to 1024 when the caller marks them as decode rows (prompt prefill)
     const bool skinny_shape = d->M <= SKINNY_MAX_M || (d->stream_weights && d->M <= SKINNY_STREAM_MAX_M);

@@ -6,7 +6,9 @@
 // Replaces mlx_whisper.whisper.{AudioEncoder,TextDecoder}.__call__ and
 // mlx_whisper.decoding.DecodingTask._main_loop (call sites scripts/train_whisper_ipa.py:223,232,356;
 // scripts/transcribe_single.py:54-55; scripts/evaluate_model.py:197-200).
+#include <algorithm>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -202,7 +204,7 @@ namespace {
 
 constexpr int MAX_SLABS = 4;
 struct DecScratch {
-    size_t x, ln, q, ao, h, slabs, posd, total;
+    size_t x, x2, ln, q, ao, h, slabs, posd, total;
 };
 // split-K factor of a decode-step residual GEMM: keep >= 3 fragment steps per wave (4 waves)
 inline int k_slices_for(int K, int dtype) {
@@ -217,11 +219,13 @@ DecScratch dec_scratch(const wipa_model_cfg* c, int B) {
     DecScratch s;
     size_t o = 0;
     s.x = o;    o += align256(R * d * 4);
+    s.x2 = o;   o += align256((size_t)B * d * 4);  // fused step: the residual stream ping-pongs between x and x2
     s.ln = o;   o += align256(R * d * e);
     s.q = o;    o += align256(R * d * e);
     s.ao = o;   o += align256(R * d * e);
     s.h = o;    o += align256(R * 4 * d * e);
-    s.slabs = o; o += align256((size_t)MAX_SLABS * R * d * 4);
+    // split-K slabs of the unfused residual GEMMs, or one slab per head from the fused self block
+    s.slabs = o; o += align256(std::max((size_t)MAX_SLABS * R, (size_t)c->n_text_head * B) * d * 4);
     s.posd = o; o += 256;
     s.total = o;
     return s;
@@ -348,6 +352,88 @@ int enqueue_step(const wipa_model_cfg* cfg, const void* const* w, char* st, cons
     hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, pos, posd, d);
     WIPA_LAUNCH_CHECK();
     return WIPA_OK;
+}
+
+// One decoder step with the fused blocks of decode_fused.hip: embed + 5 launches per layer + final LayerNorm + logits +
+// greedy update + position advance (65 launches for whisper-small instead of 137).  Same state transitions as enqueue_step.
+int enqueue_step_fused(const wipa_model_cfg* cfg, const void* const* w, char* st, const wipa_dec_layout& L, int B, int n_init,
+                       int eot, const float* mask_first, const float* mask_always, wipa_stream_t stream) {
+    const int dt = cfg->dtype;
+    const size_t e = wipa_dtype_size(dt);
+    const int d = cfg->n_text_state, H = cfg->n_text_head, nctx = cfg->n_text_ctx, Ta = cfg->n_audio_ctx;
+    const DecScratch S = dec_scratch(cfg, B);
+    char* sc = st + L.scratch;
+    float* xa = (float*)(sc + S.x);
+    float* xb = (float*)(sc + S.x2);
+    void* ln = sc + S.ln;
+    void* ao = sc + S.ao;
+    void* hb = sc + S.h;
+    float* slabs = (float*)(sc + S.slabs);
+    int64_t* posd = (int64_t*)(sc + S.posd);
+    int32_t* tokens = (int32_t*)(st + L.tokens);
+    int32_t* pos = (int32_t*)(st + L.pos);
+    RT_CALL(wipa_embed_tokens(tokens, L.ld_tok, B, 1, 0, pos, w[0], dt, (const float*)w[1], xa, d, stream));
+    float* cur = xa;
+    float* other = xb;
+    for (int l = 0; l < cfg->n_text_layer; ++l) {
+        const void* const* lw = w + WIPA_DEC_GLOBAL + WIPA_DEC_PER_LAYER * l;
+        char* skv = st + L.self_kv + (size_t)l * 3 * B * nctx * d * e;  // [3][B][nctx][d]: slot 0 unused here, 1 K, 2 V
+        char* ckv = st + L.cross_kv + (size_t)l * B * 2 * H * Ta * 64 * e;
+        const size_t slot = (size_t)B * nctx * d * e;
+        {
+            wipa_self_block_desc a;
+            memset(&a, 0, sizeof(a));
+            a.x = cur; a.ln_w = (const float*)lw[0]; a.ln_b = (const float*)lw[1];
+            a.wqkv = lw[2]; a.bqkv = (const float*)lw[3]; a.wo = lw[4];
+            a.kcache = skv + slot; a.vcache = skv + 2 * slot; a.pos = pos; a.slabs = slabs;
+            a.kv_batch_stride = (int64_t)nctx * d; a.slab_stride = (int64_t)B * d;
+            a.B = B; a.d = d; a.H = H; a.dtype = dt; a.eps = 1e-5f; a.qk_scale = QK_SCALE;
+            RT_CALL(wipa_decode_self_block(&a, stream));
+        }
+        {
+            wipa_cross_block_desc c;
+            memset(&c, 0, sizeof(c));
+            c.x_in = cur; c.x_out = other; c.slabs = slabs; c.bias_o = (const float*)lw[5];
+            c.ln_w = (const float*)lw[6]; c.ln_b = (const float*)lw[7]; c.wq = lw[8]; c.bq = (const float*)lw[9];
+            c.kv = ckv; c.out = ao; c.slab_stride = (int64_t)B * d;
+            c.n_slabs = H; c.B = B; c.d = d; c.H = H; c.Tk = Ta; c.dtype = dt; c.eps = 1e-5f; c.qk_scale = QK_SCALE;
+            RT_CALL(wipa_decode_cross_block(&c, stream));
+        }
+        std::swap(cur, other);
+        // cross out projection and the MLP update the residual rows in place (no split-K: one launch each)
+        RT_CALL(gemm(ao, d, lw[12], d, cur, d, B, d, d, dt, WIPA_F32, (const float*)lw[13], 0, cur, stream));
+        {
+            wipa_gemm_desc g;
+            memset(&g, 0, sizeof(g));
+            g.ln_x = cur; g.ln_ldx = d; g.ln_w = (const float*)lw[14]; g.ln_b = (const float*)lw[15]; g.ln_eps = 1e-5f;
+            RT_CALL(gemm(nullptr, d, lw[16], d, hb, 4 * d, B, 4 * d, d, dt, dt, (const float*)lw[17], 1, nullptr, stream, &g));
+        }
+        RT_CALL(gemm(hb, 4 * d, lw[18], 4 * d, cur, d, B, d, 4 * d, dt, WIPA_F32, (const float*)lw[19], 0, cur, stream));
+    }
+    RT_CALL(wipa_add_slabs_layernorm(cur, d, nullptr, 0, 0, ln, dt, d, (const float*)w[2], (const float*)w[3], B, d, 1e-5f, stream));
+    float* logits = (float*)(st + L.logits);
+    RT_CALL(gemm(ln, d, w[0], d, logits, L.ld_logits, B, cfg->n_vocab, d, dt, WIPA_F32, nullptr, 0, nullptr, stream));
+    RT_CALL(wipa_greedy_step(logits, L.ld_logits, B, cfg->n_vocab, mask_first, mask_always, tokens, L.ld_tok, pos, n_init,
+                             eot, (float*)(st + L.sum_logprobs), (int32_t*)(st + L.not_done), stream));
+    hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, pos, posd, d);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+// WIPA_DECODE_FUSED=1 selects the fused step; read at enqueue / capture time and part of the graph key.  It is NOT the default:
+// measured on MI355X (whisper-small bf16, 64 rows, r02, profiles/r02_fused_step_by_kernel.txt) the fused step takes 2.05 ms
+// against 1.35 ms -- each fused block is a chain of dependent memory round trips (LayerNorm rows -> weight fragments ->
+// cache rows -> weight fragments) that costs more than the ~4.5 us launch gaps it removes: self block 34.9 us vs 23.4 us for
+// the four launches it replaces, LayerNorm-prologue mlp1 37.2 us vs 12 us, cross block 57.8 us vs 58.7 us.
+bool use_fused_step(const wipa_model_cfg* cfg, int B) {
+    const char* e = getenv("WIPA_DECODE_FUSED");
+    return (e ? atoi(e) : 0) != 0 && cfg->n_text_state <= 1280 && cfg->n_text_head <= 20 && B <= 65535;
+}
+
+int enqueue_decode_step(const wipa_model_cfg* cfg, const void* const* w, char* st, const wipa_dec_layout& L, int B, int n_init,
+                        int eot, const float* mask_first, const float* mask_always, wipa_stream_t stream) {
+    if (use_fused_step(cfg, B)) return enqueue_step_fused(cfg, w, st, L, B, n_init, eot, mask_first, mask_always, stream);
+    return enqueue_step(cfg, w, st, L, B, n_init, eot, mask_first, mask_always, stream);
 }
 
 __global__ void set_pos_kernel(int32_t* pos, int64_t* posd, int value, int d) {
@@ -533,6 +619,8 @@ extern "C" int wipa_decoder_begin(const wipa_model_cfg* cfg, void* state, int B,
     hipStream_t s = (hipStream_t)stream;
     char* st = (char*)state;
     const DecScratch S = dec_scratch(cfg, B);
+    RT_CALL(wipa_decode_fused_init());  // kernel attributes are set here, outside the stream capture of the step
+    RT_CALL(wipa_gemm_init());
     WIPA_CHECK_HIP(hipMemsetAsync(st + L.tokens, 0, (size_t)B * L.ld_tok * 4, s));
     WIPA_CHECK_HIP(hipMemsetAsync(st + L.pos, 0, 512, s));  // pos and not_done
     WIPA_CHECK_HIP(hipMemsetAsync(st + L.sum_logprobs, 0, (size_t)B * 4, s));
@@ -556,12 +644,12 @@ extern "C" int wipa_decoder_run(const wipa_model_cfg* cfg, const void* const* w,
     hipStream_t s = (hipStream_t)stream;
     if (!use_graph) {
         for (int i = 0; i < n_steps; ++i)
-            RT_CALL(enqueue_step(cfg, w, st, L, B, n_init, eot, mask_first, mask_always, stream));
+            RT_CALL(enqueue_decode_step(cfg, w, st, L, B, n_init, eot, mask_first, mask_always, stream));
         return WIPA_OK;
     }
     WIPA_REQUIRE(s != nullptr, "wipa_decoder_run: graph capture needs a non-default stream");
     hipGraphExec_t exec = nullptr;
-    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split, cfg->weights_generation, 0);
+    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * (int)use_fused_step(cfg, B), cfg->weights_generation, 0);
     {
         std::lock_guard<std::mutex> lk(g_graph_mu);
         auto it = g_graphs.find(key);
@@ -570,7 +658,7 @@ extern "C" int wipa_decoder_run(const wipa_model_cfg* cfg, const void* const* w,
     if (!exec) {
         hipGraph_t graph = nullptr;
         WIPA_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
-        const int rc = enqueue_step(cfg, w, st, L, B, n_init, eot, mask_first, mask_always, stream);
+        const int rc = enqueue_decode_step(cfg, w, st, L, B, n_init, eot, mask_first, mask_always, stream);
         const hipError_t ee = hipStreamEndCapture(s, &graph);
         if (rc != WIPA_OK) {
             if (graph) hipGraphDestroy(graph);
@@ -595,13 +683,13 @@ extern "C" int wipa_decoder_prefill(const wipa_model_cfg* cfg, const void* const
     const wipa_dec_layout L = dec_layout(cfg, B);
     char* st = (char*)state;
     auto enqueue = [&]() -> int {
-        if (n_init == 1) return enqueue_step(cfg, w, st, L, B, n_init, eot, mask_first, mask_always, stream);
+        if (n_init == 1) return enqueue_decode_step(cfg, w, st, L, B, n_init, eot, mask_first, mask_always, stream);
         return enqueue_prefill(cfg, w, st, L, B, n_init, eot, mask_first, mask_always, stream);
     };
     hipStream_t s = (hipStream_t)stream;
     if (!use_graph || s == nullptr) return enqueue();
     hipGraphExec_t exec = nullptr;
-    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split, cfg->weights_generation, 1);
+    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * (int)use_fused_step(cfg, B), cfg->weights_generation, 1);
     {
         std::lock_guard<std::mutex> lk(g_graph_mu);
         auto it = g_graphs.find(key);

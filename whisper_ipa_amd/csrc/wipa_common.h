@@ -15,6 +15,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 // ---- error plumbing (never throw across the C ABI) -------------------------
 void wipa_set_error(const char* fmt, ...);
+// one-time kernel attribute setup (dynamic LDS limits); must first run OUTSIDE a stream capture
+int wipa_decode_fused_init();
+int wipa_gemm_init();
 
 #define WIPA_CHECK_HIP(expr)                                                        \
     do {                                                                            \
@@ -90,6 +93,27 @@ __device__ __forceinline__ float wave_reduce_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// MFMA 16x16 wrappers shared by the GEMM and the fused decode kernels.  Operand roles are swapped w.r.t. the textbook (W
+// feeds the "A" side): acc[e] of lane (frow = lane & 15, fq = lane >> 4) is C[m = frow][n = 4*fq + e].  A fragment is the
+// 16 bytes at (row frow, 16-byte chunk fq) of a 64-byte K step, for both dtypes.
+template <typename T>
+struct Mma;
+template <>
+struct Mma<__bf16> {
+    typedef bf16x8 Frag;
+    static __device__ __forceinline__ void run(const Frag& w, const Frag& x, f32x4& acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, acc, 0, 0, 0);
+    }
+};
+template <>
+struct Mma<float> {
+    typedef f32x4 Frag;
+    static __device__ __forceinline__ void run(const Frag& w, const Frag& x, f32x4& acc) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[e], x[e], acc, 0, 0, 0);
+    }
+};
 
 // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. f32 round-off level): one v_rcp, one
 // v_exp and a degree-5 Horner instead of libm's branchy erff -- the GELU epilogue of the MLP
