@@ -358,6 +358,8 @@ def decode_step_roofline(model, B: int, n_steps: int = 48):
     self_kv = B * Ld * 2 * t_mean * dd * e
     dec_params = d.n_vocab * dd + d.n_text_ctx * dd + Ld * (4 * dd * dd + 4 * dd * dd + 8 * dd * dd) + Ld * 11 * dd + 2 * dd
     weights = dec_params * e
+    if model.weights_format == "fp8_e4m3":  # what the step streams: 1-byte codes for everything but the cross K/V projection
+        weights = d.n_vocab * dd + Ld * 14 * dd * dd + (d.n_text_ctx * dd + Ld * 11 * dd + 2 * dd) * 4
     total = cross + self_kv + weights
     achieved = total / (ms * 1e-3) / 1e9
     return {"what": "one decode step, hipGraph replay, one pass in flight", "bound": "hbm", "ms_per_step": round(ms, 4),
@@ -594,6 +596,9 @@ def main():
                     help="sizing runs only: the benchmark metric is quoted in bf16 (f32 is what the reference's scripts set)")
     ap.add_argument("--model", default="small", choices=["tiny", "base", "small", "medium", "large-v3"],
                     help="sizing runs only: the benchmark metric is quoted on whisper-small")
+    ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"],
+                    help="fp8: BASELINE.json configs[4] sizing runs (e4m3 weights with per-row scales, bf16 activations); the "
+                         "benchmark metric is quoted on bf16 weights")
     ap.add_argument("--f32", default="exact", choices=["exact", "split"],
                     help="float32 runs: exact f32 MFMA products (default, as the reference computes) or the split-bf16 opt-in")
     ap.add_argument("--train-batch", type=int, default=32)
@@ -616,6 +621,9 @@ def main():
     model = Whisper(dims, dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32, f32_split=(args.f32 == "split"))
     model.load_weights(W)
     del W
+    if args.weights == "fp8":
+        model.quantize_weights("fp8_e4m3")
+        log("weights quantised to fp8 e4m3")
     audio_dev = torch.from_numpy(synthetic_audio(rank * B, B)).cuda()
     audio_chunks = [c.contiguous() for c in audio_dev.chunk(args.streams)]
     setup = decode_setup()
@@ -672,7 +680,8 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": f"synthetic (seeded noise clips, random-init whisper-{args.model} weights)",
-            "config": {"workload": f"whisper-{args.model} {args.dtype} batched inference, batch={B}x30s synthetic clips per GPU, "
+            "config": {"weights": model.weights_format,
+                       "workload": f"whisper-{args.model} {args.dtype}{' (fp8 e4m3 weights)' if args.weights == 'fp8' else ''} batched inference, batch={B}x30s synthetic clips per GPU, "
                                    f"log-mel + encoder + cross-KV + {NEW_TOKENS} greedy KV-cached decode steps",
                        "clips_per_gpu": B, "new_tokens": NEW_TOKENS, "streams_per_gpu": args.streams, "passes_in_flight": args.pipeline, "decode_group": args.decode_group,
                        "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
@@ -689,7 +698,7 @@ def main():
         out["roofline"] = roofline_cross_attn(model, audio_chunks[0].shape[0])
         if args.streams == 1:
             out["decode_step"] = decode_step_roofline(model, audio_chunks[0].shape[0])
-            if args.dtype == "bf16":
+            if args.dtype == "bf16" and args.batch <= 128:
                 out["roofline_mfma"] = roofline_mfma(model, audio_chunks[0])
         log("roofline microbenches done")
         if world == 1 and not args.no_cpu_baseline and args.model == "small" and B >= 8:

@@ -24,7 +24,7 @@ extern "C" {
 
 typedef void* wipa_stream_t; /* hipStream_t */
 
-enum { WIPA_F32 = 0, WIPA_BF16 = 1 };
+enum { WIPA_F32 = 0, WIPA_BF16 = 1, WIPA_FP8_E4M3 = 2 /* weights only: OCP e4m3fn codes, one byte per element */ };
 enum { WIPA_OK = 0, WIPA_ERR_ARG = -1, WIPA_ERR_HIP = -2, WIPA_ERR_STATE = -3 };
 
 #define WIPA_N_SAMPLES 480000 /* 30 s at 16 kHz (mlx_whisper.audio.N_SAMPLES) */
@@ -96,6 +96,12 @@ typedef struct wipa_gemm_desc {
                         * 1: every product a*w is taken as three bf16 MFMA terms on operands split into hi + lo
                         * (a_hi*w_lo + a_lo*w_hi + a_hi*w_hi, f32 accumulation): about twice the rate at ~5e-6 relative error
                         * of a K = 768 dot product (f32 MFMA: ~1.5e-6).  The weight-streaming kernel always multiplies exactly. */
+    /* fp8 weights (BASELINE.json configs[4]: whisper-large-v3 fp8-weight inference).  w_dtype = WIPA_FP8_E4M3: W holds OCP
+     * e4m3fn codes [N, K] (ldw in bytes = elements), the weight value is code * w_scale[n]; activations must be bf16.
+     * Weight-streaming kernel only (M <= 1024): the decode step, where the weight stream is what a projection costs.
+     * w_dtype = 0: W has the input dtype. */
+    const float* w_scale;
+    int32_t w_dtype;
     /* LayerNorm prologue (decode step: mlp_ln folded into mlp1).  ln_x != NULL: A is ignored and the A operand is
      * LayerNorm(ln_x[m, 0:K]; ln_w, ln_b, ln_eps) rounded to the input dtype, computed inside the kernel from the f32 rows
      * ln_x + m*ln_ldx.  Weight-streaming kernel only: M <= 1024, K a multiple of 64 and <= 1280, no k_slices. */
@@ -124,9 +130,11 @@ int wipa_add_slabs_layernorm(float* x, int64_t ldx, const float* slabs, int n_sl
 /* ------------------------------------------------------------------ K8 embedding
  * TextDecoder: token_embedding[tokens] + positional_embedding[offset : offset+T].
  * tokens [B, ld_tok] int32; row (b,t) uses token tokens[b][p] and position p,
- * p = t_start + (pos_dev ? *pos_dev : 0) + t.  x [B*T, D] f32. */
+ * p = t_start + (pos_dev ? *pos_dev : 0) + t.  x [B*T, D] f32.  emb_dtype WIPA_FP8_E4M3: tok_emb holds e4m3 codes and
+ * row v dequantises as bf16(code * emb_scale[v]) (emb_scale is ignored otherwise). */
 int wipa_embed_tokens(const int32_t* tokens, int64_t ld_tok, int B, int T, int t_start, const int32_t* pos_dev,
-                      const void* tok_emb, int emb_dtype, const float* pos_emb, float* x, int D, wipa_stream_t s);
+                      const void* tok_emb, int emb_dtype, const float* emb_scale, const float* pos_emb, float* x, int D,
+                      wipa_stream_t s);
 
 /* ------------------------------------------------------------------ attention
  * MultiHeadAttention.qkv_attention with head_dim 64; q and k arrive already
@@ -251,6 +259,11 @@ typedef struct wipa_model_cfg {
     int32_t dtype; /* WIPA_F32 or WIPA_BF16: matrices, activations, KV caches */
     int32_t f32_split; /* dtype == WIPA_F32 only: 1 lets the encoder / teacher-forced GEMMs and the encoder flash attention
                         * use split-bf16 products (see wipa_gemm_desc.f32_split); 0 = exact f32 products (default) */
+    int32_t dec_w_dtype; /* 0: the decoder matrices have `dtype`.  WIPA_FP8_E4M3 (bf16 models): the matrices the decode step streams
+                          * (token embedding = logits matrix, self q|k|v, self out, cross query, cross out, mlp1, mlp2) are OCP
+                          * e4m3fn codes with per-row f32 scales appended to the weight table (see WIPA_DEC_FP8_*); wipa_decoder_run
+                          * / _prefill read them through the fp8 weight-streaming GEMM.  cross.kv stays bf16 (its projection is a
+                          * tile GEMM over B*1500 rows); wipa_decoder_logits refuses an fp8 table. */
     int32_t weights_generation; /* bumped by the caller whenever any pointer of a weight table changes: part of the key of
                                  * the cached decode-step graphs (a freed table's host address may be reused) */
 } wipa_model_cfg;
@@ -272,6 +285,10 @@ typedef struct wipa_model_cfg {
  *              14 mlp_ln.w 15 mlp_ln.b 16 mlp1.w 17 mlp1.b 18 mlp2.w 19 mlp2.b */
 #define WIPA_DEC_GLOBAL 4
 #define WIPA_DEC_PER_LAYER 20
+/* fp8 decoder tables (cfg.dec_w_dtype = WIPA_FP8_E4M3) append, after the n_layer regular blocks:
+ *   token_embedding scale [V] f32, then per layer: qkv scale [3d], out [d], cross.query [d], cross.out [d], mlp1 [4d], mlp2 [d]
+ * (value = code * scale[row]); entries 0 and per-layer 2, 4, 8, 12, 16, 18 then point to e4m3 codes. */
+#define WIPA_DEC_FP8_PER_LAYER 6
 
 /* AudioEncoder.__call__ / Whisper.embed_audio (train_whisper_ipa.py:223,
  * transcribe_single.py:54).  mel_padded [B,3002,n_mels] T -> out [B, n_audio_ctx, d] T. */

@@ -474,3 +474,78 @@ def test_gemm_layernorm_prologue(ops, in_dtype, out_dtype, M, N, K, act):
         ref = torch.nn.functional.gelu(ref)
     tol = 1e-5 if in_dtype == torch.float32 else (2e-2 if out_dtype == torch.bfloat16 else 5e-3)
     assert _rel(out, ref) < tol, _rel(out, ref)
+
+
+# ------------------------------------------------------------------ fp8 (e4m3) weights
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N,K,act,slices", [(64, 768, 768, 0, 1), (64, 3072, 768, 1, 1), (64, 768, 3072, 0, 4), (1, 51866, 1280, 0, 1),
+                                              (130, 200, 128, 0, 1), (37, 1280, 5120, 0, 3), (256, 768, 768, 0, 2)])
+def test_gemm_fp8_weights(ops, out_dtype, M, N, K, act, slices):
+    """wipa_gemm with w_dtype = WIPA_FP8_E4M3: bf16 activations x e4m3 codes * per-row scale, against float64 on the
+    dequantised weights (fp8 -> bf16 is exact and the power-of-two scale commutes with the f32 accumulation, so the error is
+    that of a bf16 GEMM)."""
+    import ctypes as C
+
+    from whisper_ipa_amd import _lib
+    from whisper_ipa_amd.runtime import dt_code, on_stream, ptr, sptr
+    from whisper_ipa_amd.whisper import dequantize_fp8_e4m3, quantize_fp8_e4m3
+
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).bfloat16()
+    W = torch.randn(N, K, generator=g) * torch.logspace(-2, 0, N)[:, None]
+    codes, scale = quantize_fp8_e4m3(W)
+    Wdq = dequantize_fp8_e4m3(codes, scale)
+    bias = torch.randn(N, generator=g) * 0.1
+    if slices > 1 and out_dtype != torch.float32:
+        pytest.skip("split-K slabs are f32")
+    with on_stream() as s:
+        Ad, cd, sd, bd = A.cuda(), codes.cuda(), scale.cuda(), bias.cuda()
+        ldc = (N + 7) // 8 * 8
+        out = torch.full((max(slices, 1), M, ldc), 7.0, device="cuda", dtype=out_dtype)
+        dsc = _lib.GemmDesc()
+        dsc.A, dsc.W, dsc.C, dsc.bias = ptr(Ad), ptr(cd), ptr(out), ptr(bd)
+        dsc.w_scale, dsc.w_dtype = ptr(sd), _lib.WIPA_FP8_E4M3
+        dsc.lda, dsc.ldw, dsc.ldc = K, K, ldc
+        dsc.M, dsc.N, dsc.K, dsc.in_dtype, dsc.out_dtype, dsc.act = M, N, K, dt_code(torch.bfloat16), dt_code(out_dtype), act
+        dsc.k_slices, dsc.slab_stride, dsc.stream_weights = slices, M * ldc, 1
+        _lib.check(L.wipa_gemm(C.byref(dsc), sptr(s)), "wipa_gemm(fp8)")
+        # rows beyond the weight-streaming kernel are refused (the tile kernels run on dequantised weights)
+        dsc.M = 2048
+        assert L.wipa_gemm(C.byref(dsc), sptr(s)) != 0
+    torch.cuda.synchronize()
+    ref = A.double() @ Wdq.double().T + bias.double()
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    got = out.double().sum(0)[:, :N] if slices > 1 else out[0, :, :N]
+    assert _rel(got, ref) < (1e-2 if out_dtype == torch.bfloat16 else 1e-5), _rel(got, ref)
+    if ldc > N:
+        assert (out[..., N:] == 7.0).all()
+
+
+def test_embed_fp8_decodes_every_code_like_the_format_definition():
+    """The hardware conversion the fp8 kernels rely on is OCP e4m3fn on gfx950 (not MI300's fnuz): all 254 finite codes
+    through the fp8 embedding kernel against the bit-level definition."""
+    from whisper_ipa_amd import _lib
+    from whisper_ipa_amd.runtime import on_stream, ptr, sptr
+
+    L = _lib.lib()
+    vals = []
+    for c in range(256):
+        sgn, e, m = c >> 7, (c >> 3) & 15, c & 7
+        v = float("nan") if (e == 15 and m == 7) else (2.0 ** -6 * m / 8 if e == 0 else 2.0 ** (e - 7) * (1 + m / 8))
+        vals.append(-v if sgn else v)
+    table = torch.tensor(vals, dtype=torch.float32)
+    codes = torch.arange(256, dtype=torch.uint8).view(4, 64)  # 4 "token" rows of 64 dims
+    scale = torch.tensor([1.0, 0.5, 4.0, 2.0 ** -10])
+    with on_stream() as s:
+        tok = torch.tensor([[3, 0, 2, 1]], dtype=torch.int32, device="cuda")
+        pos = torch.zeros(8, 64, device="cuda")
+        x = torch.empty(4, 64, device="cuda")
+        cd, sd = codes.cuda(), scale.cuda()
+        _lib.check(L.wipa_embed_tokens(ptr(tok), 4, 1, 4, 0, None, ptr(cd), _lib.WIPA_FP8_E4M3, ptr(sd), ptr(pos), ptr(x), 64, sptr(s)))
+    torch.cuda.synchronize()
+    want = torch.stack([table[codes[r].long()] * scale[r] for r in (3, 0, 2, 1)])
+    ok = ~torch.isnan(want)
+    assert torch.equal(x.cpu()[ok], want[ok])
+    assert ok.sum() == 254

@@ -411,3 +411,67 @@ def test_small_width_bf16_close_and_tokens_match_where_margin_allows(small2):
             if ref.margins[b, t] < gate:
                 break
             assert res.tokens[b, 4 + t] == ref.tokens[b, 4 + t], (b, t, ref.margins[b, t], gate)
+
+
+@pytest.mark.parametrize("name,dims,n_new", [
+    ("micro", MICRO, 24),
+    ("small-width", SMALL2, 12),
+    ("large-v3-width", R.ModelDimensions(128, 1500, 1280, 20, 1, 51866, 448, 1280, 20, 2), 10),
+])
+def test_fp8_weight_model_matches_dequantised_reference(name, dims, n_new):
+    """BASELINE.json configs[4] (fp8-weight inference): a bf16 model whose matrices were quantised to e4m3 (per-row
+    power-of-two scales) -- decode-step matrices streamed as 1-byte codes by the fp8 weight-streaming GEMM, everything else
+    as the exact bf16 dequantisation -- against (a) the SAME model run entirely on the dequantised bf16 weights (features
+    bit-identical, last-step logits equal up to f32 summation order, ids equal) and (b) the f32 oracle on the dequantised
+    weights (margin-gated like every bf16 test; logits bound stated below)."""
+    import whisper_ipa_amd as wipa
+    from whisper_ipa_amd.decoding import greedy_decode_tokens
+
+    W = R.synthetic_weights(dims, seed=31)
+    audio = np.stack([R.synthetic_clip(3, 30.0), R.synthetic_clip(4, 6.0)])
+    m8 = _model(dims, W, torch.bfloat16)
+    m8.quantize_weights("fp8_e4m3")
+    assert m8.weights_format == "fp8_e4m3" and m8.packed()["cfg"].dec_w_dtype == 2
+    Wdq = {k: v.float().cpu() for k, v in m8.flat_parameters().items()}
+    changed = [k for k in W if W[k].dim() >= 2 and "positional" not in k]
+    assert all(not torch.equal(Wdq[k], W[k]) for k in changed[:5])  # really quantised
+    rel_q = max(float((Wdq[k] - W[k]).abs().max() / W[k].abs().max()) for k in changed)
+    assert rel_q < 2.0 ** -4  # e4m3: 3 mantissa bits
+    mref = _model(dims, Wdq, torch.bfloat16)
+    mel = wipa.log_mel_spectrogram(audio, n_mels=dims.n_mels)
+    f8, fr = m8.encoder(mel), mref.encoder(mel)
+    assert torch.equal(f8, fr)  # the encoder multiplies by the same bf16 values
+    sp = R.SpecialTokens.multilingual(100 if dims.n_vocab == 51866 else 99)
+    always, first = R.suppress_lists(sp)
+    init = list(sp.sot_sequence_including_notimestamps(0))
+    a = greedy_decode_tokens(m8, f8, init, always, first, sp.eot, max_new_tokens=n_new, stop_on_eot=False)
+    b = greedy_decode_tokens(mref, fr, init, always, first, sp.eot, max_new_tokens=n_new, stop_on_eot=False)
+    same = np.cumprod(a.tokens == b.tokens, axis=1).astype(bool)
+    assert same[:, : 4 + 4].all(), (name, a.tokens.tolist(), b.tokens.tolist())
+    if same.all():
+        dl = (a.last_logits.float() - b.last_logits.float()).abs().max().item()
+        assert dl < 0.15, (name, dl)  # same rounding points; only the f32 summation order inside a projection differs
+    # teacher-forced logits run on the dequantised table and agree with the reference model bit for bit
+    toks = torch.from_numpy(a.tokens[:, :8]).cuda()
+    assert torch.equal(m8.logits(toks, f8), mref.logits(toks, fr))
+    # (b) the f32 oracle on the dequantised weights
+    with torch.no_grad():
+        mel_ref = np.stack([R.log_mel_spectrogram(x, dims.n_mels) for x in audio])
+        xa = R.encoder_forward(Wdq, dims, torch.from_numpy(mel_ref))
+        ref = R.greedy_decode(Wdq, dims, xa, init, always, first, sp.eot, sample_len=n_new, stop_on_eot=False, keep_logits=True)
+    assert ((f8.float().cpu() - xa).abs().max() / xa.abs().max()).item() < 5e-2
+    finite = ref.step_logits[np.isfinite(ref.step_logits)]
+    gate = 0.05 * float(finite.std())
+    for r in range(a.tokens.shape[0]):
+        for t in range(n_new):
+            if ref.margins[r, t] < gate:
+                break
+            assert a.tokens[r, 4 + t] == ref.tokens[r, 4 + t], (name, r, t, ref.margins[r, t], gate)
+    # stated logits bound vs the oracle at the first generated position (same history for every row): 5 % of the logit spread
+    first_logits = greedy_decode_tokens(m8, f8, init, always, first, sp.eot, max_new_tokens=1, stop_on_eot=False).last_logits
+    ok = np.isfinite(ref.step_logits[:, 0])
+    err = np.abs(first_logits.float().cpu().numpy()[ok] - ref.step_logits[:, 0][ok]).max()
+    assert err < 0.05 * float(finite.std()) * 4, (name, err, float(finite.std()))
+    # a weight update invalidates the codes
+    m8.load_weights({"decoder.ln.bias": Wdq["decoder.ln.bias"] + 1}, strict=False)
+    assert m8.weights_format == "bfloat16"

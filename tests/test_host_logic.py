@@ -440,3 +440,52 @@ def test_byte_fallback_is_refused_for_real_weight_entry_points(monkeypatch, tmp_
     assert len(D.create_data_loader(str(p), allow_byte_fallback=True)) == 0
     with pytest.raises(FileNotFoundError):
         T.get_tokenizer(True, vocab_path=str(tmp_path / "missing.tiktoken"))
+
+
+def _e4m3fn_table():
+    """All 256 OCP e4m3fn codes decoded from the format definition: 1 sign, 4 exponent (bias 7), 3 mantissa bits; exponent 0 is
+    subnormal (2^-6 * m/8); S.1111.111 is NaN, there are no infinities (largest finite 448)."""
+    out = []
+    for c in range(256):
+        s, e, m = c >> 7, (c >> 3) & 15, c & 7
+        if e == 15 and m == 7:
+            v = float("nan")
+        elif e == 0:
+            v = 2.0 ** -6 * (m / 8.0)
+        else:
+            v = 2.0 ** (e - 7) * (1 + m / 8.0)
+        out.append(-v if s else v)
+    return out
+
+
+def test_fp8_e4m3_quantiser():
+    """whisper.quantize_fp8_e4m3 (BASELINE.json configs[4]): OCP e4m3fn codes, per-row power-of-two scales, round to nearest,
+    the dequantised value exact in bf16."""
+    from whisper_ipa_amd.whisper import FP8_MAX, dequantize_fp8_e4m3, quantize_fp8_e4m3
+
+    table = torch.tensor(_e4m3fn_table(), dtype=torch.float64)
+    assert table[0x7E] == FP8_MAX == 448.0 and table[0x08] == 2.0 ** -6 and table[0x01] == 2.0 ** -9
+    g = torch.Generator().manual_seed(0)
+    W = torch.randn(37, 3, 64, generator=g) * torch.logspace(-4, 2, 37)[:, None, None]  # rows of very different magnitude
+    W[5] = 0
+    codes, scale = quantize_fp8_e4m3(W)
+    assert codes.dtype == torch.uint8 and tuple(codes.shape) == (37, 192) and tuple(scale.shape) == (37,)
+    assert torch.equal(torch.exp2(torch.round(torch.log2(scale))), scale)  # powers of two
+    assert not ((codes & 0x7F) == 0x7F).any()  # no NaN codes
+    dq = dequantize_fp8_e4m3(codes, scale)
+    assert torch.equal(dq.double(), table[codes.long()] * scale[:, None].double())  # the format definition, code by code
+    assert torch.equal(dq.to(torch.bfloat16).float(), dq)  # exactly representable in bf16
+    W2 = W.reshape(37, -1)
+    amax = W2.abs().amax(1)
+    nz = amax > 0
+    assert ((amax[nz] / scale[nz]) <= 448).all() and ((amax[nz] / scale[nz]) > 224).all()  # the smallest such power of two
+    # round to nearest: no other code of the row's grid is closer
+    err = (dq - W2).abs()
+    grid = table[:0x7F].float()  # non-negative finite values
+    for r in (0, 11, 36):
+        cand = grid[None, :] * scale[r]
+        best = (cand - W2[r].abs()[:, None]).abs().min(1).values
+        assert torch.allclose(err[r], best, rtol=0, atol=1e-12 * float(scale[r]) + 1e-30)
+    big = W2.abs() > 2.0 ** -6 * scale[:, None] * 8  # normal range: relative error <= 2^-4
+    assert (err[big] / W2.abs()[big]).max() <= 2.0 ** -4
+    assert (dq[5] == 0).all()

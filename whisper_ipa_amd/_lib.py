@@ -13,9 +13,9 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwipa.so")
 
-WIPA_F32, WIPA_BF16 = 0, 1
+WIPA_F32, WIPA_BF16, WIPA_FP8_E4M3 = 0, 1, 2
 ENC_GLOBAL, ENC_PER_LAYER = 7, 14
-DEC_GLOBAL, DEC_PER_LAYER = 4, 20
+DEC_GLOBAL, DEC_PER_LAYER, DEC_FP8_PER_LAYER = 4, 20, 6
 
 c_void_p, c_int, c_int64, c_size_t, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
 
@@ -32,6 +32,7 @@ class GemmDesc(C.Structure):
         ("zero_invalid_rows", C.c_int32), ("bias_along_m", C.c_int32), ("act", C.c_int32),
         ("col_scale_n", C.c_int32), ("col_scale", c_float), ("k_slices", C.c_int32),
         ("f32_split", C.c_int32),
+        ("w_scale", c_void_p), ("w_dtype", C.c_int32),
         ("ln_x", c_void_p), ("ln_w", c_void_p), ("ln_b", c_void_p), ("ln_ldx", c_int64), ("ln_eps", c_float),
         ("stream_weights", C.c_int32),
     ]
@@ -73,7 +74,7 @@ class AttnDesc(C.Structure):
 class ModelCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n_mels", "n_audio_ctx", "n_audio_state", "n_audio_head", "n_audio_layer",
-        "n_vocab", "n_text_ctx", "n_text_state", "n_text_head", "n_text_layer", "dtype", "f32_split", "weights_generation")]
+        "n_vocab", "n_text_ctx", "n_text_state", "n_text_head", "n_text_layer", "dtype", "f32_split", "dec_w_dtype", "weights_generation")]
 
 
 class DecLayout(C.Structure):
@@ -98,7 +99,7 @@ SIGNATURES = {
                                c_float, c_void_p]),
     "wipa_add_slabs_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_void_p,
                                          c_void_p, c_int, c_int, c_float, c_void_p]),
-    "wipa_embed_tokens": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+    "wipa_embed_tokens": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                   c_int, c_void_p]),
     "wipa_attention": (c_int, [_P(AttnDesc), c_void_p]),
     "wipa_flash_attn_enc_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int,

@@ -168,6 +168,31 @@ __global__ __launch_bounds__(256) void embed_kernel(const int32_t* __restrict__ 
     }
 }
 
+// fp8 (e4m3fn) token embedding: row `tok` of the codes times its per-row scale (the same matrix and scales serve as the
+// logits weights, where the scale is per output column)
+__global__ __launch_bounds__(256) void embed_fp8_kernel(const int32_t* __restrict__ tokens, int64_t ld_tok, int T, int t_start,
+                                                        const int32_t* __restrict__ pos_dev, const unsigned char* __restrict__ emb,
+                                                        const float* __restrict__ emb_scale, const float* __restrict__ pos_emb,
+                                                        float* __restrict__ x, int D) {
+    const int row = blockIdx.x;
+    const int b = row / T, t = row - b * T;
+    const int p = t_start + (pos_dev ? *pos_dev : 0) + t;
+    const int tok = tokens[(int64_t)b * ld_tok + p];
+    const unsigned char* e = emb + (int64_t)tok * D;
+    const float sc = emb_scale[tok];
+    const float* pe = pos_emb + (int64_t)p * D;
+    float* xr = x + (int64_t)row * D;
+    for (int c = threadIdx.x * 4; c < D; c += 1024) {
+        const unsigned int u = *reinterpret_cast<const unsigned int*>(e + c);
+        const auto lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)u, false);
+        const auto hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)u, true);
+        const f32x4 q = *reinterpret_cast<const f32x4*>(pe + c);
+        // the dequantised value is rounded to bf16 like every stored weight of the bf16 model (code * scale is not exact in bf16)
+        const f32x4 a = {(float)(__bf16)(lo[0] * sc), (float)(__bf16)(lo[1] * sc), (float)(__bf16)(hi[0] * sc), (float)(__bf16)(hi[1] * sc)};
+        *reinterpret_cast<f32x4*>(xr + c) = a + q;
+    }
+}
+
 // ------------------------------------------------------------------ block reductions
 struct MaxIdx {
     float v;
@@ -458,9 +483,10 @@ extern "C" int wipa_add_slabs_layernorm(float* x, int64_t ldx, const float* slab
 }
 
 extern "C" int wipa_embed_tokens(const int32_t* tokens, int64_t ld_tok, int B, int T, int t_start, const int32_t* pos_dev,
-                                 const void* tok_emb, int emb_dtype, const float* pos_emb, float* x, int D,
+                                 const void* tok_emb, int emb_dtype, const float* emb_scale, const float* pos_emb, float* x, int D,
                                  wipa_stream_t stream) {
     WIPA_REQUIRE(tokens && tok_emb && pos_emb && x, "wipa_embed_tokens: null pointer");
+    WIPA_REQUIRE(emb_dtype != WIPA_FP8_E4M3 || emb_scale, "wipa_embed_tokens: fp8 embedding needs emb_scale");
     WIPA_REQUIRE(D % 4 == 0, "wipa_embed_tokens: D must be a multiple of 4");
     if (B * T <= 0) return WIPA_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -470,6 +496,9 @@ extern "C" int wipa_embed_tokens(const int32_t* tokens, int64_t ld_tok, int B, i
     else if (emb_dtype == WIPA_BF16)
         hipLaunchKernelGGL((embed_kernel<__bf16>), dim3(B * T), dim3(256), 0, s, tokens, ld_tok, T, t_start, pos_dev,
                            (const __bf16*)tok_emb, pos_emb, x, D);
+    else if (emb_dtype == WIPA_FP8_E4M3)
+        hipLaunchKernelGGL(embed_fp8_kernel, dim3(B * T), dim3(256), 0, s, tokens, ld_tok, T, t_start, pos_dev,
+                           (const unsigned char*)tok_emb, emb_scale, pos_emb, x, D);
     else
         WIPA_REQUIRE(false, "wipa_embed_tokens: bad dtype %d", emb_dtype);
     WIPA_LAUNCH_CHECK();

@@ -43,6 +43,7 @@ struct GemmParams {
     int stage_ok;  // epilogue_staged may be used (16-byte row-major stores are legal for this output mapping)
     int k_slices;
     int64_t slab_stride;
+    const float* w_scale = nullptr;  // fp8 (e4m3) weights: per-output-column dequantisation scale
     // LayerNorm prologue (weight-streaming kernel only): A = LayerNorm(ln_x) computed in the kernel
     const float* ln_x = nullptr;
     const float* ln_w = nullptr;
@@ -570,6 +571,148 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p) {
             epilogue4<OutT>(p, s, epi_row(p, m0 + 16 * j + frow, coff_dev), cc, vec);
         }
     }
+}
+
+// Skinny GEMM with fp8 (OCP e4m3fn) weights and bf16 activations: the decode step streams every decoder matrix once per
+// step, so halving the weight bytes halves that stream.  W [N, K] one byte per element, dequantised as code * w_scale[n]:
+// the codes are widened to bf16 in registers (exact: e4m3 has 3 mantissa bits) and fed to the bf16 MFMA; the per-column
+// scale multiplies the f32 accumulator before the usual epilogue.  A lane loads 16 weight bytes = 16 consecutive k of one
+// row and spends them in two MFMAs; the activation fragments use the same k permutation (k = 64*s + 16*fq + 8*half + 0..7).
+__device__ __forceinline__ void fp8x16_to_bf16(const uint4& w, bf16x8& lo, bf16x8& hi) {
+    const unsigned int u[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const auto a = __builtin_amdgcn_cvt_pk_f32_fp8((int)u[i], false);  // bytes 0, 1
+        const auto b = __builtin_amdgcn_cvt_pk_f32_fp8((int)u[i], true);   // bytes 2, 3
+        if (i < 2) {
+            lo[4 * i] = (__bf16)a[0]; lo[4 * i + 1] = (__bf16)a[1]; lo[4 * i + 2] = (__bf16)b[0]; lo[4 * i + 3] = (__bf16)b[1];
+        } else {
+            hi[4 * (i - 2)] = (__bf16)a[0]; hi[4 * (i - 2) + 1] = (__bf16)a[1]; hi[4 * (i - 2) + 2] = (__bf16)b[0]; hi[4 * (i - 2) + 3] = (__bf16)b[1];
+        }
+    }
+}
+
+template <typename OutT, int MT, int NT, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_w8_kernel(GemmParams p) {
+    __shared__ f32x4 red[NW][MT * NT][64];
+    constexpr int UB = (NT == 1) ? 4 : 2;  // 64-k steps whose loads are in flight together
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int n0 = blockIdx.x * (16 * NT);
+    const int m0 = blockIdx.y * (16 * MT);
+    const int ksteps_all = p.K / 64;  // 64 k per step: 64 weight bytes, 128 activation bytes per row
+    const int kz = blockIdx.z, S = p.k_slices;
+    const int s_per = ksteps_all / S, s_rem = ksteps_all % S;
+    const int s_beg = kz * s_per + min(kz, s_rem);
+    const int ksteps = s_per + (kz < s_rem ? 1 : 0);
+    const int per = ksteps / NW, rem = ksteps % NW;
+    const int kb = s_beg + wave * per + min(wave, rem);
+    const int ke = kb + per + (wave < rem ? 1 : 0);
+    const char* wp[NT];
+    const char* xp[MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) wp[i] = p.W + (int64_t)min(n0 + 16 * i + frow, p.N - 1) * p.ldw_b + fq * 16;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) xp[j] = p.A + (int64_t)min(m0 + 16 * j + frow, p.M - 1) * p.lda_b + fq * 32;
+    const bool vec = p.vec_ok != 0;
+    int64_t coff_dev = p.c_offset + (int64_t)kz * p.slab_stride;
+    if (p.c_offset_dev) coff_dev += *p.c_offset_dev;
+    if (kz > 0) p.bias = nullptr;
+    EpiCol cols[NT];
+    f32x4 wsc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        cols[i] = epi_col(p, n0 + 16 * i + 4 * fq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wsc[i][e] = p.w_scale[min(n0 + 16 * i + 4 * fq + e, p.N - 1)];
+    }
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto step = [&](int ks0, int n) {
+        uint4 fw[UB][NT];
+        bf16x8 fx[UB][MT][2];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            if (u < n) {
+                const int64_t ks = ks0 + u;
+#pragma unroll
+                for (int i = 0; i < NT; ++i) fw[u][i] = *reinterpret_cast<const uint4*>(wp[i] + ks * 64);
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    fx[u][j][0] = *reinterpret_cast<const bf16x8*>(xp[j] + ks * 128);
+                    fx[u][j][1] = *reinterpret_cast<const bf16x8*>(xp[j] + ks * 128 + 16);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            if (u < n) {
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    bf16x8 wlo, whi;
+                    fp8x16_to_bf16(fw[u][i], wlo, whi);
+#pragma unroll
+                    for (int j = 0; j < MT; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, fx[u][j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, fx[u][j][1], acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+    int ks = kb;
+    for (; ks + UB <= ke; ks += UB) step(ks, UB);
+    if (ks < ke) step(ks, ke - ks);
+#pragma unroll
+    for (int t = 0; t < NT * MT; ++t) red[wave][t][lane] = acc[t / MT][t % MT];
+    __syncthreads();
+#pragma unroll
+    for (int t0 = 0; t0 < NT * MT; t0 += NW) {
+        const int t = t0 + wave;
+        if (t < NT * MT) {
+            f32x4 s = red[0][t][lane];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) s += red[w][t][lane];
+            const int i = t / MT, j = t - i * MT;
+            EpiCol cc = cols[0];
+            f32x4 sc = wsc[0];
+#pragma unroll
+            for (int ii = 1; ii < NT; ++ii)
+                if (i == ii) {
+                    cc = cols[ii];
+                    sc = wsc[ii];
+                }
+            s *= sc;
+            epilogue4<OutT>(p, s, epi_row(p, m0 + 16 * j + frow, coff_dev), cc, vec);
+        }
+    }
+}
+
+template <typename OutT, int MT, int NT, int NW>
+int launch_skinny_w8_cfg(const GemmParams& p, hipStream_t s) {
+    dim3 grid((p.N + 16 * NT - 1) / (16 * NT), (p.M + 16 * MT - 1) / (16 * MT), p.k_slices);
+    hipLaunchKernelGGL((gemm_skinny_w8_kernel<OutT, MT, NT, NW>), grid, dim3(NW * 64), 0, s, p);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+template <typename OutT, int MT>
+int launch_skinny_w8_mt(const GemmParams& p, hipStream_t s) {
+    const int ksteps = p.K / 64 / p.k_slices;
+    if (p.N >= 8192 && MT == 4) return launch_skinny_w8_cfg<OutT, MT, 4, 4>(p, s);  // logits: 64 columns per workgroup
+    if (p.N >= 8192) return launch_skinny_w8_cfg<OutT, MT, 2, 4>(p, s);
+    if (ksteps >= 32) return launch_skinny_w8_cfg<OutT, MT, 1, 8>(p, s);
+    return launch_skinny_w8_cfg<OutT, MT, 1, 4>(p, s);
+}
+
+template <typename OutT>
+int launch_skinny_w8(const GemmParams& p, hipStream_t s) {
+    if (p.M <= 16) return launch_skinny_w8_mt<OutT, 1>(p, s);
+    if (p.M <= 32) return launch_skinny_w8_mt<OutT, 2>(p, s);
+    return launch_skinny_w8_mt<OutT, 4>(p, s);
 }
 
 // Skinny GEMM with a LayerNorm prologue (decode step: mlp_ln folded into mlp1, one launch less per layer).  A workgroup
@@ -1153,7 +1296,17 @@ extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
     WIPA_REQUIRE(d->in_dtype == WIPA_F32 || d->in_dtype == WIPA_BF16, "wipa_gemm: bad in_dtype %d", d->in_dtype);
     WIPA_REQUIRE(d->out_dtype == WIPA_F32 || d->out_dtype == WIPA_BF16, "wipa_gemm: bad out_dtype %d", d->out_dtype);
     const int64_t esz = (int64_t)wipa_dtype_size(d->in_dtype);
-    WIPA_REQUIRE((d->K * esz) % ROWB == 0, "wipa_gemm: K=%d must be a multiple of %d elements", d->K, (int)(ROWB / esz));
+    if (d->w_dtype == WIPA_FP8_E4M3) {
+        // fp8 weights: weight-streaming kernel only (decode rows); larger M runs on weights dequantised to bf16 at load time
+        WIPA_REQUIRE(d->in_dtype == WIPA_BF16 && d->w_scale && d->A, "wipa_gemm: fp8 weights need bf16 activations and w_scale");
+        WIPA_REQUIRE(d->K % 64 == 0 && d->ldw % 16 == 0 && (d->lda * 2) % 16 == 0 && ((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->W % 16) == 0,
+                     "wipa_gemm: fp8 weights: K must be a multiple of 64 and rows 16-byte aligned");
+        WIPA_REQUIRE(d->M <= SKINNY_STREAM_MAX_M, "wipa_gemm: fp8 weights: M=%d exceeds the weight-streaming kernel (%d rows)", d->M, SKINNY_STREAM_MAX_M);
+        WIPA_REQUIRE(!d->ln_x, "wipa_gemm: fp8 weights: no LayerNorm prologue");
+    } else {
+        WIPA_REQUIRE(d->w_dtype == 0, "wipa_gemm: bad w_dtype %d (0 = the input dtype, %d = fp8 e4m3)", d->w_dtype, WIPA_FP8_E4M3);
+    }
+    WIPA_REQUIRE(d->w_dtype == WIPA_FP8_E4M3 || (d->K * esz) % ROWB == 0, "wipa_gemm: K=%d must be a multiple of %d elements", d->K, (int)(ROWB / esz));
     WIPA_REQUIRE((d->lda * esz) % 16 == 0 && (d->ldw * esz) % 16 == 0, "wipa_gemm: lda/ldw rows must be 16-byte aligned");
     WIPA_REQUIRE(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->W % 16) == 0, "wipa_gemm: A/W must be 16-byte aligned");
     GemmParams p;
@@ -1165,7 +1318,8 @@ extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
     p.pos = d->pos;
     p.c_offset_dev = d->c_offset_dev;
     p.lda_b = d->lda * esz;
-    p.ldw_b = d->ldw * esz;
+    p.ldw_b = d->w_dtype == WIPA_FP8_E4M3 ? d->ldw : d->ldw * esz;
+    p.w_scale = d->w_scale;
     p.ldc = d->ldc;
     p.ldpos = d->ldpos;
     p.M = d->M;
@@ -1213,6 +1367,8 @@ extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
         const int rc = init_attrs();
         if (rc != WIPA_OK) return rc;
     }
+    if (d->w_dtype == WIPA_FP8_E4M3)
+        return d->out_dtype == WIPA_BF16 ? launch_skinny_w8<__bf16>(p, s) : launch_skinny_w8<float>(p, s);
     if (d->ln_x) {  // LayerNorm prologue: A is computed in the kernel from the f32 rows ln_x
         WIPA_REQUIRE(d->ln_w && d->ln_b && d->ln_ldx >= d->K && d->ln_ldx % 4 == 0 && ((uintptr_t)d->ln_x % 16) == 0,
                      "wipa_gemm: LayerNorm prologue needs ln_w, ln_b and 16-byte aligned rows of at least K floats");

@@ -51,6 +51,8 @@ int cfg_check(const wipa_model_cfg* c) {
                  "head_dim must be 64 (state %d heads %d)", c->n_audio_state, c->n_audio_head);
     WIPA_REQUIRE(c->n_audio_ctx == WIPA_N_FRAMES / 2, "n_audio_ctx must be 1500");
     WIPA_REQUIRE(c->n_audio_state % 64 == 0 && c->n_text_state % 64 == 0, "state must be a multiple of 64");
+    WIPA_REQUIRE(c->dec_w_dtype == 0 || (c->dec_w_dtype == WIPA_FP8_E4M3 && c->dtype == WIPA_BF16),
+                 "cfg.dec_w_dtype %d: fp8 (e4m3) decoder weights need a bf16 model", c->dec_w_dtype);
     return WIPA_OK;
 }
 
@@ -90,6 +92,31 @@ struct SplitScope {
     ~SplitScope() { t_f32_split = prev; }
 };
 
+// fp8 decoder weights (wipa_model_cfg.dec_w_dtype = WIPA_FP8_E4M3): matrix pointer -> per-row scale, built from the weight
+// table by the decode entry points for the duration of the call (host-thread local, enqueue-time only).
+typedef std::map<const void*, const float*> W8Map;
+thread_local const W8Map* t_w8 = nullptr;
+struct W8Scope {
+    W8Map map;
+    const W8Map* prev;
+    W8Scope(const wipa_model_cfg* c, const void* const* w) : prev(t_w8) {
+        if (c && w && c->dec_w_dtype == WIPA_FP8_E4M3) {
+            const int base = WIPA_DEC_GLOBAL + WIPA_DEC_PER_LAYER * c->n_text_layer;
+            map[w[0]] = (const float*)w[base];
+            static const int slots[WIPA_DEC_FP8_PER_LAYER] = {2, 4, 8, 12, 16, 18};
+            for (int l = 0; l < c->n_text_layer; ++l)
+                for (int j = 0; j < WIPA_DEC_FP8_PER_LAYER; ++j)
+                    map[w[WIPA_DEC_GLOBAL + WIPA_DEC_PER_LAYER * l + slots[j]]] = (const float*)w[base + 1 + WIPA_DEC_FP8_PER_LAYER * l + j];
+            t_w8 = &map;
+        }
+    }
+    ~W8Scope() { t_w8 = prev; }
+};
+inline int emb_dtype(const wipa_model_cfg* c) { return c->dec_w_dtype == WIPA_FP8_E4M3 ? WIPA_FP8_E4M3 : c->dtype; }
+inline const float* emb_scale(const wipa_model_cfg* c, const void* const* w) {
+    return c->dec_w_dtype == WIPA_FP8_E4M3 ? (const float*)w[WIPA_DEC_GLOBAL + WIPA_DEC_PER_LAYER * c->n_text_layer] : nullptr;
+}
+
 int gemm(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int M, int N, int K, int in_dt,
          int out_dt, const float* bias, int act, const void* residual, wipa_stream_t s, wipa_gemm_desc* extra = nullptr) {
     wipa_gemm_desc g;
@@ -98,6 +125,13 @@ int gemm(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_
     g.M = M; g.N = N; g.K = K; g.in_dtype = in_dt; g.out_dtype = out_dt;
     g.bias = bias; g.act = act; g.residual = residual;
     g.f32_split = t_f32_split;
+    if (t_w8) {  // fp8 decoder weights: matrices are recognised by their table pointer
+        auto it = t_w8->find(W);
+        if (it != t_w8->end()) {
+            g.w_dtype = WIPA_FP8_E4M3;
+            g.w_scale = it->second;
+        }
+    }
     return wipa_gemm(&g, s);
 }
 
@@ -301,7 +335,7 @@ int enqueue_step(const wipa_model_cfg* cfg, const void* const* w, char* st, cons
         pend = g.k_slices;
         return gemm(A, K, W, K, slabs, d, B, d, K, dt, WIPA_F32, (const float*)bias, 0, nullptr, stream, &g);
     };
-    RT_CALL(wipa_embed_tokens(tokens, L.ld_tok, B, 1, 0, pos, w[0], dt, (const float*)w[1], x, d, stream));
+    RT_CALL(wipa_embed_tokens(tokens, L.ld_tok, B, 1, 0, pos, w[0], emb_dtype(cfg), emb_scale(cfg, w), (const float*)w[1], x, d, stream));
     for (int l = 0; l < cfg->n_text_layer; ++l) {
         const void* const* lw = w + WIPA_DEC_GLOBAL + WIPA_DEC_PER_LAYER * l;
         char* skv = st + L.self_kv + (size_t)l * 3 * B * nctx * d * e;  // [3][B][nctx][d]
@@ -372,7 +406,7 @@ int enqueue_step_fused(const wipa_model_cfg* cfg, const void* const* w, char* st
     int64_t* posd = (int64_t*)(sc + S.posd);
     int32_t* tokens = (int32_t*)(st + L.tokens);
     int32_t* pos = (int32_t*)(st + L.pos);
-    RT_CALL(wipa_embed_tokens(tokens, L.ld_tok, B, 1, 0, pos, w[0], dt, (const float*)w[1], xa, d, stream));
+    RT_CALL(wipa_embed_tokens(tokens, L.ld_tok, B, 1, 0, pos, w[0], emb_dtype(cfg), emb_scale(cfg, w), (const float*)w[1], xa, d, stream));
     float* cur = xa;
     float* other = xb;
     for (int l = 0; l < cfg->n_text_layer; ++l) {
@@ -427,7 +461,7 @@ int enqueue_step_fused(const wipa_model_cfg* cfg, const void* const* w, char* st
 // the four launches it replaces, LayerNorm-prologue mlp1 37.2 us vs 12 us, cross block 57.8 us vs 58.7 us.
 bool use_fused_step(const wipa_model_cfg* cfg, int B) {
     const char* e = getenv("WIPA_DECODE_FUSED");
-    return (e ? atoi(e) : 0) != 0 && cfg->n_text_state <= 1280 && cfg->n_text_head <= 20 && B <= 65535;
+    return (e ? atoi(e) : 0) != 0 && cfg->dec_w_dtype == 0 && cfg->n_text_state <= 1280 && cfg->n_text_head <= 20 && B <= 65535;
 }
 
 int enqueue_decode_step(const wipa_model_cfg* cfg, const void* const* w, char* st, const wipa_dec_layout& L, int B, int n_init,
@@ -479,7 +513,7 @@ int enqueue_prefill(const wipa_model_cfg* cfg, const void* const* w, char* st, c
         pend = g.k_slices;
         return gemm(A, K, W, K, slabs, d, M, d, K, dt, WIPA_F32, (const float*)bias, 0, nullptr, stream, &g);
     };
-    RT_CALL(wipa_embed_tokens(tokens, L.ld_tok, B, P, 0, nullptr, w[0], dt, (const float*)w[1], x, d, stream));
+    RT_CALL(wipa_embed_tokens(tokens, L.ld_tok, B, P, 0, nullptr, w[0], emb_dtype(cfg), emb_scale(cfg, w), (const float*)w[1], x, d, stream));
     for (int l = 0; l < cfg->n_text_layer; ++l) {
         const void* const* lw = w + WIPA_DEC_GLOBAL + WIPA_DEC_PER_LAYER * l;
         char* skv = st + L.self_kv + (size_t)l * 3 * B * nctx * d * e;  // [3][B][nctx][d]
@@ -639,6 +673,7 @@ extern "C" int wipa_decoder_run(const wipa_model_cfg* cfg, const void* const* w,
     RT_CALL(cfg_check(cfg));
     SplitScope split_scope(cfg);
     WIPA_REQUIRE(w && state && mask_first && mask_always && B > 0 && n_steps >= 0, "wipa_decoder_run: bad arguments");
+    W8Scope w8_scope(cfg, w);
     const wipa_dec_layout L = dec_layout(cfg, B);
     char* st = (char*)state;
     hipStream_t s = (hipStream_t)stream;
@@ -649,7 +684,7 @@ extern "C" int wipa_decoder_run(const wipa_model_cfg* cfg, const void* const* w,
     }
     WIPA_REQUIRE(s != nullptr, "wipa_decoder_run: graph capture needs a non-default stream");
     hipGraphExec_t exec = nullptr;
-    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * (int)use_fused_step(cfg, B), cfg->weights_generation, 0);
+    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * (int)use_fused_step(cfg, B) + 8 * cfg->dec_w_dtype, cfg->weights_generation, 0);
     {
         std::lock_guard<std::mutex> lk(g_graph_mu);
         auto it = g_graphs.find(key);
@@ -680,6 +715,7 @@ extern "C" int wipa_decoder_prefill(const wipa_model_cfg* cfg, const void* const
     SplitScope split_scope(cfg);
     WIPA_REQUIRE(w && state && mask_first && mask_always && B > 0, "wipa_decoder_prefill: bad arguments");
     WIPA_REQUIRE(n_init >= 1 && n_init <= MAX_PROMPT, "wipa_decoder_prefill: 1..%d prompt tokens (got %d)", MAX_PROMPT, n_init);
+    W8Scope w8_scope(cfg, w);
     const wipa_dec_layout L = dec_layout(cfg, B);
     char* st = (char*)state;
     auto enqueue = [&]() -> int {
@@ -689,7 +725,7 @@ extern "C" int wipa_decoder_prefill(const wipa_model_cfg* cfg, const void* const
     hipStream_t s = (hipStream_t)stream;
     if (!use_graph || s == nullptr) return enqueue();
     hipGraphExec_t exec = nullptr;
-    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * (int)use_fused_step(cfg, B), cfg->weights_generation, 1);
+    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * (int)use_fused_step(cfg, B) + 8 * cfg->dec_w_dtype, cfg->weights_generation, 1);
     {
         std::lock_guard<std::mutex> lk(g_graph_mu);
         auto it = g_graphs.find(key);
@@ -760,6 +796,7 @@ extern "C" int wipa_decoder_logits(const wipa_model_cfg* cfg, const void* const*
     SplitScope split_scope(cfg);
     WIPA_REQUIRE(w && tokens && features && logits && workspace && B > 0 && T > 0, "wipa_decoder_logits: bad arguments");
     WIPA_REQUIRE(T <= cfg->n_text_ctx, "wipa_decoder_logits: T=%d exceeds n_text_ctx=%d", T, cfg->n_text_ctx);
+    WIPA_REQUIRE(cfg->dec_w_dtype == 0, "wipa_decoder_logits: the teacher-forced decoder runs on a bf16 / f32 weight table (fp8 tables serve the decode step)");
     const TfWs L = tf_ws(cfg, B, T);
     WIPA_REQUIRE(workspace_bytes >= L.total, "wipa_decoder_logits: workspace too small (%zu < %zu)", workspace_bytes, L.total);
     const int dt = cfg->dtype;
@@ -773,7 +810,7 @@ extern "C" int wipa_decoder_logits(const wipa_model_cfg* cfg, const void* const*
     void* ao = ws + L.ao;
     void* hb = ws + L.h;
     char* ckv = ws + L.ckv;
-    RT_CALL(wipa_embed_tokens(tokens, T, B, T, 0, nullptr, w[0], dt, (const float*)w[1], x, d, stream));
+    RT_CALL(wipa_embed_tokens(tokens, T, B, T, 0, nullptr, w[0], dt, nullptr, (const float*)w[1], x, d, stream));
     for (int l = 0; l < cfg->n_text_layer; ++l) {
         const void* const* lw = w + WIPA_DEC_GLOBAL + WIPA_DEC_PER_LAYER * l;
         RT_CALL(wipa_layernorm(x, WIPA_F32, d, ln, dt, d, (const float*)lw[0], (const float*)lw[1], M, d, 1e-5f, stream));

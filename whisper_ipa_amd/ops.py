@@ -158,7 +158,7 @@ def embed_tokens(tokens: torch.Tensor, tok_emb: torch.Tensor, pos_emb: torch.Ten
     with on_stream() as s:
         x = torch.empty(B * T, D, dtype=torch.float32, device=tok_emb.device)
         _lib.check(L.wipa_embed_tokens(ptr(tokens), tokens.stride(0), B, T, t_start, None, ptr(tok_emb), dt_code(tok_emb.dtype),
-                                       ptr(pos_emb), ptr(x), D, sptr(s)), "wipa_embed_tokens")
+                                       None, ptr(pos_emb), ptr(x), D, sptr(s)), "wipa_embed_tokens")
     return x
 
 

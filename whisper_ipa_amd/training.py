@@ -208,7 +208,7 @@ class DecoderTrainer:
             feats = audio_features.to(device=dev, dtype=torch.float32).contiguous().view(B * Ta, d)
             featsT = self._transpose(feats, B * Ta, d, _ceil(B * Ta, 32))  # [d, ceil32(B*Ta)], shared by all layers
             x = torch.empty(M, d, dtype=torch.float32, device=dev)
-            _lib.check(L.wipa_embed_tokens(ptr(tok_in), T, B, T, 0, None, ptr(P("decoder.token_embedding.weight")), 0,
+            _lib.check(L.wipa_embed_tokens(ptr(tok_in), T, B, T, 0, None, ptr(P("decoder.token_embedding.weight")), 0, None,
                                            ptr(P("decoder.positional_embedding")), ptr(x), d, sptr(s)), "wipa_embed_tokens")
             saved = []
             for l in range(dm.n_text_layer):

@@ -46,6 +46,35 @@ def _is_matrix(name: str, t: torch.Tensor) -> bool:
     return t.dim() >= 2 and not name.endswith("positional_embedding")
 
 
+FP8_MAX = 448.0  # largest finite OCP e4m3fn value
+
+
+def quantize_fp8_e4m3(W: torch.Tensor):
+    """[N, ...] -> (codes uint8 [N, K], scale f32 [N]): OCP e4m3fn codes with one POWER-OF-TWO scale per output row,
+    value = code * scale.  The scale is the smallest power of two that brings the row's largest magnitude into the
+    format's range, so the dequantised value is exactly representable in bf16 (3 mantissa bits, exponent shifted): the
+    fp8 weight-streaming kernel and the bf16 tile kernels on the dequantised copy multiply by the SAME numbers."""
+    W2 = W.detach().float().reshape(W.shape[0], -1)
+    amax = W2.abs().amax(dim=1).clamp(min=2.0 ** -100)
+    scale = torch.exp2(torch.ceil(torch.log2(amax / FP8_MAX)))
+    q = (W2 / scale[:, None]).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn)  # round to nearest even
+    return q.view(torch.uint8).contiguous(), scale.contiguous()
+
+
+def dequantize_fp8_e4m3(codes: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    return codes.view(torch.float8_e4m3fn).float() * scale[:, None].float()
+
+
+# matrices the decode step streams once per step: kept as fp8 codes by Whisper.quantize_weights
+def _decode_step_matrices(dims) -> List[str]:
+    names = ["decoder.token_embedding.weight"]
+    for i in range(dims.n_text_layer):
+        p = f"decoder.blocks.{i}"
+        names += [f"{p}.attn.query.weight", f"{p}.attn.key.weight", f"{p}.attn.value.weight", f"{p}.attn.out.weight",
+                  f"{p}.cross_attn.query.weight", f"{p}.cross_attn.out.weight", f"{p}.mlp1.weight", f"{p}.mlp2.weight"]
+    return names
+
+
 def parameter_names(dims: ModelDimensions) -> List[str]:
     names = ["encoder.conv1.weight", "encoder.conv1.bias", "encoder.conv2.weight", "encoder.conv2.bias"]
 
@@ -97,8 +126,10 @@ class Whisper:
         self.device = device()
         _lib.lib()  # fail now if the extension is missing
         self._params: Dict[str, torch.Tensor] = {}
+        self._fp8: Dict[str, tuple] = {}  # name -> (codes uint8 [N,K], scale f32 [N]) for the decode-step matrices
         self._frozen = set()
         self._packed = None
+        self._packed_tf = None
         self._enc_ws: Dict[int, torch.Tensor] = {}  # per library stream
         self._tf_ws: Dict[int, torch.Tensor] = {}
         self.encoder = _Part(self, "encoder")
@@ -147,7 +178,37 @@ class Whisper:
                     t = torch.as_tensor(flat[n]).detach()
                     want = self.dtype if _is_matrix(n, t) else torch.float32
                     self._params[n] = t.to(device=self.device, dtype=want).contiguous()
+        self._fp8 = {}  # new weights: any fp8 codes are stale (call quantize_weights again)
         self._invalidate()
+        return self
+
+    # ---- fp8 weights (BASELINE.json configs[4]: whisper-large-v3 fp8-weight inference) -------------
+    @property
+    def weights_format(self) -> str:
+        return "fp8_e4m3" if self._fp8 else str(self.dtype).replace("torch.", "")
+
+    def quantize_weights(self, fmt: str = "fp8_e4m3"):
+        """Quantise EVERY matrix of the model (Linear / Conv1d weights, token embedding) to OCP fp8 e4m3fn with one
+        power-of-two scale per output row (quantize_fp8_e4m3).  Biases, LayerNorm and positional tables stay f32.
+        The matrices the decode step streams once per step stay in fp8 (1 byte per weight) and are read by the fp8
+        weight-streaming GEMM; all matrices are ALSO kept as their exact bf16 dequantisation for the MFMA-bound tile GEMMs of
+        the encoder, the cross-K/V projection and the teacher-forced decoder -- both forms multiply by the same values."""
+        if fmt != "fp8_e4m3":
+            raise _lib.WipaError(f"quantize_weights: unknown format {fmt!r} (fp8_e4m3)")
+        if self.dtype != torch.bfloat16:
+            raise _lib.WipaError("quantize_weights: fp8 weights run with bf16 activations: call set_dtype(torch.bfloat16) first")
+        step = set(_decode_step_matrices(self.dims))
+        fp8 = {}
+        with on_stream():
+            for n, t in list(self._params.items()):
+                if not _is_matrix(n, t):
+                    continue
+                codes, scale = quantize_fp8_e4m3(t)
+                self._params[n] = dequantize_fp8_e4m3(codes, scale).to(torch.bfloat16).reshape(t.shape).contiguous()
+                if n in step:
+                    fp8[n] = (codes, scale)
+        self._invalidate()
+        self._fp8 = fp8
         return self
 
     def parameters(self) -> Dict:
@@ -174,18 +235,30 @@ class Whisper:
             st.release()
         self._generation = (getattr(self, "_generation", 0) + 1) & 0x7FFFFFFF
         self._packed = None
+        self._packed_tf = None
 
     # ---- packing -------------------------------------------------------------------
-    def _cfg(self) -> _lib.ModelCfg:
+    def _cfg(self, fp8: bool = False) -> _lib.ModelCfg:
         d = self.dims
         return _lib.ModelCfg(d.n_mels, d.n_audio_ctx, d.n_audio_state, d.n_audio_head, d.n_audio_layer, d.n_vocab,
                              d.n_text_ctx, d.n_text_state, d.n_text_head, d.n_text_layer, dt_code(self.dtype),
-                             int(self.f32_split and self.dtype == torch.float32), getattr(self, "_generation", 0))
+                             int(self.f32_split and self.dtype == torch.float32), _lib.WIPA_FP8_E4M3 if fp8 else 0,
+                             getattr(self, "_generation", 0))
 
-    def packed(self):
-        """(cfg, encoder table, decoder table); fused matrices are rebuilt after any update."""
-        if self._packed is not None:
-            return self._packed
+    def packed(self, teacher_forced: bool = False):
+        """(cfg, encoder table, decoder table); fused matrices are rebuilt after any update.  With fp8 weights the decoder
+        table carries the e4m3 codes + scales of the decode-step matrices; ``teacher_forced=True`` gives the all-bf16 table
+        (dequantised values) that wipa_decoder_logits needs."""
+        fp8 = bool(self._fp8) and not teacher_forced
+        if teacher_forced and self._fp8:
+            if self._packed_tf is None:
+                self._packed_tf = self._pack(False)
+            return self._packed_tf
+        if self._packed is None:
+            self._packed = self._pack(fp8)
+        return self._packed
+
+    def _pack(self, fp8: bool):
         P, T, d = self._params, self.dtype, self.dims
         kmul = 64 if T == torch.bfloat16 else 32
         f32 = torch.float32
@@ -233,11 +306,32 @@ class Whisper:
                         vec(P[f"{p}.mlp_ln.weight"]), vec(P[f"{p}.mlp_ln.bias"]),
                         mat(P[f"{p}.mlp1.weight"]), vec(P[f"{p}.mlp1.bias"]),
                         mat(P[f"{p}.mlp2.weight"]), vec(P[f"{p}.mlp2.bias"])]
-        assert len(enc) == _lib.ENC_GLOBAL + _lib.ENC_PER_LAYER * d.n_audio_layer
-        assert len(dec) == _lib.DEC_GLOBAL + _lib.DEC_PER_LAYER * d.n_text_layer
+            assert len(enc) == _lib.ENC_GLOBAL + _lib.ENC_PER_LAYER * d.n_audio_layer
+            assert len(dec) == _lib.DEC_GLOBAL + _lib.DEC_PER_LAYER * d.n_text_layer
+            if fp8:
+                # the decode-step matrices as e4m3 codes (rows concatenated like their bf16 counterparts) + per-row scales
+                F = self._fp8
+
+                def codes(*names):
+                    return torch.cat([F[n][0] for n in names], 0).to(self.device).contiguous()
+
+                def scales(*names):
+                    return torch.cat([F[n][1] for n in names], 0).to(device=self.device, dtype=f32).contiguous()
+
+                dec[0] = codes("decoder.token_embedding.weight")
+                tail = [scales("decoder.token_embedding.weight")]
+                for i in range(d.n_text_layer):
+                    p = f"decoder.blocks.{i}"
+                    groups = [(f"{p}.attn.query.weight", f"{p}.attn.key.weight", f"{p}.attn.value.weight"), (f"{p}.attn.out.weight",),
+                              (f"{p}.cross_attn.query.weight",), (f"{p}.cross_attn.out.weight",), (f"{p}.mlp1.weight",),
+                              (f"{p}.mlp2.weight",)]
+                    for slot, g in zip((2, 4, 8, 12, 16, 18), groups):
+                        dec[_lib.DEC_GLOBAL + _lib.DEC_PER_LAYER * i + slot] = codes(*g)
+                        tail.append(scales(*g))
+                dec += tail
+                assert len(tail) == 1 + _lib.DEC_FP8_PER_LAYER * d.n_text_layer
         stream().synchronize()  # the tables are read from every library stream
-        self._packed = dict(cfg=self._cfg(), enc=enc, dec=dec, enc_tab=ptr_table(enc), dec_tab=ptr_table(dec))
-        return self._packed
+        return dict(cfg=self._cfg(fp8), enc=enc, dec=dec, enc_tab=ptr_table(enc), dec_tab=ptr_table(dec))
 
     # ---- encoder -------------------------------------------------------------------
     def encode_padded(self, mel_padded: torch.Tensor, B: int) -> torch.Tensor:
@@ -274,7 +368,7 @@ class Whisper:
     def logits(self, tokens: torch.Tensor, audio_features: torch.Tensor) -> torch.Tensor:
         """tokens [B,T] int, features [B,1500,d] -> logits [B,T,V] f32 (train_whisper_ipa.py:232)."""
         L = _lib.lib()
-        pk = self.packed()
+        pk = self.packed(teacher_forced=True)
         B, T = tokens.shape
         V = self.dims.n_vocab
         ldl = (V + 7) // 8 * 8
