@@ -497,6 +497,16 @@ def run_train(args):
     the reference trains (:505), one rank's share of BASELINE.json configs[2] (32 clips, 64 target tokens) per GPU; under
     N > 1 the decoder gradients (614 MB) are all-reduced per block over RCCL, overlapped with the backward."""
     rank, world, dist, _ = init_ranks(args)
+    out = measure_train(args, rank, world, dist, args.steps, args.warmup)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def measure_train(args, rank, world, dist, steps, warmup):
+    """the timed fine-tune steps; returns the JSON object on rank 0 (None elsewhere)"""
     from whisper_ipa_amd.training import DecoderTrainer
     from whisper_ipa_amd.whisper import Whisper
 
@@ -516,12 +526,12 @@ def run_train(args):
     tok[:, -1] = eot
     tok = tok.cuda()
     log(f"train: rank {rank}/{world}, {B} clips x {T} target tokens, f32 products: {args.f32}")
-    for _ in range(max(1, args.warmup)):
+    for _ in range(max(1, warmup)):
         loss, _ = tr.train_step(mel, tok, eot)
     timed_barrier(dist)
     t0 = time.perf_counter()
     exposed = 0.0
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss, _ = tr.train_step(mel, tok, eot)
         exposed += tr.last_allreduce_exposed_ms
     timed_barrier(dist)
@@ -554,11 +564,11 @@ def run_train(args):
         enc = B * (2.0 * (3000 * de * 3 * dims.n_mels + Ta * de * 3 * de + dims.n_audio_layer * Ta * 12 * de * de)
                    + dims.n_audio_layer * 4.0 * Ta * Ta * de)
         f32_peak = 157.3  # TFLOP/s, f32 MFMA (MI355X_MICROARCH.md)
-        ms = 1000.0 * elapsed / args.steps
+        ms = 1000.0 * elapsed / steps
         out = {
             "metric": f"fine-tune clips/sec (whisper-{args.model} decoder-only, f32, {B} clips x {T} tokens per GPU)",
-            "value": round(world * B * args.steps / elapsed, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": round(world * B * steps / elapsed, 1), "unit": "clips/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": f"synthetic (seeded mel + token rows, random-init whisper-{args.model} weights)",
             "config": {"workload": f"whisper-{args.model} decoder fine-tune step (frozen encoder fwd + decoder fwd/bwd + masked CE + "
                                    f"per-tensor clip + AdamW), {B} clips x 30 s, {T} target tokens per GPU",
@@ -570,13 +580,11 @@ def run_train(args):
                          "achieved": round((dec + ckv + enc) / (ms * 1e-3) / 1e12, 1), "peak": f32_peak, "unit": "TFLOP/s",
                          "frac": round((dec + ckv + enc) / (ms * 1e-3) / 1e12 / f32_peak, 4), "traffic": None,
                          "note": "whole-step FLOPs / whole-step time (includes attention backward, CE, optimiser); f32 MFMA peak"},
-            "allreduce_exposed_ms_per_step": round(exposed / args.steps, 3) if world > 1 else 0.0,
+            "allreduce_exposed_ms_per_step": round(exposed / steps, 3) if world > 1 else 0.0,
             "grad_bytes": tr.n_params * 4,
         }
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        return out
+    return None
 
 
 def main():
@@ -590,6 +598,7 @@ def main():
     ap.add_argument("--streams", type=int, default=N_STREAMS, help="clip sub-batches run on this many HIP streams")
     ap.add_argument("--pipeline", type=int, default=N_PIPELINE, help="consecutive passes kept in flight on separate HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-finetune", action="store_true", help="skip the short fine-tune step measurement appended to the default line")
     ap.add_argument("--decode-group", type=int, default=1,
                     help="EXPERIMENT: decode this many consecutive 64-clip batches together (encoder still per batch)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"],
@@ -705,6 +714,18 @@ def main():
             out["cpu_baseline"], ref = cpu_baseline(8)  # ~25 s of host work
             out["parity_vs_cpu"] = parity_vs_cpu(single, ref, len(setup[0]))
             log("cpu baseline + parity done")
+        if world == 1 and not args.no_finetune and args.model == "small" and args.dtype == "bf16" and args.weights == "bf16":
+            # BASELINE.json configs[2], one rank's share, next to the headline number (outside its timed region): the step the
+            # reference times at scripts/train_whisper_ipa.py:552-555, float32 with exact products.  `--mode train` is the
+            # full-length / multi-rank form of the same measurement.
+            import gc
+
+            del model
+            gc.collect()  # the decode states reference the model (cycle): collect before returning the 20+ GB of caches
+            torch.cuda.empty_cache()
+            ft = measure_train(args, 0, 1, None, steps=3, warmup=1)
+            out["finetune_step"] = {k: ft[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "stages", "roofline", "loss")}
+            log("fine-tune step measured")
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -1,6 +1,12 @@
 #!/usr/bin/env python3
-"""PMC target (no hipGraph: counters + graph replay hung once): the logits projection of a decode step,
-M = 64 rows, N = 51 865, K = 768, bf16 -> f32, ten plain launches."""
+"""PMC target: the logits projection of a decode step, M = 64 rows, N = 51 865, K = 768, bf16 -> f32, ten plain launches.
+Collect in SEPARATE passes of at most ~4 counters (one oversized --pmc set aborted rocprofv3 in round 1 with "Request exceeds
+the capabilities of the hardware"), program directly after `--`:
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d out/f -- python3 tools/pmc_logits.py
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d out/w -- python3 tools/pmc_logits.py
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d out/s -- python3 tools/pmc_logits.py
+(The library enqueues decode steps eagerly while counters are attached -- runtime.hip counters_attached() -- so whole-model
+targets are safe too; this one only needs the GEMM.)"""
 import os
 import sys
 

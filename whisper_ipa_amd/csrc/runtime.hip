@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
+#include <strings.h>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -574,6 +575,16 @@ int enqueue_prefill(const wipa_model_cfg* cfg, const void* const* w, char* st, c
     return WIPA_OK;
 }
 
+// Hardware-counter collection (rocprofv3 --pmc sets ROCPROF_COUNTER_COLLECTION) serialises every dispatch and intercepts the
+// queues; a captured step replayed under it hung once in round 1 (no record of the last dispatch survived, so the cause --
+// capture under the intercept, or graph launch under serialised dispatch -- could not be pinned).  The library therefore does
+// not capture or replay graphs while counters are attached: the same kernels are enqueued eagerly, which is also what a
+// per-kernel counter run wants.  Kernel tracing alone (--kernel-trace / --stats) keeps the graphs.
+bool counters_attached() {
+    const char* e = getenv("ROCPROF_COUNTER_COLLECTION");
+    return e && *e && strcmp(e, "0") != 0 && strcasecmp(e, "false") != 0;
+}
+
 // graph cache: one captured step per (state blob, weights, masks, shape)
 // The key carries cfg->weights_generation: the host address of a weight table can be reused by a NEW table after the old
 // one was freed, so the address alone does not identify the device pointers baked into a captured graph.
@@ -677,7 +688,7 @@ extern "C" int wipa_decoder_run(const wipa_model_cfg* cfg, const void* const* w,
     const wipa_dec_layout L = dec_layout(cfg, B);
     char* st = (char*)state;
     hipStream_t s = (hipStream_t)stream;
-    if (!use_graph) {
+    if (!use_graph || counters_attached()) {
         for (int i = 0; i < n_steps; ++i)
             RT_CALL(enqueue_decode_step(cfg, w, st, L, B, n_init, eot, mask_first, mask_always, stream));
         return WIPA_OK;
@@ -723,7 +734,7 @@ extern "C" int wipa_decoder_prefill(const wipa_model_cfg* cfg, const void* const
         return enqueue_prefill(cfg, w, st, L, B, n_init, eot, mask_first, mask_always, stream);
     };
     hipStream_t s = (hipStream_t)stream;
-    if (!use_graph || s == nullptr) return enqueue();
+    if (!use_graph || s == nullptr || counters_attached()) return enqueue();
     hipGraphExec_t exec = nullptr;
     const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * (int)use_fused_step(cfg, B) + 8 * cfg->dec_w_dtype, cfg->weights_generation, 1);
     {
