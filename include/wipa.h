@@ -216,7 +216,8 @@ typedef struct wipa_self_block_desc {
 } wipa_self_block_desc;
 int wipa_decode_self_block(const wipa_self_block_desc* d, wipa_stream_t s);
 /* cross block, one workgroup per (head, clip):
- *   r = x_in[b] + bias_o + slabs[0][b] + ... + slabs[n_slabs-1][b] (that order; the h = 0 workgroup stores r to x_out[b]) ->
+ *   r = x_in[b] + bias_o + slabs[0][b] + ... + slabs[n_slabs-1][b] (that order; bias_o may be NULL when slab 0 already carries
+ *   the bias, as the split-K slabs of wipa_gemm do; the h = 0 workgroup stores r to x_out[b]) ->
  *   y = LayerNorm(r; ln_w, ln_b) -> q_h = (y Wq[h]^T + bq) * qk_scale (rounded to T) -> out[b][h*64:(h+1)*64] =
  *   softmax(q_h K^T) V over the cached cross keys/values kv [B][2H][Tk][64] T (K heads then V heads; every element read
  *   once, non-temporal).  x_out must not alias x_in.  n_slabs <= 20. */

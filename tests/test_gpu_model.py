@@ -220,15 +220,22 @@ def test_fused_decode_step_equals_unfused_step(micro, small2, monkeypatch, dtype
         m = _model(dims, W, dtype)
         feats = xa.cuda().to(dtype)
         out = {}
-        for fused in ("1", "0"):
+        for fused in ("1", "2", "0"):
             monkeypatch.setenv("WIPA_DECODE_FUSED", fused)
             for use_graph in (True, False):
                 r = greedy_decode_tokens(m, feats, init, always, first, sp.eot, max_new_tokens=n_new, stop_on_eot=False,
                                          use_graph=use_graph)
                 out[(fused, use_graph)] = (r.tokens, r.sum_logprobs.copy(), r.last_logits.float().cpu().clone())
         monkeypatch.delenv("WIPA_DECODE_FUSED")
-        a, b = out[("1", True)], out[("0", True)]
-        assert (a[0] == out[("1", False)][0]).all() and torch.equal(a[2], out[("1", False)][2])  # graph == eager, bit for bit
+        for mode in ("1", "2"):
+            assert (out[(mode, True)][0] == out[(mode, False)][0]).all() and torch.equal(out[(mode, True)][2], out[(mode, False)][2])  # graph == eager
+        h, b = out[("2", True)], out[("0", True)]  # mode 2: only the cross block differs from the unfused step
+        if dtype == torch.float32:
+            assert (h[0] == b[0]).all() and np.abs(h[1] - b[1]).max() < 1e-3 and (h[2] - b[2]).abs().max() < 2e-4
+        else:
+            same2 = np.cumprod(h[0] == b[0], axis=1).astype(bool)
+            assert same2[:, : 4 + 6].all(), (h[0].tolist(), b[0].tolist())
+        a = out[("1", True)]
         if dtype == torch.float32:
             assert (a[0] == b[0]).all(), (a[0].tolist(), b[0].tolist())
             assert np.abs(a[1] - b[1]).max() < 1e-3 and (a[2] - b[2]).abs().max() < 2e-4

@@ -23,4 +23,26 @@ out = torch.zeros(M, 51872, device="cuda")
 for _ in range(10):
     ops.gemm(A, W, out, M=M, N=N, K=K, lda=K, ldw=K, ldc=51872)
 torch.cuda.synchronize()
+if "ROCPROF_COUNTER_COLLECTION" not in os.environ:  # plain run: event timing over graph-replayed launches
+    from whisper_ipa_amd.runtime import stream
+
+    s = stream()
+    Ws = [W] + [W.clone() for _ in range(3)]  # cycle 4 copies (320 MB) so the weights are not cache resident
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        for w in Ws:
+            ops.gemm(A, w, out, M=M, N=N, K=K, lda=K, ldw=K, ldc=51872)
+    s.synchronize()
+    with torch.cuda.graph(graph, stream=s):
+        for i in range(40):
+            ops.gemm(A, Ws[i % 4], out, M=M, N=N, K=K, lda=K, ldw=K, ldc=51872)
+    with torch.cuda.stream(s):
+        graph.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        graph.replay()
+        e1.record(s)
+    e1.synchronize()
+    us = e0.elapsed_time(e1) / 40 * 1e3
+    print(f"logits GEMM WIPA_SKINNY_WIDE_NT={os.environ.get('WIPA_SKINNY_WIDE_NT', '4')}: {us:.2f} us  {(N * K * 2 + M * 51872 * 4) / us / 1e6:.2f} TB/s")
 print("done")

@@ -346,6 +346,17 @@ __global__ __launch_bounds__(256, 6) void decode_cross_block_kernel(CrossBlockPa
     const int h = blockIdx.x, b = blockIdx.y;
     const int d = p.d;
 
+    // The cross-query weights do not depend on the residual row: the first batch of this thread's 16-byte chunks of row
+    // (h*64 + j) is requested before anything else, so its round trip overlaps the prologue's.
+    constexpr int UQ = 6;
+    const int qj = tid >> 2, qpart = tid & 3;
+    const T* wr = reinterpret_cast<const T*>(p.wq) + (int64_t)(h * 64 + qj) * d;
+    const int nch = d / EPL;  // 16-byte chunks per weight row
+    Vec16<T> wcur[UQ];
+#pragma unroll
+    for (int u = 0; u < UQ; ++u)
+        if (qpart + 4 * u < nch) wcur[u] = *reinterpret_cast<const Vec16<T>*>(wr + (qpart + 4 * u) * EPL);
+
     // ---- 1. residual row: x + out-bias + slabs in order 0..n-1; LayerNorm -> xn (rounded through T)
     {
         f32x4 v[2];
@@ -356,8 +367,7 @@ __global__ __launch_bounds__(256, 6) void decode_cross_block_kernel(CrossBlockPa
             v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (c < d) {
                 v[i] = *reinterpret_cast<const f32x4*>(p.x_in + (int64_t)b * d + c);
-                const f32x4 bo = *reinterpret_cast<const f32x4*>(p.bias_o + c);
-                v[i] += bo;
+                if (p.bias_o) v[i] += *reinterpret_cast<const f32x4*>(p.bias_o + c);
                 // slabs in groups of SG loads in flight (all 20 at once cost 80 registers and a third of the occupancy the
                 // streaming phase wants); the additions stay in slab order
                 constexpr int SG = 6;
@@ -412,32 +422,27 @@ __global__ __launch_bounds__(256, 6) void decode_cross_block_kernel(CrossBlockPa
 
     // ---- 2. cross query of head h: q[j] = (xn . Wq[h*64 + j, :] + bq) * scale, 4 threads per output
     {
-        const int j = tid >> 2, part = tid & 3;
-        const T* wr = reinterpret_cast<const T*>(p.wq) + (int64_t)(h * 64 + j) * d;
-        const int nch = d / EPL;  // 16-byte chunks per weight row
         float a = 0.f;
-        constexpr int UQ = 6;
-        int ch = part;
-        for (; ch + 4 * (UQ - 1) < nch; ch += 4 * UQ) {
-            Vec16<T> wv[UQ];
+        for (int ch = qpart; ch < nch; ch += 4 * UQ) {  // two register sets: the next batch is in flight while this one is spent
+            Vec16<T> wnext[UQ];
+            const int chn = ch + 4 * UQ;
 #pragma unroll
-            for (int u = 0; u < UQ; ++u) wv[u] = *reinterpret_cast<const Vec16<T>*>(wr + (ch + 4 * u) * EPL);
+            for (int u = 0; u < UQ; ++u)
+                if (chn + 4 * u < nch) wnext[u] = *reinterpret_cast<const Vec16<T>*>(wr + (chn + 4 * u) * EPL);
 #pragma unroll
             for (int u = 0; u < UQ; ++u) {
-                const float* xp = xn + (ch + 4 * u) * EPL;
+                if (ch + 4 * u < nch) {
+                    const float* xp = xn + (ch + 4 * u) * EPL;
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) a = fmaf(xp[e], wv[u].get(e), a);
+                    for (int e = 0; e < EPL; ++e) a = fmaf(xp[e], wcur[u].get(e), a);
+                }
             }
-        }
-        for (; ch < nch; ch += 4) {
-            const Vec16<T> wv = *reinterpret_cast<const Vec16<T>*>(wr + ch * EPL);
-            const float* xp = xn + ch * EPL;
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) a = fmaf(xp[e], wv.get(e), a);
+            for (int u = 0; u < UQ; ++u) wcur[u] = wnext[u];
         }
         a += __shfl_xor(a, 1, 64);
         a += __shfl_xor(a, 2, 64);
-        if (part == 0) q_s[j] = round_through<T>((a + p.bq[h * 64 + j]) * p.qk_scale);
+        if (qpart == 0) q_s[qj] = round_through<T>((a + p.bq[h * 64 + qj]) * p.qk_scale);
     }
     __syncthreads();
 
@@ -577,7 +582,7 @@ extern "C" int wipa_decode_self_block(const wipa_self_block_desc* d, wipa_stream
 }
 
 extern "C" int wipa_decode_cross_block(const wipa_cross_block_desc* d, wipa_stream_t stream) {
-    WIPA_REQUIRE(d && d->x_in && d->x_out && d->bias_o && d->ln_w && d->ln_b && d->wq && d->bq && d->kv && d->out &&
+    WIPA_REQUIRE(d && d->x_in && d->x_out && d->ln_w && d->ln_b && d->wq && d->bq && d->kv && d->out &&
                      (d->slabs || d->n_slabs == 0), "wipa_decode_cross_block: null pointer");
     WIPA_REQUIRE(d->dtype == WIPA_F32 || d->dtype == WIPA_BF16, "wipa_decode_cross_block: dtype %d", d->dtype);
     WIPA_REQUIRE(d->B > 0 && d->B <= 65535 && d->H > 0 && d->d == d->H * 64 && d->d <= 1280 && d->Tk > 0,

@@ -857,7 +857,9 @@ int launch_skinny_cfg(const GemmParams& p, hipStream_t s) {
 template <typename T, typename OutT, int MT>
 int launch_skinny_mt(const GemmParams& p, hipStream_t s) {
     const int ksteps = p.K * (int)sizeof(T) / 64 / p.k_slices;
-    if (p.N >= 8192 && MT == 4) return launch_skinny_cfg<T, OutT, MT, 4, 4>(p, s);  // logits: 64 columns per workgroup
+    static const int wide_nt = [] { const char* e = getenv("WIPA_SKINNY_WIDE_NT"); return e ? atoi(e) : 4; }();  // A/B timing
+    if (p.N >= 8192 && MT == 4 && wide_nt == 4) return launch_skinny_cfg<T, OutT, MT, 4, 4>(p, s);  // logits: 64 columns per workgroup
+    if (p.N >= 8192 && wide_nt == 1) return launch_skinny_cfg<T, OutT, MT, 1, 4>(p, s);
     if (p.N >= 8192) return launch_skinny_cfg<T, OutT, MT, 2, 4>(p, s);
     if (ksteps >= 64) return launch_skinny_cfg<T, OutT, MT, 1, 8>(p, s);
     return launch_skinny_cfg<T, OutT, MT, 1, 4>(p, s);

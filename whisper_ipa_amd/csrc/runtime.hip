@@ -247,6 +247,7 @@ inline int k_slices_for(int K, int dtype) {
     int s = ksteps / 12;
     return s < 1 ? 1 : (s > MAX_SLABS ? MAX_SLABS : s);
 }
+int decode_mode(const wipa_model_cfg* cfg, int B);  // 0 unfused, 1 fused blocks, 2 unfused + fused cross block (defined below)
 constexpr int MAX_PROMPT = 4;  // prompt positions handled by one prefill pass (wipa_decoder_begin takes 1..4 tokens)
 DecScratch dec_scratch(const wipa_model_cfg* c, int B) {
     const size_t e = wipa_dtype_size(c->dtype), d = c->n_text_state;
@@ -309,6 +310,8 @@ int enqueue_step(const wipa_model_cfg* cfg, const void* const* w, char* st, cons
     const DecScratch S = dec_scratch(cfg, B);
     char* sc = st + L.scratch;
     float* x = (float*)(sc + S.x);
+    float* x_other = (float*)(sc + S.x2);
+    const bool cross_fused = decode_mode(cfg, B) == 2;
     void* ln = sc + S.ln;
     void* q = sc + S.q;
     void* ao = sc + S.ao;
@@ -366,14 +369,28 @@ int enqueue_step(const wipa_model_cfg* cfg, const void* const* w, char* st, cons
             RT_CALL(wipa_decode_attn(&a, stream));
         }
         RT_CALL(residual_gemm(ao, d, lw[4], lw[5]));
-        RT_CALL(ln_step(lw[6], lw[7]));
-        {
-            wipa_gemm_desc g;
-            memset(&g, 0, sizeof(g));
-            g.col_scale_n = d; g.col_scale = QK_SCALE;
-            RT_CALL(gemm(ln, d, lw[8], d, q, d, B, d, d, dt, dt, (const float*)lw[9], 0, nullptr, stream, &g));
+        if (cross_fused) {
+            // one launch for [slab sum + residual + cross_attn_ln + cross query + cross-attention]; the residual row moves to
+            // the other buffer (H workgroups read the row that one of them writes)
+            wipa_cross_block_desc c;
+            memset(&c, 0, sizeof(c));
+            c.x_in = x; c.x_out = x_other; c.slabs = slabs; c.bias_o = nullptr;  // slab 0 carries the out-projection bias
+            c.ln_w = (const float*)lw[6]; c.ln_b = (const float*)lw[7]; c.wq = lw[8]; c.bq = (const float*)lw[9];
+            c.kv = ckv; c.out = ao; c.slab_stride = slab_stride;
+            c.n_slabs = pend; c.B = B; c.d = d; c.H = H; c.Tk = Ta; c.dtype = dt; c.eps = 1e-5f; c.qk_scale = QK_SCALE;
+            RT_CALL(wipa_decode_cross_block(&c, stream));
+            pend = 0;
+            std::swap(x, x_other);
+        } else {
+            RT_CALL(ln_step(lw[6], lw[7]));
+            {
+                wipa_gemm_desc g;
+                memset(&g, 0, sizeof(g));
+                g.col_scale_n = d; g.col_scale = QK_SCALE;
+                RT_CALL(gemm(ln, d, lw[8], d, q, d, B, d, d, dt, dt, (const float*)lw[9], 0, nullptr, stream, &g));
+            }
+            RT_CALL(wipa_decode_cross_attn(q, ckv, ao, B, H, Ta, dt, stream));
         }
-        RT_CALL(wipa_decode_cross_attn(q, ckv, ao, B, H, Ta, dt, stream));
         RT_CALL(residual_gemm(ao, d, lw[12], lw[13]));
         RT_CALL(ln_step(lw[14], lw[15]));
         RT_CALL(gemm(ln, d, lw[16], d, hb, 4 * d, B, 4 * d, d, dt, dt, (const float*)lw[17], 1, nullptr, stream));
@@ -455,15 +472,24 @@ int enqueue_step_fused(const wipa_model_cfg* cfg, const void* const* w, char* st
     return WIPA_OK;
 }
 
-// WIPA_DECODE_FUSED=1 selects the fused step; read at enqueue / capture time and part of the graph key.  It is NOT the default:
-// measured on MI355X (whisper-small bf16, 64 rows, r02, profiles/r02_fused_step_by_kernel.txt) the fused step takes 2.05 ms
-// against 1.35 ms -- each fused block is a chain of dependent memory round trips (LayerNorm rows -> weight fragments ->
-// cache rows -> weight fragments) that costs more than the ~4.5 us launch gaps it removes: self block 34.9 us vs 23.4 us for
-// the four launches it replaces, LayerNorm-prologue mlp1 37.2 us vs 12 us, cross block 57.8 us vs 58.7 us.
-bool use_fused_step(const wipa_model_cfg* cfg, int B) {
+// Decode-step variants, WIPA_DECODE_FUSED (read at enqueue / capture time, part of the graph key):
+//   2 (default)  the unfused step with ONE fusion: [split-K slab sum + residual + cross_attn_ln + cross query + cross-attention]
+//                in a single launch (wipa_decode_cross_block, query weights prefetched under the prologue): 9 launches per
+//                layer, 1.311 ms per step against 1.352 ms (whisper-small bf16, 64 rows, MI355X, r02);
+//   0            the unfused step, 11 launches per layer;
+//   1            every fused block (5 launches per layer).  NOT the default: it measured 2.05 ms per step
+//                (profiles/r02_fused_step_by_kernel.txt) -- a fused block is a chain of dependent memory round trips (LayerNorm
+//                rows -> weight fragments -> cache rows -> weight fragments) that costs more than the ~4.5 us launch gaps it
+//                removes: self block 34.9 us vs 23.4 us for the four launches it replaces, LayerNorm-prologue mlp1 37.2 us vs
+//                12 us, and without split-K the mlp2 projection has 48 workgroups to stream 4.7 MB (19.7 us vs 7.4 us).
+int decode_mode(const wipa_model_cfg* cfg, int B) {
     const char* e = getenv("WIPA_DECODE_FUSED");
-    return (e ? atoi(e) : 0) != 0 && cfg->dec_w_dtype == 0 && cfg->n_text_state <= 1280 && cfg->n_text_head <= 20 && B <= 65535;
+    const int m = e ? atoi(e) : 2;
+    // the fused blocks read their weights as T: fp8 tables stay on the unfused step
+    if (m == 0 || cfg->dec_w_dtype != 0 || cfg->n_text_state > 1280 || cfg->n_text_head > 20 || B > 65535) return 0;
+    return m == 1 ? 1 : 2;
 }
+bool use_fused_step(const wipa_model_cfg* cfg, int B) { return decode_mode(cfg, B) == 1; }
 
 int enqueue_decode_step(const wipa_model_cfg* cfg, const void* const* w, char* st, const wipa_dec_layout& L, int B, int n_init,
                         int eot, const float* mask_first, const float* mask_always, wipa_stream_t stream) {
@@ -695,7 +721,7 @@ extern "C" int wipa_decoder_run(const wipa_model_cfg* cfg, const void* const* w,
     }
     WIPA_REQUIRE(s != nullptr, "wipa_decoder_run: graph capture needs a non-default stream");
     hipGraphExec_t exec = nullptr;
-    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * (int)use_fused_step(cfg, B) + 8 * cfg->dec_w_dtype, cfg->weights_generation, 0);
+    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * decode_mode(cfg, B) + 16 * cfg->dec_w_dtype, cfg->weights_generation, 0);
     {
         std::lock_guard<std::mutex> lk(g_graph_mu);
         auto it = g_graphs.find(key);
@@ -736,7 +762,7 @@ extern "C" int wipa_decoder_prefill(const wipa_model_cfg* cfg, const void* const
     hipStream_t s = (hipStream_t)stream;
     if (!use_graph || s == nullptr || counters_attached()) return enqueue();
     hipGraphExec_t exec = nullptr;
-    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * (int)use_fused_step(cfg, B) + 8 * cfg->dec_w_dtype, cfg->weights_generation, 1);
+    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * decode_mode(cfg, B) + 16 * cfg->dec_w_dtype, cfg->weights_generation, 1);
     {
         std::lock_guard<std::mutex> lk(g_graph_mu);
         auto it = g_graphs.find(key);
