@@ -251,6 +251,23 @@ int wipa_greedy_step(const float* logits, int64_t ldl, int B, int V, const float
                      int eot, float* sum_logprobs, int32_t* not_done, wipa_stream_t s);
 int wipa_add_i32(int32_t* p, int32_t v, wipa_stream_t s);
 
+/* ------------------------------------------------------------------ host-side text plumbing (no GPU work)
+ * Byte-level BPE of mlx_whisper.tokenizer (tiktoken's CoreBPE) and the token-batch builder of
+ * IPADataset._tokenize_ipa_batch (scripts/ipa_data_loader.py:102-131, 146-152).  HOST pointers throughout.
+ * The GPT-2 pre-tokeniser regex stays with the caller: encode one pre-split piece at a time.
+ * table: n tokens, their bytes concatenated in `blob` (token i has lens[i] bytes) with rank ranks[i]
+ *        (multilingual.tiktoken: 50 257 entries; the 256 single bytes must be present). */
+typedef struct wipa_bpe wipa_bpe;
+wipa_bpe* wipa_bpe_create(const uint8_t* blob, const int32_t* lens, const int32_t* ranks, int n); /* NULL on error */
+void wipa_bpe_free(wipa_bpe* b);
+/* lowest-rank-first pair merging; returns the number of ids written (<= max_out) or a negative error */
+int wipa_bpe_encode_piece(const wipa_bpe* b, const uint8_t* piece, int len, int32_t* out, int max_out);
+/* bytes of the ids, concatenated; returns the byte count, a negative WIPA_ERR_*, or -(i+1)-100 if ids[i] is not in the table */
+int wipa_bpe_decode(const wipa_bpe* b, const int32_t* ids, int n, uint8_t* out, int max_out);
+/* rows = prefix + ids of row r + eot, eot-padded to the longest row; returns the row width (<= ld_out) */
+int wipa_build_token_batch(const int32_t* ids, const int32_t* row_lens, int n_rows, const int32_t* prefix, int n_prefix,
+                           int32_t eot, int32_t* out, int64_t ld_out);
+
 /* ------------------------------------------------------------------ model runtime
  * Sequencing of the kernels above for a whole encoder / decoder pass, in C++ so the
  * decode loop runs from a hipGraph with no per-kernel host work. */

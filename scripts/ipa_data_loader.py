@@ -52,10 +52,21 @@ class IPADataset:
 
     def tokenize_batch(self, ipa_texts: List[str]) -> torch.Tensor:
         """<|sot|><|en|><|transcribe|><|notimestamps|> ipa <|eot|>, EOT-padded to the longest row."""
+        import ctypes as C
+
+        from whisper_ipa_amd import _lib
+
         tok = self.tokenizer
-        rows = [list(tok.sot_sequence_including_notimestamps) + tok.encode(t) + [tok.eot] for t in ipa_texts]
-        width = max(len(r) for r in rows)
-        return torch.tensor([r + [tok.eot] * (width - len(r)) for r in rows], dtype=torch.int32)
+        ids = [tok.encode(t) for t in ipa_texts]
+        prefix = list(tok.sot_sequence_including_notimestamps)
+        n = len(ids)
+        flat = [i for row in ids for i in row]
+        ld = len(prefix) + max(len(r) for r in ids) + 1
+        out = torch.empty(n, ld, dtype=torch.int32)
+        width = _lib.lib().wipa_build_token_batch((C.c_int32 * max(len(flat), 1))(*flat), (C.c_int32 * n)(*[len(r) for r in ids]), n,
+                                                  (C.c_int32 * len(prefix))(*prefix), len(prefix), tok.eot, out.data_ptr(), ld)
+        _lib.check(0 if width > 0 else width, "wipa_build_token_batch")
+        return out[:, :width].contiguous()
 
     # reference name (ipa_data_loader.py:102)
     _tokenize_ipa_batch = tokenize_batch

@@ -489,3 +489,47 @@ def test_fp8_e4m3_quantiser():
     big = W2.abs() > 2.0 ** -6 * scale[:, None] * 8  # normal range: relative error <= 2^-4
     assert (err[big] / W2.abs()[big]).max() <= 2.0 ** -4
     assert (dq[5] == 0).all()
+
+
+def test_native_bpe_matches_the_python_merge_loop(tmp_path):
+    """csrc/text_host.cpp (wipa_bpe_*) against the pure-Python statement of tiktoken's lowest-rank-first merging, on a
+    synthetic table with competing merges, on every IPA string of the reference's test split (byte-level table) and on
+    random byte strings; decode round trips; the batch builder against the list arithmetic of ipa_data_loader.py:102-131."""
+    import ctypes as C
+
+    from whisper_ipa_amd import _lib
+    from whisper_ipa_amd.tokenizer import Tokenizer, _NativeBPE, _bpe, gpt2_byte_ranks
+
+    ranks = dict(gpt2_byte_ranks())
+    for i, t in enumerate([b"ab", b"bc", b"abc", b"cd", b"abcd", b" a", "ə".encode(), "əː".encode(), b"aa", b"aaa", b"aaaa", b"\xc9\x99\xcb"]):
+        ranks[t] = 256 + i
+    nat = _NativeBPE(ranks)
+    rng = np.random.default_rng(0)
+    cases = [b"abcd", b"abcabcd", b"aaaaaaa", b"bcd", "əːə".encode(), b" ab", b"x", b"", bytes(range(256))]
+    cases += [bytes(rng.choice(list(b"abcd \xc9\x99\xcb\x90"), size=int(n))) for n in rng.integers(1, 40, size=200)]
+    for piece in cases:
+        want = _bpe(ranks, piece) if piece else []
+        got = nat.encode_piece(piece)
+        assert got == want, (piece, got, want)
+        assert nat.decode_bytes(got) == piece
+    assert nat.decode_bytes([5, 99999]) is None  # unknown id: left to the caller (special tokens)
+    tok = Tokenizer(gpt2_byte_ranks(), byte_fallback=True)
+    p = "/root/reference/data/v2_filtered/combined_test_ipa.json"
+    texts = [e["ipa_transcription"] for e in json.load(open(p))[:300]] if os.path.exists(p) else ["kæt n̩ tʰ əː", "ɛ̃ ʃ"]
+    for s in texts:
+        ids = tok.encode(s)
+        assert ids == [i for piece in tok._pat.findall(s) for i in _bpe(tok.ranks, piece.encode("utf-8"))]
+        assert tok.decode(ids) == s
+    # batch builder
+    L = _lib.lib()
+    rows = [[5, 6, 7], [], [9] * 11, [1]]
+    prefix, eot = [50258, 50259, 50359, 50363], 50257
+    flat = [i for r in rows for i in r]
+    out = torch.full((4, 20), -1, dtype=torch.int32)
+    w = L.wipa_build_token_batch((C.c_int32 * len(flat))(*flat), (C.c_int32 * 4)(*[len(r) for r in rows]), 4, (C.c_int32 * 4)(*prefix), 4, eot,
+                                 out.data_ptr(), 20)
+    assert w == 4 + 11 + 1
+    want = [prefix + r + [eot] * (w - 4 - len(r)) for r in rows]
+    assert out[:, :w].tolist() == want and (out[:, w:] == -1).all()
+    assert L.wipa_build_token_batch((C.c_int32 * len(flat))(*flat), (C.c_int32 * 4)(*[len(r) for r in rows]), 4, (C.c_int32 * 4)(*prefix), 4, eot,
+                                    out.data_ptr(), 10) < 0  # rows do not fit

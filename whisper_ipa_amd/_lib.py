@@ -113,6 +113,11 @@ SIGNATURES = {
     "wipa_greedy_step": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int,
                                  c_int, c_void_p, c_void_p, c_void_p]),
     "wipa_add_i32": (c_int, [c_void_p, C.c_int32, c_void_p]),
+    "wipa_bpe_create": (c_void_p, [c_void_p, c_void_p, c_void_p, c_int]),
+    "wipa_bpe_free": (None, [c_void_p]),
+    "wipa_bpe_encode_piece": (c_int, [c_void_p, C.c_char_p, c_int, c_void_p, c_int]),
+    "wipa_bpe_decode": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int]),
+    "wipa_build_token_batch": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, C.c_int32, c_void_p, c_int64]),
     "wipa_profile_begin": (c_int, [c_void_p]),
     "wipa_profile_end": (c_int, [_P(c_float), _P(c_int)]),
     "wipa_encoder_workspace_bytes": (c_size_t, [_P(ModelCfg), c_int]),

@@ -62,7 +62,8 @@ def load_tiktoken_ranks(path: str) -> Dict[bytes, int]:
 
 
 def _bpe(ranks: Dict[bytes, int], piece: bytes) -> List[int]:
-    """Byte-pair merge by lowest rank (tiktoken's algorithm)."""
+    """Byte-pair merge by lowest rank (tiktoken's algorithm), pure Python: the statement the native
+    wipa_bpe_encode_piece (csrc/text_host.cpp) is tested against; the Tokenizer itself calls the native one."""
     if piece in ranks:
         return [ranks[piece]]
     parts = [bytes([b]) for b in piece]
@@ -76,6 +77,57 @@ def _bpe(ranks: Dict[bytes, int], piece: bytes) -> List[int]:
             break
         parts[best : best + 2] = [parts[best] + parts[best + 1]]
     return [ranks[p] for p in parts]
+
+
+class _NativeBPE:
+    """The merge table inside libwipa (wipa_bpe_*): built once per Tokenizer, freed with it."""
+
+    def __init__(self, ranks: Dict[bytes, int]):
+        import ctypes as C
+
+        from . import _lib
+
+        self._C, self._L = C, _lib.lib()
+        toks = list(ranks.items())
+        blob = b"".join(t for t, _ in toks)
+        lens = (C.c_int32 * len(toks))(*[len(t) for t, _ in toks])
+        rk = (C.c_int32 * len(toks))(*[r for _, r in toks])
+        self._h = self._L.wipa_bpe_create(blob, lens, rk, len(toks))
+        if not self._h:
+            raise _lib.WipaError("wipa_bpe_create failed: " + (self._L.wipa_last_error() or b"").decode())
+
+    def encode_piece(self, piece: bytes) -> List[int]:
+        C = self._C
+        buf = (C.c_int32 * max(len(piece), 1))()
+        n = self._L.wipa_bpe_encode_piece(self._h, piece, len(piece), buf, len(buf))
+        if n < 0:
+            from . import _lib
+
+            raise _lib.WipaError(f"wipa_bpe_encode_piece failed ({n}): " + (self._L.wipa_last_error() or b"").decode())
+        return list(buf[:n])
+
+    def decode_bytes(self, ids: Sequence[int]) -> Optional[bytes]:
+        """bytes of ids that are all in the table, else None"""
+        C = self._C
+        arr = (C.c_int32 * len(ids))(*ids)
+        cap = 64 + 16 * len(ids)
+        while True:
+            buf = (C.c_uint8 * cap)()
+            n = self._L.wipa_bpe_decode(self._h, arr, len(ids), buf, cap)
+            if n >= 0:
+                return bytes(buf[:n])
+            if n == -1 and cap < (1 << 24):  # WIPA_ERR_ARG: buffer too small
+                cap *= 8
+                continue
+            return None
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.wipa_bpe_free(self._h)
+                self._h = None
+        except Exception:
+            pass
 
 
 @dataclass
@@ -98,6 +150,7 @@ class Tokenizer:
         self._decoder = {v: k for k, v in self.ranks.items()}
         self._special_decoder = {v: k for k, v in self.special_tokens.items()}
         self._pat = _compile_pat()
+        self._native = _NativeBPE(self.ranks)
         # like mlx_whisper, sot_sequence is frozen here: assigning .language later (ipa_data_loader.py:152)
         # does NOT change it.
         seq = [self.sot]
@@ -143,7 +196,7 @@ class Tokenizer:
     def encode(self, text: str) -> List[int]:
         out: List[int] = []
         for piece in self._pat.findall(text):
-            out.extend(_bpe(self.ranks, piece.encode("utf-8")))
+            out.extend(self._native.encode_piece(piece.encode("utf-8")))
         return out
 
     def decode(self, token_ids: Sequence[int]) -> str:
