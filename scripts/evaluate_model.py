@@ -6,7 +6,7 @@ target thresholds (reference :127-268), same CLI flags (:272-308).
 Differences that the hardware asks for:
   * clips are decoded in batches of ``--batch-size`` (the reference is batch 1, :181-212); the
     result per clip is the same because every kernel on the path is batch-invariant
-    (tests/test_gpu_model.py::test_batch_invariance_full_size);
+    (tests/test_gpu_model.py::tests/test_gpu_model.py::test_full_size_bench_workload_properties);
   * under ``torchrun`` every rank takes a contiguous slice of the test list with a full weight
     replica and no collective on the data path; the hypotheses are gathered once at the end;
   * the base model is a local directory (no hub access) and the base-model leg uses the same
