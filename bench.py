@@ -76,6 +76,7 @@ N_PIPELINE = 4      # consecutive passes kept in flight on separate HIP streams 
 N_STREAMS = 1       # sub-batches of the 64 clips, one HIP stream each (measured r01: 1 -> 162 ms,
                     # 2 -> 156 ms, 4 -> 200 ms, 8 -> 266 ms per pass: the per-step cost of the decode
                     # loop is launch/latency bound and does not shrink with the sub-batch)
+DECODE_SPLIT = 1    # see --decode-split
 NEW_TOKENS = 64     # decode positions per clip (SURVEY.md section 8d primary setting)
 HBM_PEAK_GBS = 8000.0
 MFMA_BF16_PEAK_TFLOPS = 2500.0
@@ -184,10 +185,22 @@ def pass_launch(model, audio_chunks, setup, stream_base: int):
     init, always, first, eot = setup
     handles = []
     for sid, a in enumerate(audio_chunks):
-        with use_stream(stream_base + sid):
+        with use_stream(stream_base + sid) as s_enc:
             mel = A.log_mel_padded(a, model.dims.n_mels, model.dtype)
             feats = model.encode_padded(mel, a.shape[0])
-            handles.append(greedy_launch(model, feats, init, always, first, eot, max_new_tokens=NEW_TOKENS))
+            if DECODE_SPLIT <= 1:
+                handles.append(greedy_launch(model, feats, init, always, first, eot, max_new_tokens=NEW_TOKENS))
+                continue
+            done = torch.cuda.Event()
+            done.record(s_enc)
+        # EXPERIMENT (--decode-split): the decode loop of the batch as DECODE_SPLIT independent row groups on their own streams,
+        # so one group's latency-bound small kernels run beside the other's chip-filling cross-attention
+        n = a.shape[0]
+        per = (n + DECODE_SPLIT - 1) // DECODE_SPLIT
+        for g in range(DECODE_SPLIT):
+            with use_stream(1000 + (stream_base + sid) * DECODE_SPLIT + g) as s_dec:
+                s_dec.wait_event(done)
+                handles.append(greedy_launch(model, feats[g * per:(g + 1) * per], init, always, first, eot, max_new_tokens=NEW_TOKENS))
     return handles
 
 
@@ -599,6 +612,8 @@ def main():
     ap.add_argument("--pipeline", type=int, default=N_PIPELINE, help="consecutive passes kept in flight on separate HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-finetune", action="store_true", help="skip the short fine-tune step measurement appended to the default line")
+    ap.add_argument("--decode-split", type=int, default=1,
+                    help="EXPERIMENT: decode the batch as this many independent row groups on separate HIP streams")
     ap.add_argument("--decode-group", type=int, default=1,
                     help="EXPERIMENT: decode this many consecutive 64-clip batches together (encoder still per batch)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"],
@@ -616,6 +631,8 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    global DECODE_SPLIT
+    DECODE_SPLIT = args.decode_split
     torch.set_num_threads(host_cores())
     if args.mode == "train":
         return run_train(args)
@@ -704,8 +721,9 @@ def main():
         single = one_pass(model, audio_chunks, setup)
         out["ms_per_pass_single_in_flight"] = round((time.perf_counter() - t1) * 1e3, 2)
         assert args.decode_group > 1 or (single == tokens).all(), "the pipelined and the single pass disagree on the ids"
-        out["roofline"] = roofline_cross_attn(model, audio_chunks[0].shape[0])
-        if args.streams == 1:
+        if args.decode_split == 1:
+            out["roofline"] = roofline_cross_attn(model, audio_chunks[0].shape[0])
+        if args.streams == 1 and args.decode_split == 1:
             out["decode_step"] = decode_step_roofline(model, audio_chunks[0].shape[0])
             if args.dtype == "bf16" and args.batch <= 128:
                 out["roofline_mfma"] = roofline_mfma(model, audio_chunks[0])
