@@ -60,3 +60,24 @@ def test_bench_train_mode_single_and_two_ranks():
     assert {"encoder_ms", "loss_and_grads_ms", "update_ms"} <= set(one["stages"])
     two = _run(["--gpus", "2"] + args, share_gpu=True)
     assert two["n_gpus"] == 2 and two["allreduce_exposed_ms_per_step"] >= 0.0 and two["grad_bytes"] == one["grad_bytes"]
+
+
+def test_bench_under_torch_distributed_run_two_ranks():
+    """The driver's multi-GPU form: `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (here N = 2 on
+    one GPU, gloo for the timing collectives).  WORLD_SIZE must equal --gpus; rank 0 prints the one JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["WIPA_BENCH_SHARE_GPU"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--model", "tiny",
+           "--batch", "8", "--pipeline", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.lstrip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    # a mismatch between the launcher's world size and --gpus is refused, not silently run
+    base = cmd[: cmd.index(os.path.join(ROOT, "bench.py")) + 1]
+    bad = subprocess.run(base + ["--gpus", "4", "--steps", "1", "--warmup", "1", "--model", "tiny", "--batch", "8", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert bad.returncode != 0 and "WORLD_SIZE=2 but --gpus 4" in (bad.stderr + bad.stdout)
