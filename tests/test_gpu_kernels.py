@@ -361,6 +361,8 @@ def test_decode_self_block(dtype, B, H, pos):
     wo = (torch.randn(d, d, generator=g) * 0.06).to(dtype)
     kc = (torch.randn(B, nctx, d, generator=g) * 0.5).to(dtype)
     vc = torch.randn(B, nctx, d, generator=g).to(dtype)
+    kc[:, pos:] = float("nan")  # slots from `pos` on are unwritten memory in real use: nothing of them may reach the result
+    vc[:, pos:] = float("nan")
     scale = 64 ** -0.25
     with on_stream() as s:
         dev = [t.cuda() for t in (x, ln_w, ln_b, wqkv, bqkv, wo, kc, vc)]
@@ -382,7 +384,8 @@ def test_decode_self_block(dtype, B, H, pos):
     assert _rel(kcd[:, pos], k) < tol and _rel(vcd[:, pos], v) < tol
     keep = torch.ones(nctx, dtype=torch.bool)
     keep[pos] = False
-    assert torch.equal(kcd.cpu()[:, keep], kc[:, keep]) and torch.equal(vcd.cpu()[:, keep], vc[:, keep])
+    assert torch.equal(kcd.cpu()[:, :pos], kc[:, :pos]) and torch.equal(vcd.cpu()[:, :pos], vc[:, :pos])
+    assert torch.isnan(kcd[:, pos + 1:].float()).all() and torch.isnan(vcd[:, pos + 1:].float()).all()  # untouched
     K = torch.cat([kc[:, :pos].double(), k[:, None]], 1).view(B, pos + 1, H, 64)
     V = torch.cat([vc[:, :pos].double(), v[:, None]], 1).view(B, pos + 1, H, 64)
     sc = torch.einsum("bhd,bthd->bht", q.view(B, H, 64), K)

@@ -249,6 +249,33 @@ def test_fused_decode_step_equals_unfused_step(micro, small2, monkeypatch, dtype
                 assert (a[2][rows] - b[2][rows]).abs().max() < 0.25
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("mode", ["0", "1", "2"])
+def test_decode_never_reads_unwritten_state(micro, monkeypatch, dtype, mode):
+    """The decode blob comes from torch.empty: whatever the caches and scratch held before must not reach the result.  The
+    blob is filled with 0xFF bytes (NaN in f32 and bf16, -1 as a token id) before the run, with and without the batched
+    prompt pass, for every step variant; the ids and log-probabilities must equal those of a run on a zeroed blob."""
+    from whisper_ipa_amd.decoding import _state_for, greedy_decode_tokens
+    from whisper_ipa_amd.runtime import on_stream
+
+    W, mels, xa = micro
+    sp = R.SpecialTokens.multilingual()
+    always, first = R.suppress_lists(sp)
+    init = list(sp.sot_sequence_including_notimestamps(0))
+    monkeypatch.setenv("WIPA_DECODE_FUSED", mode)
+    m = _model(MICRO, W, dtype)
+    feats = xa.cuda().to(dtype)
+    out = {}
+    for prompt in (init, init[:1]):  # 4-token prompt (prefill pass) and a bare [sot] (the first step runs at position 0)
+        for fill in (0x00, 0xFF):
+            with on_stream():
+                _state_for(m, feats.shape[0]).blob.fill_(fill)
+            r = greedy_decode_tokens(m, feats, prompt, always, first, sp.eot, max_new_tokens=10, stop_on_eot=False)
+            out[(len(prompt), fill)] = (r.tokens, r.sum_logprobs.copy())
+        a, b = out[(len(prompt), 0x00)], out[(len(prompt), 0xFF)]
+        assert np.isfinite(b[1]).all() and (a[0] == b[0]).all() and np.array_equal(a[1], b[1]), (mode, len(prompt), a[0].tolist(), b[0].tolist())
+
+
 def test_detect_language_matches_oracle(micro):
     from whisper_ipa_amd.decoding import detect_language
     from whisper_ipa_amd.tokenizer import get_tokenizer

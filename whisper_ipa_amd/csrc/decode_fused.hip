@@ -255,8 +255,11 @@ __global__ __launch_bounds__(256) void decode_self_block_kernel(SelfBlockParams 
                 const int t = t0 + u * G + g;
                 const float pr = (s[u] <= NEG_TEST) ? 0.f : __expf(s[u] - m_new);
                 l += pr;
+                // keys beyond Tk were loaded from a clamped (at pos = 0: not yet written) slot: their values must not reach the
+                // accumulator even multiplied by zero (0 * NaN)
+                const bool live = t < Tk;
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) acc[e] = fmaf(pr, t == pos ? vc[e] : va[u].get(e), acc[e]);
+                for (int e = 0; e < EPL; ++e) acc[e] = fmaf(pr, live ? (t == pos ? vc[e] : va[u].get(e)) : 0.f, acc[e]);
             }
             m = m_new;
         }
