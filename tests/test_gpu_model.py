@@ -276,6 +276,23 @@ def test_decode_never_reads_unwritten_state(micro, monkeypatch, dtype, mode):
         assert np.isfinite(b[1]).all() and (a[0] == b[0]).all() and np.array_equal(a[1], b[1]), (mode, len(prompt), a[0].tolist(), b[0].tolist())
 
 
+def test_no_graph_replay_while_hardware_counters_are_attached(micro, monkeypatch):
+    """rocprofv3 --pmc sets ROCPROF_COUNTER_COLLECTION; the runtime then enqueues the decode steps eagerly instead of capturing
+    / replaying hipGraphs (runtime.hip counters_attached).  Same ids either way."""
+    from whisper_ipa_amd.decoding import greedy_decode_tokens
+
+    W, mels, xa = micro
+    sp = R.SpecialTokens.multilingual()
+    always, first = R.suppress_lists(sp)
+    init = list(sp.sot_sequence_including_notimestamps(0))
+    m = _model(MICRO, W, torch.float32)
+    a = greedy_decode_tokens(m, xa.cuda(), init, always, first, sp.eot, max_new_tokens=12, stop_on_eot=False)
+    monkeypatch.setenv("ROCPROF_COUNTER_COLLECTION", "1")
+    m2 = _model(MICRO, W, torch.float32)  # fresh state: nothing captured before
+    b = greedy_decode_tokens(m2, xa.cuda(), init, always, first, sp.eot, max_new_tokens=12, stop_on_eot=False)
+    assert (a.tokens == b.tokens).all() and np.array_equal(a.sum_logprobs, b.sum_logprobs)
+
+
 def test_detect_language_matches_oracle(micro):
     from whisper_ipa_amd.decoding import detect_language
     from whisper_ipa_amd.tokenizer import get_tokenizer
