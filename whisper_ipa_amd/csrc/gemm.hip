@@ -1396,9 +1396,15 @@ extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
     }();
     // the 256-tile kernels address a tile with 32-bit buffer offsets: 256 rows x row pitch + K bytes must stay below 2^31
     const bool pitch_ok = p.lda_b < (1 << 22) && p.ldw_b < (1 << 22) && d->K * esz < (1 << 22);
+    // A grid of 256 x 256 tiles must at least come close to filling the 256 CUs: the decoder GEMMs of a fine-tune step
+    // (M = 32 clips x 64 tokens = 2048 rows, N = 768 or 3072) are 24 / 96 such tiles and ran at 7 / 51 TF/s in float32
+    // (r02 trace of `bench.py --mode train`: 55 ms of a 237 ms step); they go to the 128 x 128 kernel (96 / 384 workgroups).
+    static const int min_big_tiles = [] { const char* e = getenv("WIPA_GEMM_MIN_BIG_TILES"); return e ? atoi(e) : 160; }();
+    const int64_t t256_grid = (int64_t)((d->M + LBM - 1) / LBM) * ((d->N + LBN - 1) / LBN);
     const bool big = pitch_ok && p.k_slices == 1 && (  // split-K beyond the skinny rows lives in the 128x128 kernel
                      force_tile >= 256 ||  // WIPA_GEMM_TILE=256: the 256x256 kernel for every shape
-                                  (force_tile != 128 && d->M >= 512 && d->N >= 256 && (int64_t)d->M * d->N >= (1 << 20)));
+                                  (force_tile != 128 && d->M >= 512 && d->N >= 256 && (int64_t)d->M * d->N >= (1 << 20) &&
+                                   t256_grid >= min_big_tiles));
     // 384 x 256 tile (fewer staged bytes per FLOP, 2.93 instead of 4.39 rounds at N = 768): measured faster on every encoder
     // shape without an activation (its instantiations are compiled without the GELU path, which is what keeps 192
     // accumulators + the epilogue under 256 registers), unless its grid quantises clearly worse than the 256-tile grid.
