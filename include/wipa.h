@@ -390,9 +390,11 @@ int wipa_colsum(const float* x, int64_t ld, int rows, int cols, float* out, int 
                 int64_t workspace_floats, wipa_stream_t s);
 /* out[i] (+)= sum over k of slabs[k * slab_stride + i], k ascending: the reduction of a split-K wipa_gemm (k_slices > 1). */
 int wipa_sum_slabs(const float* slabs, int n_slabs, int64_t slab_stride, float* out, int64_t n, int accumulate, wipa_stream_t s);
-/* LayerNorm backward: dx (+)= ..., dw, db; stats f32 [2*rows] scratch (mean, rstd). x, dy, dx contiguous [rows, D]. */
+/* LayerNorm backward: dx (+)= ..., dw, db.  stats: f32 scratch of stats_floats elements, at least 2*rows (mean, rstd per row);
+ * with room for 2*rows + 64*D the dw / db column sums are cut into up to 32 row chunks reduced by separate workgroups and
+ * added in a fixed order.  x, dy, dx contiguous [rows, D]. */
 int wipa_layernorm_bwd(const float* x, const float* dy, const float* w, float* dx, int accumulate_dx, float* dw, float* db,
-                       float* stats, int rows, int D, float eps, wipa_stream_t s);
+                       float* stats, int64_t stats_floats, int rows, int D, float eps, wipa_stream_t s);
 /* exact-erf GELU forward / backward on n (multiple of 4) contiguous f32 values. */
 int wipa_gelu(const float* z, float* u, int64_t n, wipa_stream_t s);
 int wipa_gelu_bwd(const float* z, const float* du, float* dz, int64_t n, wipa_stream_t s);

@@ -139,7 +139,7 @@ SIGNATURES = {
     "wipa_transpose": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "wipa_sum_slabs": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int64, c_int, c_void_p]),
     "wipa_colsum": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
-    "wipa_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+    "wipa_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                                    c_float, c_void_p]),
     "wipa_gelu": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "wipa_gelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),

@@ -155,14 +155,19 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const float* __restrict_
 }
 
 // dw[c] = sum_r dy*xhat, db[c] = sum_r dy  (one workgroup per 64 columns, fixed order)
+// Column sums over the rows, in two deterministic stages: workgroup (column tile, row chunk) reduces its rows [r0, r1) and
+// either writes dw / db directly (one chunk) or a partial pair into `part` [n_chunks][2][D]; ln_bwd_params_finish_kernel adds
+// the chunks in order.  (One workgroup per column tile walking ALL rows took 147 us for 2048 x 768: 12 workgroups on a
+// 256-CU chip, 5.4 ms of a fine-tune step.)
 __global__ __launch_bounds__(256) void ln_bwd_params_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                            const float* __restrict__ stats, int rows, int D,
-                                                            float* __restrict__ dw, float* __restrict__ db) {
+                                                            const float* __restrict__ stats, int rows, int D, int rows_per_chunk,
+                                                            float* __restrict__ dw, float* __restrict__ db, float* __restrict__ part) {
     __shared__ float pw[4][64], pb[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
     float sw = 0.f, sb = 0.f;
     if (c < D)
-        for (int r = g; r < rows; r += 4) {
+        for (int r = r0 + g; r < r1; r += 4) {
             const float d = dy[(int64_t)r * D + c];
             sw += d * (x[(int64_t)r * D + c] - stats[2 * r]) * stats[2 * r + 1];
             sb += d;
@@ -171,9 +176,28 @@ __global__ __launch_bounds__(256) void ln_bwd_params_kernel(const float* __restr
     pb[g][threadIdx.x & 63] = sb;
     __syncthreads();
     if (g == 0 && c < D) {
-        dw[c] = (pw[0][threadIdx.x] + pw[1][threadIdx.x]) + (pw[2][threadIdx.x] + pw[3][threadIdx.x]);
-        db[c] = (pb[0][threadIdx.x] + pb[1][threadIdx.x]) + (pb[2][threadIdx.x] + pb[3][threadIdx.x]);
+        const float tw = (pw[0][threadIdx.x] + pw[1][threadIdx.x]) + (pw[2][threadIdx.x] + pw[3][threadIdx.x]);
+        const float tb = (pb[0][threadIdx.x] + pb[1][threadIdx.x]) + (pb[2][threadIdx.x] + pb[3][threadIdx.x]);
+        if (part) {
+            part[((int64_t)blockIdx.y * 2) * D + c] = tw;
+            part[((int64_t)blockIdx.y * 2 + 1) * D + c] = tb;
+        } else {
+            dw[c] = tw;
+            db[c] = tb;
+        }
     }
+}
+__global__ __launch_bounds__(256) void ln_bwd_params_finish_kernel(const float* __restrict__ part, int n_chunks, int D,
+                                                                   float* __restrict__ dw, float* __restrict__ db) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= D) return;
+    float tw = 0.f, tb = 0.f;
+    for (int k = 0; k < n_chunks; ++k) {  // fixed order
+        tw += part[((int64_t)k * 2) * D + c];
+        tb += part[((int64_t)k * 2 + 1) * D + c];
+    }
+    dw[c] = tw;
+    db[c] = tb;
 }
 
 // ------------------------------------------------------------------ GELU forward / backward (exact erf form)
@@ -272,16 +296,23 @@ __global__ __launch_bounds__(256) void sumsq_chunks_kernel(const float* __restri
     __syncthreads();
     if (threadIdx.x == 0) partial[ch] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
-// one thread per segment: fixed-order sum of its chunks -> clip coefficient
-__global__ void clip_coef_kernel(const float* __restrict__ partial, const int32_t* __restrict__ seg_first_chunk, int n_seg,
-                                 float max_norm, float* __restrict__ coef, float* __restrict__ norms) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_seg) return;
+// one workgroup per segment (tensor): thread i adds chunks i, i + 256, ... in order, then a fixed tree over the 256 partial
+// sums -> clip coefficient.  Deterministic; the token embedding alone has 9 724 chunks, which one thread per segment walked
+// in 0.7 ms.
+__global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict__ partial, const int32_t* __restrict__ seg_first_chunk,
+                                                        int n_seg, float max_norm, float* __restrict__ coef, float* __restrict__ norms) {
+    __shared__ float s_red[4];
+    const int s = blockIdx.x;
     float t = 0.f;
-    for (int c = seg_first_chunk[s]; c < seg_first_chunk[s + 1]; ++c) t += partial[c];
-    const float nrm = sqrtf(t);
-    norms[s] = nrm;
-    coef[s] = fminf(max_norm / (nrm + 1e-6f), 1.0f);  // train_whisper_ipa.py:295-297
+    for (int c = seg_first_chunk[s] + threadIdx.x; c < seg_first_chunk[s + 1]; c += 256) t += partial[c];
+    t = wave_reduce_sum(t);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float nrm = sqrtf((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
+        norms[s] = nrm;
+        coef[s] = fminf(max_norm / (nrm + 1e-6f), 1.0f);  // train_whisper_ipa.py:295-297
+    }
 }
 __global__ __launch_bounds__(256) void adamw_chunks_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                            float* __restrict__ v, const int64_t* __restrict__ chunk_off,
@@ -357,13 +388,23 @@ extern "C" int wipa_sum_slabs(const float* slabs, int n_slabs, int64_t slab_stri
     return WIPA_OK;
 }
 
+constexpr int LNB_CHUNKS = 32;
 extern "C" int wipa_layernorm_bwd(const float* x, const float* dy, const float* w, float* dx, int accumulate_dx, float* dw,
-                                  float* db, float* stats, int rows, int D, float eps, wipa_stream_t stream) {
+                                  float* db, float* stats, int64_t stats_floats, int rows, int D, float eps, wipa_stream_t stream) {
     WIPA_REQUIRE(x && dy && w && dx && dw && db && stats, "wipa_layernorm_bwd: null pointer");
+    WIPA_REQUIRE(stats_floats >= (int64_t)2 * rows, "wipa_layernorm_bwd: stats needs at least 2*rows floats");
     WIPA_REQUIRE(D % 4 == 0 && D <= LNB_MAXV * 256 && rows > 0, "wipa_layernorm_bwd: bad shape");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, dy, w, dx, stats, rows, D, eps, accumulate_dx);
-    hipLaunchKernelGGL(ln_bwd_params_kernel, dim3((D + 63) / 64), dim3(256), 0, s, x, dy, stats, rows, D, dw, db);
+    // dw / db: rows cut into up to LNB_CHUNKS chunks when the scratch has room for the partials (stats_floats >= 2*rows + 2*chunks*D)
+    int chunks = (rows + 63) / 64;
+    if (chunks > LNB_CHUNKS) chunks = LNB_CHUNKS;
+    if (stats_floats < (int64_t)2 * rows + (int64_t)2 * chunks * D) chunks = 1;
+    const int per = (rows + chunks - 1) / chunks;
+    float* part = chunks > 1 ? stats + (int64_t)2 * rows : nullptr;
+    hipLaunchKernelGGL(ln_bwd_params_kernel, dim3((D + 63) / 64, chunks), dim3(256), 0, s, x, dy, stats, rows, D, per, dw, db, part);
+    if (chunks > 1)
+        hipLaunchKernelGGL(ln_bwd_params_finish_kernel, dim3((D + 255) / 256), dim3(256), 0, s, part, chunks, D, dw, db);
     WIPA_LAUNCH_CHECK();
     return WIPA_OK;
 }
@@ -410,7 +451,7 @@ extern "C" int wipa_clip_adamw(float* params, float* grads, float* m, float* v, 
     WIPA_REQUIRE(n_chunks > 0 && n_seg > 0, "wipa_clip_adamw: empty");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(sumsq_chunks_kernel, dim3(n_chunks), dim3(256), 0, s, grads, chunk_off, chunk_len, partial);
-    hipLaunchKernelGGL(clip_coef_kernel, dim3((n_seg + 63) / 64), dim3(64), 0, s, partial, seg_first_chunk, n_seg, (float)max_norm,
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(n_seg), dim3(256), 0, s, partial, seg_first_chunk, n_seg, (float)max_norm,
                        coef, norms);
     // the scalar coefficients are formed in double like the Python reference forms them, then rounded once
     hipLaunchKernelGGL(adamw_chunks_kernel, dim3(n_chunks), dim3(256), 0, s, params, grads, m, v, chunk_off, chunk_len, chunk_seg,

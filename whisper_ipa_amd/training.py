@@ -163,9 +163,9 @@ class DecoderTrainer:
 
     def _ln_bwd(self, x, dy, w, dx, accumulate, dw, db, M, D):
         with on_stream() as s:
-            stats = torch.empty(2 * M, dtype=torch.float32, device=x.device)
+            stats = torch.empty(2 * M + 64 * D, dtype=torch.float32, device=x.device)  # (mean, rstd) + chunked dw / db partials
             _lib.check(self.L.wipa_layernorm_bwd(ptr(x), ptr(dy), ptr(w), ptr(dx), int(accumulate), ptr(dw), ptr(db), ptr(stats),
-                                                 M, D, 1e-5, sptr(s)), "wipa_layernorm_bwd")
+                                                 stats.numel(), M, D, 1e-5, sptr(s)), "wipa_layernorm_bwd")
 
     def _attn(self, q, k, v, B, H, Tq, Tk, causal, k_rows_per_batch):
         """q [B*Tq, d], k/v [B*Tk, d] row-major -> (out [B*Tq, d], lse [B,H,Tq], desc)"""
