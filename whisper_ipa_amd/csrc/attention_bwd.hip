@@ -7,6 +7,9 @@
 // with P_ij = exp(q_i.k_j - lse_i), dS_ij = P_ij (dO_i.v_j - D_i).  q and k are the PRE-SCALED
 // values the forward used (64^-0.25 each); dq/dk are multiplied by that scale on the way out so
 // they are gradients of the unscaled projections.
+#include <cstdlib>
+#include <cstring>
+
 #include "wipa_common.h"
 
 namespace {
@@ -182,6 +185,120 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdParams p) {
     }
 }
 
+// ---- kernel 2 on the f32 MFMA (16x16x4, exact f32 products): 64 keys per workgroup, wave w owns keys 16w .. 16w+15 and walks
+// the queries in tiles of 64.  The trick that keeps P out of LDS: the scores are computed with the QUERIES on the MFMA's row
+// side, S[q][key] = sum_d Q[q][d] K[key][d], so a lane ends up with 4 consecutive q of ONE key -- exactly the fragment the
+// next contractions over q need (dV[key][d] += sum_q P[q][key] dO[q][d], dK[key][d] += sum_q dS[q][key] Q[q][d]); the
+// probabilities go from the accumulators straight back into the matrix pipe.  K / V rows of the wave live in registers,
+// the Q / dO tile in LDS in both orientations ([q][d] for the scores, [d][q] for the two accumulations).
+constexpr int BQ = 68;  // padded row (floats): 16-byte aligned, conflict-light
+__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(AttnBwdParams p) {
+    __shared__ __attribute__((aligned(16))) float Qs[64 * BQ];
+    __shared__ __attribute__((aligned(16))) float Gs[64 * BQ];
+    __shared__ __attribute__((aligned(16))) float QsT[64 * BQ];
+    __shared__ __attribute__((aligned(16))) float GsT[64 * BQ];
+    __shared__ float s_lse[64], s_d[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int k0 = blockIdx.x * 64;
+    const int key = k0 + 16 * wave + frow;  // the key whose K / V row this lane feeds to the matrix pipe
+    const int kc = min(key, p.Tk - 1);
+    f32x4 kx[4], vx[4];
+    {
+        const float* kp = p.k + b * p.k_bs + (int64_t)kc * p.k_rs + h * p.k_hs + 4 * fq;
+        const float* vp = p.v + b * p.v_bs + (int64_t)kc * p.v_rs + h * p.v_hs + 4 * fq;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kx[ks] = *reinterpret_cast<const f32x4*>(kp + 16 * ks);
+            vx[ks] = *reinterpret_cast<const f32x4*>(vp + 16 * ks);
+        }
+    }
+    f32x4 dV[4], dK[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dV[j] = dK[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int off = p.Tk - p.Tq;  // causal: key j is seen by queries i >= j - off
+    const int q_begin = p.causal ? max(0, k0 - off) : 0;
+    const int srow = tid >> 2, sseg = (tid & 3) * 16;
+    const float* qb = p.q + b * p.q_bs + h * p.q_hs;
+    const float* gb = p.d_o + b * p.o_bs + h * p.o_hs;
+    for (int q0 = (q_begin / 64) * 64; q0 < p.Tq; q0 += 64) {
+        __syncthreads();
+        {
+            const int qi = q0 + srow;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f}, g = {0.f, 0.f, 0.f, 0.f};
+                if (qi < p.Tq) {
+                    a = *reinterpret_cast<const f32x4*>(qb + (int64_t)qi * p.q_rs + sseg + 4 * c);
+                    g = *reinterpret_cast<const f32x4*>(gb + (int64_t)qi * p.o_rs + sseg + 4 * c);
+                }
+                *reinterpret_cast<f32x4*>(&Qs[srow * BQ + sseg + 4 * c]) = a;
+                *reinterpret_cast<f32x4*>(&Gs[srow * BQ + sseg + 4 * c]) = g;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    QsT[(sseg + 4 * c + e) * BQ + srow] = a[e];
+                    GsT[(sseg + 4 * c + e) * BQ + srow] = g[e];
+                }
+            }
+            if (tid < 64) {
+                const int qq = q0 + tid;
+                s_lse[tid] = qq < p.Tq ? p.lse[((int64_t)b * p.H + h) * p.Tq + qq] : 0.f;
+                s_d[tid] = qq < p.Tq ? p.dvec[((int64_t)b * p.H + h) * p.Tq + qq] : 0.f;
+            }
+        }
+        __syncthreads();
+        // S[q][key] and dP[q][key] for the wave's 16 keys and the tile's 64 queries: acc[i][e] <-> q = 16i + 4fq + e
+        f32x4 S[4], dP[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            S[i] = dP[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const f32x4 qf = *reinterpret_cast<const f32x4*>(&Qs[(16 * i + frow) * BQ + 16 * ks + 4 * fq]);
+                const f32x4 gf = *reinterpret_cast<const f32x4*>(&Gs[(16 * i + frow) * BQ + 16 * ks + 4 * fq]);
+                Mma<float>::run(qf, kx[ks], S[i]);
+                Mma<float>::run(gf, vx[ks], dP[i]);
+            }
+        }
+        // P = exp(S - lse), dS = P (dP - D); masked where the query or the key does not exist / is not visible
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ql = 16 * i + 4 * fq + e, qi = q0 + ql;
+                const bool vis = qi < p.Tq && key < p.Tk && (!p.causal || key <= qi + off);
+                const float pr = vis ? __expf(S[i][e] - s_lse[ql]) : 0.f;
+                S[i][e] = pr;
+                dP[i][e] = pr * (dP[i][e] - s_d[ql]);
+            }
+        // dV[key][d] += sum_q P[q][key] dO[q][d];  dK[key][d] += sum_q dS[q][key] Q[q][d]   (k-step i = queries 16i .. 16i+15)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 gt = *reinterpret_cast<const f32x4*>(&GsT[(16 * j + frow) * BQ + 16 * i + 4 * fq]);
+                const f32x4 qt = *reinterpret_cast<const f32x4*>(&QsT[(16 * j + frow) * BQ + 16 * i + 4 * fq]);
+                Mma<float>::run(S[i], gt, dV[j]);
+                Mma<float>::run(dP[i], qt, dK[j]);
+            }
+    }
+    // acc[j][r] <-> key = k0 + 16 wave + 4 fq + r, d = 16 j + frow
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int kj = k0 + 16 * wave + 4 * fq + r;
+        if (kj < p.Tk) {
+            float* dkp = p.dk + b * p.k_bs + (int64_t)kj * p.k_rs + h * p.k_hs + frow;
+            float* dvp = p.dv + b * p.v_bs + (int64_t)kj * p.v_rs + h * p.v_hs + frow;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dkp[16 * j] = dK[j][r] * p.qk_scale;
+                dvp[16 * j] = dV[j][r];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int wipa_attention_bwd(const wipa_attn_desc* d, const float* out, const float* d_out, const float* lse, float* dq,
@@ -203,7 +320,12 @@ extern "C" int wipa_attention_bwd(const wipa_attn_desc* d, const float* out, con
     p.qk_scale = qk_scale;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((d->Tq + 15) / 16, d->H, d->B), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((d->Tk + 15) / 16, d->H, d->B), dim3(256), 0, s, p);
+    // key-major half: the f32-MFMA kernel (64 keys per workgroup); WIPA_ATTN_BWD=valu keeps the shuffle-reduction kernel for A/B runs
+    static const bool valu = [] { const char* e = getenv("WIPA_ATTN_BWD"); return e && !strcmp(e, "valu"); }();
+    if (valu)
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((d->Tk + 15) / 16, d->H, d->B), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, dim3((d->Tk + 63) / 64, d->H, d->B), dim3(256), 0, s, p);
     WIPA_LAUNCH_CHECK();
     return WIPA_OK;
 }
