@@ -299,6 +299,107 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(AttnBwdParams p)
     }
 }
 
+// ---- kernel 1 on the f32 MFMA: 64 queries per workgroup, wave w owns queries 16w .. 16w+15 (their q / dO rows live in
+// registers as MFMA fragments) and walks the keys in tiles of 64 staged in LDS as [key][d] (scores, dP) and [d][key] (dQ).
+// Mirror image of the key-major kernel: here the KEYS sit on the row side of the score product, S[key][q], so a lane holds
+// 4 consecutive keys of one query -- the fragment of dQ[q][d] += sum_key dS[q][key] K[key][d].
+__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(AttnBwdParams p) {
+    __shared__ __attribute__((aligned(16))) float Ks[64 * BQ];
+    __shared__ __attribute__((aligned(16))) float Vs[64 * BQ];
+    __shared__ __attribute__((aligned(16))) float KsT[64 * BQ];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 64;
+    const int qi = q0 + 16 * wave + frow;
+    const int qc = min(qi, p.Tq - 1);
+    f32x4 qx[4], gx[4];
+    float dsum = 0.f;
+    {
+        const float* qp = p.q + b * p.q_bs + (int64_t)qc * p.q_rs + h * p.q_hs + 4 * fq;
+        const float* gp = p.d_o + b * p.o_bs + (int64_t)qc * p.o_rs + h * p.o_hs + 4 * fq;
+        const float* op = p.o + b * p.o_bs + (int64_t)qc * p.o_rs + h * p.o_hs + 4 * fq;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qx[ks] = *reinterpret_cast<const f32x4*>(qp + 16 * ks);
+            gx[ks] = *reinterpret_cast<const f32x4*>(gp + 16 * ks);
+            const f32x4 oo = *reinterpret_cast<const f32x4*>(op + 16 * ks);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dsum = fmaf(gx[ks][e], oo[e], dsum);
+        }
+        dsum += __shfl_xor(dsum, 16, 64);  // the four fq lanes of a query hold 16 of its 64 dims each
+        dsum += __shfl_xor(dsum, 32, 64);
+    }
+    const float lse = p.lse[((int64_t)b * p.H + h) * p.Tq + qc];
+    if (fq == 0 && qi < p.Tq) p.dvec[((int64_t)b * p.H + h) * p.Tq + qi] = dsum;
+    f32x4 dQ[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dQ[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int off = p.Tk - p.Tq;
+    const int q_last = min(q0 + 63, p.Tq - 1);
+    const int k_end = p.causal ? min(p.Tk, q_last + off + 1) : p.Tk;
+    const int srow = tid >> 2, sseg = (tid & 3) * 16;
+    const float* kb = p.k + b * p.k_bs + h * p.k_hs;
+    const float* vb = p.v + b * p.v_bs + h * p.v_hs;
+    for (int k0 = 0; k0 < k_end; k0 += 64) {
+        __syncthreads();
+        {
+            const int key = k0 + srow;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f}, bb = {0.f, 0.f, 0.f, 0.f};
+                if (key < p.Tk) {
+                    a = *reinterpret_cast<const f32x4*>(kb + (int64_t)key * p.k_rs + sseg + 4 * c);
+                    bb = *reinterpret_cast<const f32x4*>(vb + (int64_t)key * p.v_rs + sseg + 4 * c);
+                }
+                *reinterpret_cast<f32x4*>(&Ks[srow * BQ + sseg + 4 * c]) = a;
+                *reinterpret_cast<f32x4*>(&Vs[srow * BQ + sseg + 4 * c]) = bb;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) KsT[(sseg + 4 * c + e) * BQ + srow] = a[e];
+            }
+        }
+        __syncthreads();
+        f32x4 S[4], dP[4];  // acc[i][e] <-> key = k0 + 16 i + 4 fq + e, query = the lane's
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            S[i] = dP[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const f32x4 kf = *reinterpret_cast<const f32x4*>(&Ks[(16 * i + frow) * BQ + 16 * ks + 4 * fq]);
+                const f32x4 vf = *reinterpret_cast<const f32x4*>(&Vs[(16 * i + frow) * BQ + 16 * ks + 4 * fq]);
+                Mma<float>::run(kf, qx[ks], S[i]);
+                Mma<float>::run(vf, gx[ks], dP[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = k0 + 16 * i + 4 * fq + e;
+                const bool vis = qi < p.Tq && key < p.Tk && (!p.causal || key <= qi + off);
+                dP[i][e] = vis ? __expf(S[i][e] - lse) * (dP[i][e] - dsum) : 0.f;
+            }
+        // dQ[q][d] += sum_key dS[q][key] K[key][d]   (k-step i = keys 16i .. 16i+15 of the tile)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 kt = *reinterpret_cast<const f32x4*>(&KsT[(16 * j + frow) * BQ + 16 * i + 4 * fq]);
+                Mma<float>::run(dP[i], kt, dQ[j]);
+            }
+    }
+    // acc[j][r] <-> query = q0 + 16 wave + 4 fq + r, d = 16 j + frow
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qq = q0 + 16 * wave + 4 * fq + r;
+        if (qq < p.Tq) {
+            float* dqp = p.dq + b * p.q_bs + (int64_t)qq * p.q_rs + h * p.q_hs + frow;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dqp[16 * j] = dQ[j][r] * p.qk_scale;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int wipa_attention_bwd(const wipa_attn_desc* d, const float* out, const float* d_out, const float* lse, float* dq,
@@ -319,13 +420,15 @@ extern "C" int wipa_attention_bwd(const wipa_attn_desc* d, const float* out, con
     p.H = d->H; p.Tq = d->Tq; p.Tk = d->Tk; p.causal = d->causal;
     p.qk_scale = qk_scale;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((d->Tq + 15) / 16, d->H, d->B), dim3(256), 0, s, p);
-    // key-major half: the f32-MFMA kernel (64 keys per workgroup); WIPA_ATTN_BWD=valu keeps the shuffle-reduction kernel for A/B runs
+    // both halves on the f32 MFMA (64 queries / 64 keys per workgroup); WIPA_ATTN_BWD=valu keeps the VALU kernels for A/B runs
     static const bool valu = [] { const char* e = getenv("WIPA_ATTN_BWD"); return e && !strcmp(e, "valu"); }();
-    if (valu)
+    if (valu) {
+        hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((d->Tq + 15) / 16, d->H, d->B), dim3(256), 0, s, p);
         hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((d->Tk + 15) / 16, d->H, d->B), dim3(256), 0, s, p);
-    else
+    } else {
+        hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, dim3((d->Tq + 63) / 64, d->H, d->B), dim3(256), 0, s, p);
         hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, dim3((d->Tk + 63) / 64, d->H, d->B), dim3(256), 0, s, p);
+    }
     WIPA_LAUNCH_CHECK();
     return WIPA_OK;
 }
