@@ -523,6 +523,10 @@ def test_fp8_weight_model_matches_dequantised_reference(name, dims, n_new):
     ok = np.isfinite(ref.step_logits[:, 0])
     err = np.abs(first_logits.float().cpu().numpy()[ok] - ref.step_logits[:, 0][ok]).max()
     assert err < 0.05 * float(finite.std()) * 4, (name, err, float(finite.std()))
-    # a weight update invalidates the codes
+    # a weight update or a dtype change invalidates the codes
     m8.load_weights({"decoder.ln.bias": Wdq["decoder.ln.bias"] + 1}, strict=False)
     assert m8.weights_format == "bfloat16"
+    m8.quantize_weights()
+    assert m8.weights_format == "fp8_e4m3"
+    m8.set_dtype(torch.float32)
+    assert m8.weights_format == "float32" and m8.packed()["cfg"].dec_w_dtype == 0

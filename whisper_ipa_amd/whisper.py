@@ -159,6 +159,7 @@ class Whisper:
         positional tables stay f32 (train_whisper_ipa.py:505, transcribe_single.py:13)."""
         dt_code(dtype)
         self.dtype = dtype
+        self._fp8 = {}  # fp8 codes belong to the bf16 configuration they were made for (quantize_weights again if wanted)
         with on_stream():
             for k, v in list(self._params.items()):
                 if _is_matrix(k, v):
