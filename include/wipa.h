@@ -390,6 +390,10 @@ int wipa_colsum(const float* x, int64_t ld, int rows, int cols, float* out, int 
                 int64_t workspace_floats, wipa_stream_t s);
 /* out[i] (+)= sum over k of slabs[k * slab_stride + i], k ascending: the reduction of a split-K wipa_gemm (k_slices > 1). */
 int wipa_sum_slabs(const float* slabs, int n_slabs, int64_t slab_stride, float* out, int64_t n, int accumulate, wipa_stream_t s);
+/* out[i] = scale * sum over k of slabs[k * slab_stride + i] (k ascending) + (residual ? residual[i] : 0): finishes a split-K GEMM
+ * whose slices cannot apply a column scale or a residual themselves (bias rides on slice 0).  residual may alias out. */
+int wipa_sum_slabs_ex(const float* slabs, int n_slabs, int64_t slab_stride, float* out, int64_t n, const float* residual,
+                      float scale, wipa_stream_t s);
 /* LayerNorm backward: dx (+)= ..., dw, db.  stats: f32 scratch of stats_floats elements, at least 2*rows (mean, rstd per row);
  * with room for 2*rows + 64*D the dw / db column sums are cut into up to 32 row chunks reduced by separate workgroups and
  * added in a fixed order.  x, dy, dx contiguous [rows, D]. */

@@ -138,6 +138,7 @@ SIGNATURES = {
                                c_void_p]),
     "wipa_transpose": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "wipa_sum_slabs": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int64, c_int, c_void_p]),
+    "wipa_sum_slabs_ex": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int64, c_void_p, c_float, c_void_p]),
     "wipa_colsum": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
     "wipa_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                                    c_float, c_void_p]),

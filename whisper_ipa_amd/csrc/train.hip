@@ -87,6 +87,27 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict_
     }
 }
 
+// out[i] = scale * sum_k slabs[k * stride + i] (+ residual[i]): the epilogue of a split-K GEMM whose slices could not apply it
+__global__ __launch_bounds__(256) void sum_slabs_ex_kernel(const float* __restrict__ slabs, int n_slabs, int64_t stride,
+                                                           float* __restrict__ out, int64_t n, const float* __restrict__ residual,
+                                                           float scale) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        f32x4 t = *reinterpret_cast<const f32x4*>(slabs + i);
+        for (int k = 1; k < n_slabs; ++k) t += *reinterpret_cast<const f32x4*>(slabs + k * stride + i);
+        t *= scale;
+        if (residual) t += *reinterpret_cast<const f32x4*>(residual + i);
+        *reinterpret_cast<f32x4*>(out + i) = t;
+    } else {
+        for (int64_t j = i; j < n; ++j) {
+            float t = slabs[j];
+            for (int k = 1; k < n_slabs; ++k) t += slabs[k * stride + j];
+            t *= scale;
+            out[j] = residual ? residual[j] + t : t;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ LayerNorm backward
 // dx (+)= rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w ; stats[r] = (mean, rstd)
 constexpr int LNB_MAXV = 8;
@@ -384,6 +405,17 @@ extern "C" int wipa_sum_slabs(const float* slabs, int n_slabs, int64_t slab_stri
                  "wipa_sum_slabs: slabs / out must be 16-byte aligned, slab_stride a multiple of 4");
     hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, slabs, n_slabs,
                        slab_stride, out, n, accumulate);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+extern "C" int wipa_sum_slabs_ex(const float* slabs, int n_slabs, int64_t slab_stride, float* out, int64_t n, const float* residual,
+                                 float scale, wipa_stream_t stream) {
+    WIPA_REQUIRE(slabs && out && n_slabs >= 1 && n > 0, "wipa_sum_slabs_ex: bad arguments");
+    WIPA_REQUIRE(slab_stride % 4 == 0 && ((uintptr_t)slabs % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)residual % 16) == 0,
+                 "wipa_sum_slabs_ex: slabs / out / residual must be 16-byte aligned, slab_stride a multiple of 4");
+    hipLaunchKernelGGL(sum_slabs_ex_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, slabs, n_slabs,
+                       slab_stride, out, n, residual, scale);
     WIPA_LAUNCH_CHECK();
     return WIPA_OK;
 }

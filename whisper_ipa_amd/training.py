@@ -90,6 +90,7 @@ class DecoderTrainer:
         self.step_count = 0
         self._colsum_ws = None  # partial sums of the chunked bias-gradient reduction (wipa_colsum)
         self._dw_slabs = None   # split-K partial weight gradients (wipa_gemm k_slices + wipa_sum_slabs)
+        self._mm_slabs = None   # split-K partial outputs of the token-row GEMMs (_mm)
 
     # ---- views into the flat buffers
     def p(self, name: str) -> torch.Tensor:
@@ -110,8 +111,27 @@ class DecoderTrainer:
     def _lin(self, x, M, K, W, N, bias=None, scale=None, residual=None, out=None):
         """out[M,N] = (x[M,K] W[N,K]^T + bias) * scale (+ residual)"""
         out = torch.empty(x.shape[0], N, dtype=torch.float32, device=x.device) if out is None else out
-        self._gemm(x, W, out, M=M, N=N, K=K, lda=x.stride(0), ldw=W.stride(0), ldc=out.stride(0), bias=bias,
-                 residual=residual, col_scale_n=(N if scale is not None else 0), col_scale=(scale or 1.0))
+        return self._mm(x, W, out, M, N, K, x.stride(0), W.stride(0), bias=bias, scale=scale, residual=residual)
+
+    def _mm(self, A, W, out, M, N, K, lda, ldw, bias=None, scale=None, residual=None):
+        """out[M,N] = (A[M,K] W[N,K]^T + bias) * scale (+ residual).  The decoder's GEMMs over the B*T token rows (2048 x 768)
+        are 96 tiles of 128 x 128 -- a third of the chip -- so K is cut into slices computed by separate workgroups (slabs
+        summed in a fixed order, then scale / residual: wipa_sum_slabs_ex) whenever the tile grid alone leaves CUs idle."""
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        slices = min(4, 288 // max(tiles, 1), K // 256) if (M >= 512 and tiles < 192) else 1
+        plain = out.dim() == 2 and out.shape[0] == M and out.shape[1] == N and out.is_contiguous() and (
+            residual is None or (residual.is_contiguous() and residual.shape == out.shape))
+        if slices > 1 and plain:
+            need = slices * M * N
+            if self._mm_slabs is None or self._mm_slabs.numel() < need:
+                self._mm_slabs = torch.empty(need, dtype=torch.float32, device=out.device)
+            self._gemm(A, W, self._mm_slabs, M=M, N=N, K=K, lda=lda, ldw=ldw, ldc=N, bias=bias, k_slices=slices, slab_stride=M * N)
+            with on_stream() as s:
+                _lib.check(self.L.wipa_sum_slabs_ex(ptr(self._mm_slabs), slices, M * N, ptr(out), M * N, ptr(residual),
+                                                    float(scale) if scale is not None else 1.0, sptr(s)), "wipa_sum_slabs_ex")
+        else:
+            self._gemm(A, W, out, M=M, N=N, K=K, lda=lda, ldw=ldw, ldc=out.stride(0), bias=bias, residual=residual,
+                       col_scale_n=(N if scale is not None else 0), col_scale=(scale or 1.0))
         return out
 
     def _transpose(self, a, rows, cols, rows_pad):
@@ -132,8 +152,7 @@ class DecoderTrainer:
             WT = self._transpose(W, N, K, Np)  # [K, Np]
             out_dx = dx if dx is not None else torch.empty(dy.shape[0], K, dtype=torch.float32, device=dy.device)
             # contraction over n: A = dy (row stride ld, first Np columns must be readable and zero beyond N)
-            self._gemm(dy, WT, out_dx, M=M, N=K, K=Np, lda=dy.stride(0), ldw=Np, ldc=out_dx.stride(0),
-                     residual=(out_dx if accumulate_dx else None))
+            self._mm(dy, WT, out_dx, M, K, Np, dy.stride(0), Np, residual=(out_dx if accumulate_dx else None))
         dyT = self._transpose(dy, M, N, Mp)  # [N, Mp]
         if xT is None:
             xT = self._transpose(x, M, K, Mp)
