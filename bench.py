@@ -77,6 +77,9 @@ N_STREAMS = 1       # sub-batches of the 64 clips, one HIP stream each (measured
                     # 2 -> 156 ms, 4 -> 200 ms, 8 -> 266 ms per pass: the per-step cost of the decode
                     # loop is launch/latency bound and does not shrink with the sub-batch)
 DECODE_SPLIT = 1    # see --decode-split
+ENCODER_CUS = None  # see --encoder-cus
+ENC_STREAM_BASE = 2000
+ENC_STREAMS = int(os.environ.get("WIPA_BENCH_ENC_STREAMS", "1"))
 NEW_TOKENS = 64     # decode positions per clip (SURVEY.md section 8d primary setting)
 HBM_PEAK_GBS = 8000.0
 MFMA_BF16_PEAK_TFLOPS = 2500.0
@@ -185,14 +188,22 @@ def pass_launch(model, audio_chunks, setup, stream_base: int):
     init, always, first, eot = setup
     handles = []
     for sid, a in enumerate(audio_chunks):
-        with use_stream(stream_base + sid) as s_enc:
+        enc_sid = stream_base + sid if ENCODER_CUS is None else ENC_STREAM_BASE + (stream_base + sid) % ENC_STREAMS
+        with use_stream(enc_sid) as s_enc:
             mel = A.log_mel_padded(a, model.dims.n_mels, model.dtype)
             feats = model.encode_padded(mel, a.shape[0])
-            if DECODE_SPLIT <= 1:
+            if DECODE_SPLIT <= 1 and ENCODER_CUS is None:
                 handles.append(greedy_launch(model, feats, init, always, first, eot, max_new_tokens=NEW_TOKENS))
                 continue
             done = torch.cuda.Event()
             done.record(s_enc)
+        if DECODE_SPLIT <= 1:
+            # --encoder-cus: log-mel + encoder on a CU-limited stream, the decode loop on the pass's unrestricted stream
+            with use_stream(stream_base + sid) as s_dec:
+                s_dec.wait_event(done)
+                feats.record_stream(s_dec)
+                handles.append(greedy_launch(model, feats, init, always, first, eot, max_new_tokens=NEW_TOKENS))
+            continue
         # EXPERIMENT (--decode-split): the decode loop of the batch as DECODE_SPLIT independent row groups on their own streams,
         # so one group's latency-bound small kernels run beside the other's chip-filling cross-attention
         n = a.shape[0]
@@ -200,6 +211,7 @@ def pass_launch(model, audio_chunks, setup, stream_base: int):
         for g in range(DECODE_SPLIT):
             with use_stream(1000 + (stream_base + sid) * DECODE_SPLIT + g) as s_dec:
                 s_dec.wait_event(done)
+                feats.record_stream(s_dec)
                 handles.append(greedy_launch(model, feats[g * per:(g + 1) * per], init, always, first, eot, max_new_tokens=NEW_TOKENS))
     return handles
 
@@ -655,6 +667,10 @@ def main():
     ap.add_argument("--no-finetune", action="store_true", help="skip the short fine-tune step measurement appended to the default line")
     ap.add_argument("--decode-split", type=int, default=1,
                     help="EXPERIMENT: decode the batch as this many independent row groups on separate HIP streams")
+    ap.add_argument("--encoder-cus", type=int, default=None,
+                    help="log-mel + encoder of every pass on a HIP stream limited to this many CUs (multiple of 8), the decode loop "
+                         "on an unrestricted one: the decode loops of the other passes in flight keep the remaining CUs")
+    ap.add_argument("--decoder-cus", type=int, default=None, help="EXPERIMENT: limit the decode streams to this many CUs")
     ap.add_argument("--decode-group", type=int, default=1,
                     help="EXPERIMENT: decode this many consecutive 64-clip batches together (encoder still per batch)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"],
@@ -672,14 +688,20 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
-    global DECODE_SPLIT
-    DECODE_SPLIT = args.decode_split
+    global DECODE_SPLIT, ENCODER_CUS
+    DECODE_SPLIT, ENCODER_CUS = args.decode_split, args.encoder_cus
     torch.set_num_threads(host_cores())
     if args.mode == "train":
         return run_train(args)
     rank, world, dist, device_index = init_ranks(args)
 
     from whisper_ipa_amd.whisper import Whisper
+    from whisper_ipa_amd.runtime import limit_stream_cus
+    for sid in range(args.pipeline * args.streams):
+        if args.encoder_cus:  # 0: the split into an encoder and a decode stream alone, no CU limit
+            limit_stream_cus(ENC_STREAM_BASE + sid, args.encoder_cus)
+        if args.decoder_cus is not None:
+            limit_stream_cus(sid, args.decoder_cus)
 
     B = args.batch
     log(f"start: rank {rank}/{world}, host cores {host_cores()}")
@@ -751,6 +773,7 @@ def main():
                        "workload": f"whisper-{args.model} {args.dtype}{' (fp8 e4m3 weights)' if args.weights == 'fp8' else ''} batched inference, batch={B}x30s synthetic clips per GPU, "
                                    f"log-mel + encoder + cross-KV + {NEW_TOKENS} greedy KV-cached decode steps",
                        "clips_per_gpu": B, "new_tokens": NEW_TOKENS, "streams_per_gpu": args.streams, "passes_in_flight": args.pipeline, "decode_group": args.decode_group,
+                       "encoder_cus": args.encoder_cus, "decoder_cus": args.decoder_cus,
                        "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "parallelism": f"dp{world} (clip sharding, no collective)"},
             "tokens_checksum": int(tokens.sum() % 1000003),

@@ -36,6 +36,13 @@ enum { WIPA_OK = 0, WIPA_ERR_ARG = -1, WIPA_ERR_HIP = -2, WIPA_ERR_STATE = -3 };
 int wipa_version(void);
 const char* wipa_last_error(void);
 
+/* A HIP stream whose kernels may only run on the first n_cus compute units of the device's CU-mask order (on MI355X mask bit
+ * i is CU i/8 of XCD i%8, so every XCD keeps n_cus/8 of its 32 CUs; n_cus a multiple of 8).  Serving keeps several passes in
+ * flight; giving the MFMA-bound encoder of one pass fewer than all CUs leaves the rest to the HBM-/latency-bound decode loop of
+ * another (bench.py --encoder-cus).  The caller destroys the stream after synchronising it. */
+int wipa_stream_create_cu_limited(int n_cus, wipa_stream_t* out);
+int wipa_stream_destroy(wipa_stream_t s);
+
 /* ------------------------------------------------------------------ K1 log-mel
  * replaces mlx_whisper.audio.log_mel_spectrogram (+ pad_or_trim) at
  * scripts/ipa_data_loader.py:80-82, scripts/transcribe_single.py:44-45,

@@ -552,3 +552,29 @@ def test_embed_fp8_decodes_every_code_like_the_format_definition():
     ok = ~torch.isnan(want)
     assert torch.equal(x.cpu()[ok], want[ok])
     assert ok.sum() == 254
+
+
+def test_cu_limited_stream_runs_the_same_gemm(ops):
+    """wipa_stream_create_cu_limited: a GEMM on a stream confined to 64 of the CUs gives the bits of the unrestricted launch;
+    bad CU counts are refused."""
+    import ctypes as C
+
+    from whisper_ipa_amd import _lib
+    from whisper_ipa_amd.runtime import limit_stream_cus, use_stream
+
+    g = torch.Generator().manual_seed(5)
+    A, W = torch.randn(512, 256, generator=g).cuda(), torch.randn(384, 256, generator=g).cuda()
+    ref = torch.empty(512, 384, device="cuda")
+    ops.gemm(A, W, ref, M=512, N=384, K=256, lda=256, ldw=256, ldc=384)
+    torch.cuda.synchronize()
+    limit_stream_cus(9001, 64)
+    out = torch.empty_like(ref)
+    with use_stream(9001) as s:
+        ops.gemm(A, W, out, M=512, N=384, K=256, lda=256, ldw=256, ldc=384)
+        s.synchronize()
+    assert torch.equal(out, ref)
+    with pytest.raises(_lib.WipaError):
+        limit_stream_cus(9001, 32)  # the stream exists already
+    raw = C.c_void_p()
+    assert _lib.lib().wipa_stream_create_cu_limited(12, C.byref(raw)) == -1  # WIPA_ERR_ARG: not a multiple of 8
+    assert _lib.lib().wipa_stream_create_cu_limited(100000, C.byref(raw)) == -1

@@ -89,6 +89,8 @@ _P = C.POINTER
 SIGNATURES = {
     "wipa_version": (c_int, []),
     "wipa_last_error": (C.c_char_p, []),
+    "wipa_stream_create_cu_limited": (c_int, [c_int, C.POINTER(c_void_p)]),
+    "wipa_stream_destroy": (c_int, [c_void_p]),
     "wipa_logmel_tables_bytes": (c_size_t, [c_int]),
     "wipa_logmel_init": (c_int, [c_void_p, c_int, c_void_p]),
     "wipa_logmel_workspace_bytes": (c_size_t, [c_int, c_int]),

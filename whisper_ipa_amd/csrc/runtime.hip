@@ -29,6 +29,26 @@ void wipa_set_error(const char* fmt, ...) {
 extern "C" const char* wipa_last_error(void) { return g_err; }
 extern "C" int wipa_version(void) { return 100; }
 
+extern "C" int wipa_stream_create_cu_limited(int n_cus, wipa_stream_t* out) {
+    int dev = 0, total = 0;
+    WIPA_CHECK_HIP(hipGetDevice(&dev));
+    WIPA_CHECK_HIP(hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, dev));
+    WIPA_REQUIRE(out && n_cus >= 8 && n_cus <= total && n_cus % 8 == 0, "wipa_stream_create_cu_limited: n_cus=%d must be a multiple of 8 in [8, %d]",
+                 n_cus, total);
+    uint32_t mask[32] = {0};
+    WIPA_REQUIRE(total <= 32 * 32, "wipa_stream_create_cu_limited: %d CUs", total);
+    for (int i = 0; i < n_cus; ++i) mask[i / 32] |= 1u << (i % 32);
+    hipStream_t s = nullptr;
+    WIPA_CHECK_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)((total + 31) / 32), mask));
+    *out = (wipa_stream_t)s;
+    return WIPA_OK;
+}
+extern "C" int wipa_stream_destroy(wipa_stream_t s) {
+    WIPA_REQUIRE(s, "wipa_stream_destroy: null stream");
+    WIPA_CHECK_HIP(hipStreamDestroy((hipStream_t)s));
+    return WIPA_OK;
+}
+
 namespace {
 
 constexpr float QK_SCALE = 0.35355339059327379f;  // 64 ** -0.25

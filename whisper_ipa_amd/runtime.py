@@ -20,6 +20,7 @@ import torch
 from . import _lib
 
 _streams = {}
+_stream_cus = {}  # library stream id -> CU limit (limit_stream_cus), read when the stream is first used
 _tls = threading.local()
 
 
@@ -40,9 +41,25 @@ def stream(sid: Optional[int] = None) -> torch.cuda.Stream:
     key = (torch.cuda.current_device(), sid)
     s = _streams.get(key)
     if s is None:
-        s = torch.cuda.Stream(device=key[0])
+        n_cus = _stream_cus.get(sid)
+        if n_cus is None:
+            s = torch.cuda.Stream(device=key[0])
+        else:
+            raw = C.c_void_p()
+            _lib.check(_lib.lib().wipa_stream_create_cu_limited(int(n_cus), C.byref(raw)), "wipa_stream_create_cu_limited")
+            s = torch.cuda.ExternalStream(raw.value, device=key[0])  # lives as long as the process
         _streams[key] = s
     return s
+
+
+def limit_stream_cus(sid: int, n_cus: Optional[int]) -> None:
+    """Library stream ``sid`` (not yet used) will run its kernels on the first ``n_cus`` CUs only (wipa_stream_create_cu_limited)."""
+    if any(k[1] == sid for k in _streams):
+        raise _lib.WipaError(f"library stream {sid} already exists; set its CU limit before first use")
+    if n_cus is None:
+        _stream_cus.pop(sid, None)
+    else:
+        _stream_cus[sid] = int(n_cus)
 
 
 @contextlib.contextmanager
