@@ -578,3 +578,29 @@ def test_cu_limited_stream_runs_the_same_gemm(ops):
     raw = C.c_void_p()
     assert _lib.lib().wipa_stream_create_cu_limited(12, C.byref(raw)) == -1  # WIPA_ERR_ARG: not a multiple of 8
     assert _lib.lib().wipa_stream_create_cu_limited(100000, C.byref(raw)) == -1
+
+
+@pytest.mark.parametrize("dtype,act,with_res", [(torch.float32, 0, True), (torch.float32, 1, False), (torch.bfloat16, 0, True),
+                                                (torch.bfloat16, 1, False)])
+def test_gemm_384x128_tiles_on_a_badly_quantised_grid(ops, dtype, act, with_res, f32_mode):
+    """48 000 x 768 (32 clips of encoder rows, as in a fine-tune batch) is 375 tiles of 384 x 256 -- 1.46 rounds on 256 CUs --
+    so the dispatcher takes 384 x 128 tiles; checked on the whole matrix, ragged last row tile included (M = 47 990)."""
+    if dtype == torch.bfloat16 and f32_mode == "split":
+        pytest.skip("one bf16 run is enough")
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 47990, 768, 128
+    A = torch.randn(M, K, generator=g).to(dtype)
+    W = (torch.randn(N, K, generator=g) * 0.1).to(dtype)
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g) if with_res else None
+    out = res.clone().cuda() if with_res else torch.empty(M, N, device="cuda")
+    ops.gemm(A.cuda(), W.cuda(), out, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, bias=bias.cuda(), act=act, residual=(out if with_res else None),
+             f32_split=(f32_mode == "split"))
+    torch.cuda.synchronize()
+    y = A.double() @ W.double().T + bias.double()
+    if act:
+        y = torch.nn.functional.gelu(y)
+    if with_res:
+        y = y + res.double()
+    tol = 2e-6 if (dtype == torch.float32 and f32_mode == "exact") else 1e-5 if dtype == torch.float32 else 1e-5
+    assert _rel(out, y) < tol  # bf16 inputs are exact in f32 accumulation too: only the summation order differs

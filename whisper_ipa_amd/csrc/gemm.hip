@@ -1020,19 +1020,29 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
 // 384 (M) x 256 (N) tile (WIPA_GEMM_TILE=384 forces it, =256 forbids it), 8 waves (2 x 4), 192 x 64 per wave = 4 x 12 MFMA tiles
 // (192 accumulator registers).  Stages (256 + 384) x 128 B = 80 KiB per K-step: 1/153.6 byte per FLOP instead of 1/128, and
 // N = 768 gives 750 tiles = 2.93 rounds instead of 4.39.  LDS 2 x 80 KiB = all of it.
+// WN = 2: the same 384 rows against 128 columns, waves 4 x 2, 96 x 64 per wave (4 x 6 MFMA tiles).  For grids the wide tile
+// quantises badly on 256 CUs: the float32 encoder of a 32-clip fine-tune batch (48 000 x 768) is 375 wide tiles = 1.46 rounds
+// but 750 narrow ones = 2.93, and the f32 MFMA is slow enough that the extra staged bytes per FLOP do not show.
 constexpr int XBM = 384;
-constexpr int XW_TILE = LBN * ROWB;        // 32 KiB
-constexpr int XA_TILE = XBM * ROWB;        // 48 KiB
-constexpr int XSTAGE = XW_TILE + XA_TILE;  // 80 KiB
-constexpr int XSMEM = 2 * XSTAGE;          // 160 KiB
+constexpr int XA_TILE = XBM * ROWB;  // 48 KiB
+template <int WN>
+struct X384 {
+    static constexpr int BN = 64 * WN;            // 256 | 128 columns
+    static constexpr int MT = 12 * WN / 4;        // 16-row slices per wave: 12 | 6
+    static constexpr int W_TILE = BN * ROWB;      // 32 | 16 KiB
+    static constexpr int STAGE = W_TILE + XA_TILE;  // 80 | 64 KiB
+    static constexpr int SMEM = 2 * STAGE;          // 160 | 128 KiB
+};
 
-template <typename T, typename OutT, bool ACT, bool SPLIT>  // SPLIT (f32 inputs only): products as three bf16 MFMA terms
-__global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][W tile 256 rows | A tile 384 rows]
+template <typename T, typename OutT, bool ACT, bool SPLIT, int WN>  // SPLIT (f32 inputs only): products as three bf16 MFMA terms
+__device__ __forceinline__ void gemm_nt384_body(GemmParams p) {
+    typedef X384<WN> X;
+    constexpr int MT = X::MT, XW_TILE = X::W_TILE, XSTAGE = X::STAGE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][W tile BN rows | A tile 384 rows]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WN, wn = wave % WN;
     const int nblocks = p.tiles_m * p.tiles_n;
     int id;
     {
@@ -1048,32 +1058,32 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmParams p) {
     const int in_group = id - group * group_size;
     const int tile_m = first_m + in_group % gm;
     const int tile_n = in_group / gm;
-    const int m0 = tile_m * XBM, n0 = tile_n * LBN;
+    const int m0 = tile_m * XBM, n0 = tile_n * X::BN;
 
     const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (int64_t)n0 * p.ldw_b), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)m0 * p.lda_b), 0, 0x7fffffff, 0x00020000);
-    int oW[4], oA[6];
+    int oW[WN], oA[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int row = 64 * i + 8 * wave + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);
-        if (i < 4) oW[i] = (min(n0 + row, p.N - 1) - n0) * (int)p.ldw_b + c * 16;
+        if (i < WN) oW[i] = (min(n0 + row, p.N - 1) - n0) * (int)p.ldw_b + c * 16;
         oA[i] = (min(m0 + row, p.M - 1) - m0) * (int)p.lda_b + c * 16;
     }
     auto stage = [&](int kt, int buf) {
         const int kb = kt * ROWB;
         char* base = smem + buf * XSTAGE + wave * (8 * ROWB);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)(base + i * 64 * ROWB), 16, oW[i], kb, 0, 0);
+        for (int i = 0; i < WN; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)(base + i * 64 * ROWB), 16, oW[i], kb, 0, 0);
 #pragma unroll
         for (int i = 0; i < 6; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(base + XW_TILE + i * 64 * ROWB), 16, oA[i], kb, 0, 0);
     };
-    f32x4 acc[4][12];  // [n tile i][m tile j]
+    f32x4 acc[4][MT];  // [n tile i][m tile j]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 12; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int frow = lane & 15;
     const int fsw = (lane >> 1) & 7;
     const int fq = lane >> 4;
@@ -1104,7 +1114,7 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmParams p) {
         }
         if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
         const char* wb = smem + (kt & 1) * XSTAGE + (wn * 64 + frow) * ROWB;
-        const char* ab = smem + (kt & 1) * XSTAGE + XW_TILE + (wm * 192 + frow) * ROWB;
+        const char* ab = smem + (kt & 1) * XSTAGE + XW_TILE + (wm * (16 * MT) + frow) * ROWB;
         if constexpr (SPLIT && sizeof(T) == 4) {
             // one bf16 MFMA K-step per stage: the lane's floats 4fq..4fq+3 and 16+4fq..19+4fq of every row
             const int c0 = (fq ^ fsw) << 4, c1 = ((fq + 4) ^ fsw) << 4;
@@ -1118,7 +1128,7 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmParams p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) frag(wb + i * 16 * ROWB, wh[i], wl[i]);
 #pragma unroll
-            for (int j = 0; j < 12; ++j) {
+            for (int j = 0; j < MT; ++j) {
                 bf16x8 xh, xl;
                 frag(ab + j * 16 * ROWB, xh, xl);
 #pragma unroll
@@ -1135,15 +1145,16 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmParams p) {
             typename Mma<T>::Frag fw[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) fw[i] = *reinterpret_cast<const typename Mma<T>::Frag*>(wb + i * 16 * ROWB + coff);
+            constexpr int JG = MT == 12 ? 4 : MT;  // A fragments per group: 192 accumulators leave no room for twelve at once
 #pragma unroll
-            for (int jg = 0; jg < 3; ++jg) {  // the A fragments four at a time: 192 accumulators leave no room for twelve
-                typename Mma<T>::Frag fx[4];
+            for (int jg = 0; jg < MT / JG; ++jg) {
+                typename Mma<T>::Frag fx[JG];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) fx[j] = *reinterpret_cast<const typename Mma<T>::Frag*>(ab + (4 * jg + j) * 16 * ROWB + coff);
+                for (int j = 0; j < JG; ++j) fx[j] = *reinterpret_cast<const typename Mma<T>::Frag*>(ab + (JG * jg + j) * 16 * ROWB + coff);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) Mma<T>::run(fw[i], fx[j], acc[i][4 * jg + j]);
+                    for (int j = 0; j < JG; ++j) Mma<T>::run(fw[i], fx[j], acc[i][JG * jg + j]);
             }
         }
         }  // exact path
@@ -1165,7 +1176,7 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmParams p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) b4[e] = (p.bias && n + e < p.N) ? p.bias[n + e] : 0.f;
 #pragma unroll
-                for (int j = 0; j < 12; ++j) {
+                for (int j = 0; j < MT; ++j) {
                     const f32x2 g0 = gelu_erf2(f32x2{acc[i][j][0] + b4[0], acc[i][j][1] + b4[1]});
                     const f32x2 g1 = gelu_erf2(f32x2{acc[i][j][2] + b4[2], acc[i][j][3] + b4[3]});
                     acc[i][j] = f32x4{g0.x, g0.y, g1.x, g1.y};
@@ -1174,38 +1185,71 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmParams p) {
             }
             p.bias = nullptr;
         }
-        epilogue_staged<OutT, 12, 0, 12, false, !ACT>(p, acc, smem + wave * 4096, m0 + wm * 192, n0 + wn * 64, coff_dev, lane);
+        epilogue_staged<OutT, MT, 0, MT, false, !ACT>(p, acc, smem + wave * 4096, m0 + wm * (16 * MT), n0 + wn * 64, coff_dev, lane);
         return;
     }
     EpiCol cols[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) cols[i] = epi_col(p, n0 + wn * 64 + 16 * i + 4 * fq);
 #pragma unroll
-    for (int j = 0; j < 12; ++j) {
-        const EpiRow row = epi_row(p, m0 + wm * 192 + 16 * j + frow, coff_dev);
+    for (int j = 0; j < MT; ++j) {
+        const EpiRow row = epi_row(p, m0 + wm * (16 * MT) + 16 * j + frow, coff_dev);
 #pragma unroll
         for (int i = 0; i < 4; ++i) epilogue4<OutT>(p, acc[i][j], row, cols[i], vec);
     }
 }
 
+template <typename T, typename OutT, bool ACT, bool SPLIT>
+__global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmParams p) {
+    gemm_nt384_body<T, OutT, ACT, SPLIT, 4>(p);
+}
+template <typename T, typename OutT, bool ACT, bool SPLIT>
+__global__ __launch_bounds__(512) void gemm_nt384n_kernel(GemmParams p) {  // 384 x 128
+    gemm_nt384_body<T, OutT, ACT, SPLIT, 2>(p);
+}
+
 template <typename T, typename OutT>
 int launch384(GemmParams p, hipStream_t s) {
+    typedef X384<4> X;
     p.tiles_m = (p.M + XBM - 1) / XBM;
-    p.tiles_n = (p.N + LBN - 1) / LBN;
+    p.tiles_n = (p.N + X::BN - 1) / X::BN;
     const dim3 grid(p.tiles_m * p.tiles_n);
     const bool act = p.act == 1 && p.stage_ok;
     if constexpr (sizeof(T) == 4) {
         if (p.f32_split) {
-            if (act) hipLaunchKernelGGL((gemm_nt384_kernel<T, OutT, true, true>), grid, dim3(512), XSMEM, s, p);
-            else hipLaunchKernelGGL((gemm_nt384_kernel<T, OutT, false, true>), grid, dim3(512), XSMEM, s, p);
+            if (act) hipLaunchKernelGGL((gemm_nt384_kernel<T, OutT, true, true>), grid, dim3(512), X::SMEM, s, p);
+            else hipLaunchKernelGGL((gemm_nt384_kernel<T, OutT, false, true>), grid, dim3(512), X::SMEM, s, p);
             WIPA_LAUNCH_CHECK();
             return WIPA_OK;
         }
     }
     if (act)
-        hipLaunchKernelGGL((gemm_nt384_kernel<T, OutT, true, false>), grid, dim3(512), XSMEM, s, p);
+        hipLaunchKernelGGL((gemm_nt384_kernel<T, OutT, true, false>), grid, dim3(512), X::SMEM, s, p);
     else
-        hipLaunchKernelGGL((gemm_nt384_kernel<T, OutT, false, false>), grid, dim3(512), XSMEM, s, p);
+        hipLaunchKernelGGL((gemm_nt384_kernel<T, OutT, false, false>), grid, dim3(512), X::SMEM, s, p);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+template <typename T, typename OutT>
+int launch384n(GemmParams p, hipStream_t s) {
+    typedef X384<2> X;
+    p.tiles_m = (p.M + XBM - 1) / XBM;
+    p.tiles_n = (p.N + X::BN - 1) / X::BN;
+    const dim3 grid(p.tiles_m * p.tiles_n);
+    const bool act = p.act == 1 && p.stage_ok;
+    if constexpr (sizeof(T) == 4) {
+        if (p.f32_split) {
+            if (act) hipLaunchKernelGGL((gemm_nt384n_kernel<T, OutT, true, true>), grid, dim3(512), X::SMEM, s, p);
+            else hipLaunchKernelGGL((gemm_nt384n_kernel<T, OutT, false, true>), grid, dim3(512), X::SMEM, s, p);
+            WIPA_LAUNCH_CHECK();
+            return WIPA_OK;
+        }
+    }
+    if (act)
+        hipLaunchKernelGGL((gemm_nt384n_kernel<T, OutT, true, false>), grid, dim3(512), X::SMEM, s, p);
+    else
+        hipLaunchKernelGGL((gemm_nt384n_kernel<T, OutT, false, false>), grid, dim3(512), X::SMEM, s, p);
     WIPA_LAUNCH_CHECK();
     return WIPA_OK;
 }
@@ -1247,7 +1291,7 @@ int init_attrs() {
             const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LSMEM);
             if (e != hipSuccess) err = e;
         }
-        const void* wide[12] = {reinterpret_cast<const void*>(&gemm_nt384_kernel<__bf16, __bf16, false, false>),
+        const void* wide[24] = {reinterpret_cast<const void*>(&gemm_nt384_kernel<__bf16, __bf16, false, false>),
                                 reinterpret_cast<const void*>(&gemm_nt384_kernel<__bf16, float, false, false>),
                                 reinterpret_cast<const void*>(&gemm_nt384_kernel<float, __bf16, false, false>),
                                 reinterpret_cast<const void*>(&gemm_nt384_kernel<float, float, false, false>),
@@ -1258,9 +1302,21 @@ int init_attrs() {
                                 reinterpret_cast<const void*>(&gemm_nt384_kernel<float, __bf16, false, true>),
                                 reinterpret_cast<const void*>(&gemm_nt384_kernel<float, float, false, true>),
                                 reinterpret_cast<const void*>(&gemm_nt384_kernel<float, __bf16, true, true>),
-                                reinterpret_cast<const void*>(&gemm_nt384_kernel<float, float, true, true>)};
-        for (const void* f : wide) {
-            const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, XSMEM);
+                                reinterpret_cast<const void*>(&gemm_nt384_kernel<float, float, true, true>),
+                                reinterpret_cast<const void*>(&gemm_nt384n_kernel<__bf16, __bf16, false, false>),
+                                reinterpret_cast<const void*>(&gemm_nt384n_kernel<__bf16, float, false, false>),
+                                reinterpret_cast<const void*>(&gemm_nt384n_kernel<float, __bf16, false, false>),
+                                reinterpret_cast<const void*>(&gemm_nt384n_kernel<float, float, false, false>),
+                                reinterpret_cast<const void*>(&gemm_nt384n_kernel<__bf16, __bf16, true, false>),
+                                reinterpret_cast<const void*>(&gemm_nt384n_kernel<__bf16, float, true, false>),
+                                reinterpret_cast<const void*>(&gemm_nt384n_kernel<float, __bf16, true, false>),
+                                reinterpret_cast<const void*>(&gemm_nt384n_kernel<float, float, true, false>),
+                                reinterpret_cast<const void*>(&gemm_nt384n_kernel<float, __bf16, false, true>),
+                                reinterpret_cast<const void*>(&gemm_nt384n_kernel<float, float, false, true>),
+                                reinterpret_cast<const void*>(&gemm_nt384n_kernel<float, __bf16, true, true>),
+                                reinterpret_cast<const void*>(&gemm_nt384n_kernel<float, float, true, true>)};
+        for (int i = 0; i < 24; ++i) {
+            const hipError_t e = hipFuncSetAttribute(wide[i], hipFuncAttributeMaxDynamicSharedMemorySize, i < 12 ? X384<4>::SMEM : X384<2>::SMEM);
             if (e != hipSuccess) err = e;
         }
         const void* lnk[9] = {reinterpret_cast<const void*>(&gemm_skinny_ln_kernel<__bf16, __bf16, 1>),
@@ -1411,15 +1467,25 @@ extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
     // an activation is applied before the epilogue there, which is only equivalent for: column bias, no column scale, no
     // positional term, no residual ordering issue (act precedes pos/residual in epilogue order anyway)
     const bool act384_ok = d->act == 0 || (p.stage_ok && !d->bias_along_m && d->col_scale_n == 0);
-    bool use384 = force_tile == 384 && act384_ok;
+    bool use384 = force_tile == 384 && act384_ok, narrow = false;
     if (big && force_tile == 0 && act384_ok && d->M >= 2 * XBM) {
-        const int64_t t256 = (int64_t)((d->M + LBM - 1) / LBM) * ((d->N + LBN - 1) / LBN);
-        const int64_t t384 = (int64_t)((d->M + XBM - 1) / XBM) * ((d->N + LBN - 1) / LBN);
-        const double e256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);
-        const double e384 = (double)t384 / (double)(((t384 + 255) / 256) * 256);
+        auto fill = [](int64_t t) { return (double)t / (double)(((t + 255) / 256) * 256); };
+        const int64_t tm384 = (d->M + XBM - 1) / XBM;
+        const double e256 = fill((int64_t)((d->M + LBM - 1) / LBM) * ((d->N + LBN - 1) / LBN));
+        const double e384 = fill(tm384 * ((d->N + LBN - 1) / LBN));
         use384 = e384 >= 0.95 * e256;
+        // 384 x 128 tiles when the wide grids leave a large part of the last round empty (48 000 x 768: 375 or 564 tiles, 0.73
+        // either way, against 750 narrow ones, 0.98).  Float32 runs at the f32 MFMA's pace whatever the tile; bf16 pays for the
+        // extra staged bytes per FLOP, so it needs a bigger gain.
+        const double e384n = fill(tm384 * ((d->N + 127) / 128));
+        if (e384n >= (d->in_dtype == WIPA_F32 ? 1.10 : 1.25) * (e384 > e256 ? e384 : e256)) use384 = narrow = true;
     }
     if (big && use384) {
+        if (narrow) {
+            if (d->in_dtype == WIPA_BF16)
+                return d->out_dtype == WIPA_BF16 ? launch384n<__bf16, __bf16>(p, s) : launch384n<__bf16, float>(p, s);
+            return d->out_dtype == WIPA_BF16 ? launch384n<float, __bf16>(p, s) : launch384n<float, float>(p, s);
+        }
         if (d->in_dtype == WIPA_BF16)
             return d->out_dtype == WIPA_BF16 ? launch384<__bf16, __bf16>(p, s) : launch384<__bf16, float>(p, s);
         return d->out_dtype == WIPA_BF16 ? launch384<float, __bf16>(p, s) : launch384<float, float>(p, s);

@@ -118,7 +118,7 @@ class DecoderTrainer:
         are 96 tiles of 128 x 128 -- a third of the chip -- so K is cut into slices computed by separate workgroups (slabs
         summed in a fixed order, then scale / residual: wipa_sum_slabs_ex) whenever the tile grid alone leaves CUs idle."""
         tiles = ((M + 127) // 128) * ((N + 127) // 128)
-        slices = min(4, 288 // max(tiles, 1), K // 256) if (M >= 512 and tiles < 192) else 1
+        slices = min(4 if K < 8192 else 8, 768 // max(tiles, 1), K // 256) if (M >= 512 and tiles < 192) else 1
         plain = out.dim() == 2 and out.shape[0] == M and out.shape[1] == N and out.is_contiguous() and (
             residual is None or (residual.is_contiguous() and residual.shape == out.shape))
         if slices > 1 and plain:
@@ -290,7 +290,7 @@ class DecoderTrainer:
             # logits = hf E^T : dhf = dlogits E ; dE = dlogits^T hf
             ET = self._transpose(E, V, d, Vp)  # [d, Vp]
             dhf = torch.empty(M, d, dtype=torch.float32, device=dev)
-            self._gemm(dlogits, ET, dhf, M=M, N=d, K=Vp, lda=Vp, ldw=Vp, ldc=d)
+            self._mm(dlogits, ET, dhf, M, d, Vp, Vp, Vp)  # 96 tiles over a 51 872-long contraction: eight K slices
             dlT = self._transpose(dlogits, M, V, Mp)  # [V, Mp]
             hfT = self._transpose(hf, M, d, Mp)
             self._gemm(dlT, hfT, G("decoder.token_embedding.weight"), M=V, N=d, K=Mp, lda=Mp, ldw=Mp, ldc=d)
