@@ -604,3 +604,38 @@ def test_gemm_384x128_tiles_on_a_badly_quantised_grid(ops, dtype, act, with_res,
         y = y + res.double()
     tol = 2e-6 if (dtype == torch.float32 and f32_mode == "exact") else 1e-5 if dtype == torch.float32 else 1e-5
     assert _rel(out, y) < tol  # bf16 inputs are exact in f32 accumulation too: only the summation order differs
+
+
+@pytest.mark.parametrize("Tq,Tk,causal", [(64, 1500, False), (64, 64, True), (50, 100, False), (100, 100, True), (16, 17, True)])
+def test_attention_f32_mfma_forward_with_lse(Tq, Tk, causal):
+    """wipa_attention in float32 with >= 16 queries runs on the f32 MFMA: output AND the saved log-sum-exp rows (what the
+    backward pass consumes) against an fp64 reference; strided q / k / v views as the trainer passes them."""
+    import ctypes as C
+
+    from whisper_ipa_amd import _lib
+    from whisper_ipa_amd.runtime import on_stream, ptr, sptr
+
+    g = torch.Generator().manual_seed(Tq * 7 + Tk)
+    B, H = 2, 3
+    qkv = (torch.randn(B, max(Tq, Tk), 3, H, 64, generator=g) * 0.6)
+    q, k, v = qkv[:, :Tq, 0], qkv[:, :Tk, 1], qkv[:, :Tk, 2]
+    dev = qkv.cuda()
+    qd, kd, vd = dev[:, :Tq, 0], dev[:, :Tk, 1], dev[:, :Tk, 2]
+    out = torch.full((B, Tq, H, 64), 7.0, device="cuda")
+    lse = torch.full((B, H, Tq), 7.0, device="cuda")
+    with on_stream() as s:
+        d = _lib.AttnDesc()
+        d.q, d.k, d.v, d.out, d.lse = ptr(qd), ptr(kd), ptr(vd), ptr(out), ptr(lse)
+        d.q_bs, d.q_rs, d.q_hs = qd.stride(0), qd.stride(1), qd.stride(2)
+        d.k_bs, d.k_rs, d.k_hs = kd.stride(0), kd.stride(1), kd.stride(2)
+        d.v_bs, d.v_rs, d.v_hs = vd.stride(0), vd.stride(1), vd.stride(2)
+        d.o_bs, d.o_rs, d.o_hs = out.stride(0), out.stride(1), out.stride(2)
+        d.B, d.H, d.Tq, d.Tk, d.causal, d.dtype = B, H, Tq, Tk, int(causal), _lib.WIPA_F32
+        _lib.check(_lib.lib().wipa_attention(C.byref(d), sptr(s)), "wipa_attention")
+    torch.cuda.synchronize()
+    sc = torch.einsum("bqhd,bkhd->bhqk", q.double(), k.double())
+    if causal:
+        sc = sc + torch.triu(torch.full((Tk, Tk), float("-inf"), dtype=torch.float64), 1)[Tk - Tq:]
+    ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(sc, -1), v.double())
+    assert _rel(out, ref) < 2e-6
+    assert (lse.cpu().double() - torch.logsumexp(sc, -1)).abs().max() < 2e-5

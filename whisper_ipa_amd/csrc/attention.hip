@@ -159,6 +159,119 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(AttnParams p) {
     }
 }
 
+// ---- the same attention on the f32 MFMA, for float32 with at least one 16-query fragment (the teacher-forced decoder of a
+// fine-tune step: 64 target positions against 64 causal keys, and against the 1500 encoder positions -- 0.5 ms per layer on
+// the VALU kernel above).  64 queries per workgroup, wave w owns queries 16w .. 16w+15 with the query row as MFMA fragment
+// in registers and walks the keys in tiles of 64 staged as K [key][d] and V^T [d][key].  The keys sit on the ROW side of the
+// score product, S[key][q], so a lane ends up holding 4 consecutive keys of one query: after the softmax these ARE the
+// fragment of O[q][d] += sum_key P[q][key] V[key][d] (no LDS round trip for P; attention_bwd.hip uses the same orientation).
+// Online softmax per query: its 64 scores of a tile are spread over the 4 lanes (frow = query, fq = 0..3).
+__global__ __launch_bounds__(256) void attn_fwd_f32_mfma_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) float Ks[64 * GA_LD];
+    __shared__ __attribute__((aligned(16))) float VsT[64 * GA_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 64;
+    const int qi = q0 + 16 * wave + frow;
+    const int qc = min(qi, p.Tq - 1);
+    f32x4 qx[4];
+    {
+        const float* qp = reinterpret_cast<const float*>(p.q) + b * p.q_bs + (int64_t)qc * p.q_rs + h * p.q_hs + 4 * fq;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qx[ks] = *reinterpret_cast<const f32x4*>(qp + 16 * ks);
+    }
+    f32x4 O[4];  // O[j][r] <-> query q0 + 16 wave + 4 fq + r, d = 16 j + frow
+#pragma unroll
+    for (int j = 0; j < 4; ++j) O[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m = NEG_BIG, l = 0.f;  // of query frow; l is this lane's share (its 16 keys of every tile)
+    const int off = p.Tk - p.Tq;
+    const int kmax = p.causal ? qc + off : p.Tk - 1;  // last visible key of the lane's query
+    const int q_last = min(q0 + 63, p.Tq - 1);
+    const int k_end = p.causal ? min(p.Tk, q_last + off + 1) : p.Tk;
+    const int srow = tid >> 2, sseg = (tid & 3) * 16;
+    const float* kb = reinterpret_cast<const float*>(p.k) + b * p.k_bs + h * p.k_hs;
+    const float* vb = reinterpret_cast<const float*>(p.v) + b * p.v_bs + h * p.v_hs;
+    for (int k0 = 0; k0 < k_end; k0 += 64) {
+        __syncthreads();
+        {
+            const int key = k0 + srow;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f}, bb = {0.f, 0.f, 0.f, 0.f};
+                if (key < p.Tk) {
+                    a = *reinterpret_cast<const f32x4*>(kb + (int64_t)key * p.k_rs + sseg + 4 * c);
+                    bb = *reinterpret_cast<const f32x4*>(vb + (int64_t)key * p.v_rs + sseg + 4 * c);
+                }
+                *reinterpret_cast<f32x4*>(&Ks[srow * GA_LD + sseg + 4 * c]) = a;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) VsT[(sseg + 4 * c + e) * GA_LD + srow] = bb[e];
+            }
+        }
+        __syncthreads();
+        f32x4 S[4];  // S[i][e] <-> key k0 + 16 i + 4 fq + e, query = the lane's
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            S[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const f32x4 kf = *reinterpret_cast<const f32x4*>(&Ks[(16 * i + frow) * GA_LD + 16 * ks + 4 * fq]);
+                Mma<float>::run(kf, qx[ks], S[i]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (k0 + 16 * i + 4 * fq + e > kmax) S[i][e] = NEG_BIG;
+                mx = fmaxf(mx, S[i][e]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m, mx);
+        if (__any(m_new > m)) {
+            const float alpha = __expf(m - m_new);
+            l *= alpha;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ar = __shfl(alpha, 4 * fq + r, 64);  // lane 4fq + r holds query 4fq + r of this wave
+#pragma unroll
+                for (int j = 0; j < 4; ++j) O[j][r] *= ar;
+            }
+            m = m_new;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pr = (S[i][e] <= NEG_TEST) ? 0.f : __expf(S[i][e] - m);
+                S[i][e] = pr;
+                l += pr;
+            }
+        // O[q][d] += sum_key P[q][key] V[key][d]   (k-step i = keys 16i .. 16i+15 of the tile)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 vt = *reinterpret_cast<const f32x4*>(&VsT[(16 * j + frow) * GA_LD + 16 * i + 4 * fq]);
+                Mma<float>::run(S[i], vt, O[j]);
+            }
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (p.lse && fq == 0 && qi < p.Tq) p.lse[((int64_t)b * gridDim.y + h) * p.Tq + qi] = m + __logf(l);
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float ir = __shfl(inv, 4 * fq + r, 64);
+        const int qq = q0 + 16 * wave + 4 * fq + r;
+        if (qq < p.Tq) {
+            float* op = reinterpret_cast<float*>(p.out) + b * p.o_bs + (int64_t)qq * p.o_rs + h * p.o_hs + frow;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) op[16 * j] = O[j][r] * ir;
+        }
+    }
+}
+
 // =============================================================================
 // K11 decode-step cross-attention
 // =============================================================================
@@ -903,6 +1016,15 @@ extern "C" int wipa_attention(const wipa_attn_desc* d, wipa_stream_t stream) {
     p.Tk = d->Tk;
     p.causal = d->causal;
     dim3 grid((d->Tq + 15) / 16, d->H, d->B);
+    // float32 with whole 16-query fragments and no device-side offsets (teacher-forced decoder, fine-tune step): f32 MFMA kernel;
+    // the few-row prefill and everything bf16 stay on the VALU kernel.  WIPA_ATTN_FWD=valu keeps it for A/B runs.
+    static const bool valu = [] { const char* e = getenv("WIPA_ATTN_FWD"); return e && !strcmp(e, "valu"); }();
+    if (d->dtype == WIPA_F32 && !valu && d->Tq >= 16 && !d->tk_dev && !d->q_row_dev && d->o_rs % 4 == 0 && d->o_hs % 4 == 0 &&
+        d->o_bs % 4 == 0) {
+        hipLaunchKernelGGL(attn_fwd_f32_mfma_kernel, dim3((d->Tq + 63) / 64, d->H, d->B), dim3(256), 0, (hipStream_t)stream, p);
+        WIPA_LAUNCH_CHECK();
+        return WIPA_OK;
+    }
     if (d->dtype == WIPA_F32)
         hipLaunchKernelGGL((attn_generic_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, p);
     else
