@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256, 6) void decode_cross_block_kernel(CrossBlockPa
 
     // The cross-query weights do not depend on the residual row: the first batch of this thread's 16-byte chunks of row
     // (h*64 + j) is requested before anything else, so its round trip overlaps the prologue's.
-    constexpr int UQ = 6;
+    constexpr int UQ = 3;
     const int qj = tid >> 2, qpart = tid & 3;
     const T* wr = reinterpret_cast<const T*>(p.wq) + (int64_t)(h * 64 + qj) * d;
     const int nch = d / EPL;  // 16-byte chunks per weight row
@@ -359,7 +359,18 @@ __global__ __launch_bounds__(256, 6) void decode_cross_block_kernel(CrossBlockPa
 #pragma unroll
     for (int u = 0; u < UQ; ++u)
         if (qpart + 4 * u < nch) wcur[u] = *reinterpret_cast<const Vec16<T>*>(wr + (qpart + 4 * u) * EPL);
+    // streaming roles (phase 3), fixed by the lane alone: the K rows of this wave's FIRST key group are requested right behind
+    // the prologue's own loads -- every workgroup of the launch is resident at once, so without this HBM idles for the whole
+    // prologue (slab sum, LayerNorm, query GEMV: ~5 us of a 55 us kernel)
+    const int g = lane / LPK, c = lane % LPK;
+    const int Tk = p.Tk;
+    const int64_t head = (int64_t)Tk * 64;
+    const T* Kb = reinterpret_cast<const T*>(p.kv) + ((int64_t)b * 2 * p.H + h) * head + c * EPL;
+    const T* Vb = Kb + (int64_t)p.H * head;
+    typedef decltype(wcur[0].v) VT;
 
+    constexpr int PRE = 3;  // key rows of the first group requested ahead (all U would spill at 80 registers)
+    Vec16<T> kpre[PRE];
     // ---- 1. residual row: x + out-bias + slabs in order 0..n-1; LayerNorm -> xn (rounded through T)
     {
         f32x4 v[2];
@@ -391,6 +402,9 @@ __global__ __launch_bounds__(256, 6) void decode_cross_block_kernel(CrossBlockPa
         sum = wave_reduce_sum(sum);
         if (lane == 0) s_red[wave] = sum;
         __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PRE; ++u)
+            kpre[u].v = __builtin_nontemporal_load(reinterpret_cast<const VT*>(Kb + (int64_t)min(wave * G * U + u * G + g, Tk - 1) * 64));
         const float mean = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) / (float)d;
         float sq = 0.f;
 #pragma unroll
@@ -450,27 +464,18 @@ __global__ __launch_bounds__(256, 6) void decode_cross_block_kernel(CrossBlockPa
     __syncthreads();
 
     // ---- 3. streaming cross-attention (the arithmetic of decode_attn_kernel<T, 4>: 4 waves split the keys)
-    const int g = lane / LPK, c = lane % LPK;
-    const int Tk = p.Tk;
     float qf[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) qf[e] = q_s[c * EPL + e];
-    const int64_t head = (int64_t)Tk * 64;
-    const T* Kb = reinterpret_cast<const T*>(p.kv) + ((int64_t)b * 2 * p.H + h) * head + c * EPL;
-    const T* Vb = Kb + (int64_t)p.H * head;
     float m = NEG_BIG, l = 0.f, acc[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
     constexpr int STEP = 4 * G * U;
-    for (int t0 = wave * G * U; t0 < Tk; t0 += STEP) {
-        Vec16<T> ka[U], va[U];
-        typedef decltype(ka[0].v) VT;
+    auto key_group = [&](Vec16<T> (&ka)[U], int t0) {
+        Vec16<T> va[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int t = min(t0 + u * G + g, Tk - 1);
-            ka[u].v = __builtin_nontemporal_load(reinterpret_cast<const VT*>(Kb + (int64_t)t * 64));
-            va[u].v = __builtin_nontemporal_load(reinterpret_cast<const VT*>(Vb + (int64_t)t * 64));
-        }
+        for (int u = 0; u < U; ++u)
+            va[u].v = __builtin_nontemporal_load(reinterpret_cast<const VT*>(Vb + (int64_t)min(t0 + u * G + g, Tk - 1) * 64));
         float s[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -496,6 +501,23 @@ __global__ __launch_bounds__(256, 6) void decode_cross_block_kernel(CrossBlockPa
             for (int e = 0; e < EPL; ++e) acc[e] = fmaf(pr, va[u].get(e), acc[e]);
         }
         m = m_new;
+    };
+    if (wave * G * U < Tk) {
+        const int t0 = wave * G * U;
+        Vec16<T> ka[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (u < PRE) ka[u] = kpre[u];
+            else ka[u].v = __builtin_nontemporal_load(reinterpret_cast<const VT*>(Kb + (int64_t)min(t0 + u * G + g, Tk - 1) * 64));
+        }
+        key_group(ka, t0);
+    }
+    for (int t0 = wave * G * U + STEP; t0 < Tk; t0 += STEP) {
+        Vec16<T> ka[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            ka[u].v = __builtin_nontemporal_load(reinterpret_cast<const VT*>(Kb + (int64_t)min(t0 + u * G + g, Tk - 1) * 64));
+        key_group(ka, t0);
     }
 #pragma unroll
     for (int o = LPK; o < 64; o <<= 1) {
