@@ -639,3 +639,43 @@ def test_attention_f32_mfma_forward_with_lse(Tq, Tk, causal):
     ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(sc, -1), v.double())
     assert _rel(out, ref) < 2e-6
     assert (lse.cpu().double() - torch.logsumexp(sc, -1)).abs().max() < 2e-5
+
+
+def test_gemm_phase_interleaved_256_tile_in_a_subprocess():
+    """gemm_nt256p_kernel (WIPA_GEMM_TILE=2568, read once per process): K-tile counts 2 / 4 / 10, ragged M and N, the three
+    epilogues -- against torch in float32."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import torch
+from whisper_ipa_amd import ops
+g = torch.Generator().manual_seed(0)
+worst = 0.0
+for (M, N, K, odt, act, res) in [(4096, 2560, 128, torch.bfloat16, 0, False), (4000, 2500, 256, torch.float32, 0, True),
+                                 (4100, 2560, 640, torch.bfloat16, 1, False), (8192, 1280, 1280, torch.float32, 0, False)]:
+    A = torch.randn(M, K, generator=g).bfloat16().cuda()
+    W = (torch.randn(N, K, generator=g) * 0.1).bfloat16().cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    ldc = (N + 7) // 8 * 8
+    r0 = torch.randn(M, ldc, generator=g).to(odt).cuda()
+    out = r0.clone()
+    ops.gemm(A, W, out, M=M, N=N, K=K, lda=K, ldw=K, ldc=ldc, bias=bias, act=act, residual=(out if res else None))
+    torch.cuda.synchronize()
+    y = A.float() @ W.float().T + bias
+    if act:
+        y = torch.nn.functional.gelu(y)
+    if res:
+        y = y + r0[:, :N].float()
+    err = float((out[:, :N].float() - y).abs().max() / y.abs().max())
+    tol = 1e-2 if odt == torch.bfloat16 else 2e-5
+    assert err < tol, (M, N, K, err)
+    assert torch.equal(out[:, N:], r0[:, N:])  # padding columns untouched
+    worst = max(worst, err)
+print("OK", worst)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WIPA_GEMM_TILE="2568", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:] + r.stdout[-500:]

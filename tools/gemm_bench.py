@@ -21,6 +21,22 @@ cases = [
     ("mlp2    N=768  K=3072 bf16->f32  bias+resid", 768, 3072, torch.float32, 0, True, False),
     ("mlp2*   N=768  K=3072 bf16->bf16 bias      ", 768, 3072, torch.bfloat16, 0, False, False),
 ]
+if len(sys.argv) > 2 and sys.argv[2] == "large":  # whisper-large-v3 width (d = 1280), 64 clips
+    cases = [
+        ("qk      N=2560 K=1280 bf16->bf16 bias+scale", 2560, 1280, torch.bfloat16, 0, False, True),
+        ("mlp1    N=5120 K=1280 bf16->bf16 bias+gelu ", 5120, 1280, torch.bfloat16, 1, False, False),
+        ("out     N=1280 K=1280 bf16->f32  bias+resid", 1280, 1280, torch.float32, 0, True, False),
+        ("mlp2    N=1280 K=5120 bf16->f32  bias+resid", 1280, 5120, torch.float32, 0, True, False),
+        ("mlp2*   N=1280 K=5120 bf16->bf16 bias      ", 1280, 5120, torch.bfloat16, 0, False, False),
+    ]
+if len(sys.argv) > 2 and sys.argv[2] == "medium":  # whisper-medium width (d = 1024), 64 clips
+    cases = [
+        ("qk      N=2048 K=1024 bf16->bf16 bias+scale", 2048, 1024, torch.bfloat16, 0, False, True),
+        ("mlp1    N=4096 K=1024 bf16->bf16 bias+gelu ", 4096, 1024, torch.bfloat16, 1, False, False),
+        ("out     N=1024 K=1024 bf16->f32  bias+resid", 1024, 1024, torch.float32, 0, True, False),
+        ("mlp2    N=1024 K=4096 bf16->f32  bias+resid", 1024, 4096, torch.float32, 0, True, False),
+        ("mlp2*   N=1024 K=4096 bf16->bf16 bias      ", 1024, 4096, torch.bfloat16, 0, False, False),
+    ]
 g = torch.Generator(device="cuda").manual_seed(0)
 for name, N, K, odt, act, resid, scale in cases:
     A = (torch.randn(M, K, device="cuda", generator=g)).bfloat16()
@@ -43,5 +59,16 @@ for name, N, K, odt, act, resid, scale in cases:
     tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
     osz = 4 if odt == torch.float32 else 2
     gb = (M * K * 2 + N * K * 2 + M * N * osz * (2 if resid else 1)) / 1e9
-    print(f"{tag:8s} {name}: {ms * 1e3:8.1f} us  {tf:7.1f} TF/s  min-traffic {gb:5.2f} GB -> {gb / (ms * 1e-3) / 1e3:5.2f} TB/s", flush=True)
-    del A, W, out
+    # correctness on a sample of rows (first / last tiles and 2000 random rows) against torch in float32
+    out2 = torch.zeros(M, N, device="cuda", dtype=odt)
+    ops.gemm(A, W, out2, **dict(kw, residual=out2 if resid else None))
+    torch.cuda.synchronize()
+    rows = torch.cat([torch.arange(0, 600), torch.arange(M - 600, M), torch.randint(0, M, (2000,))]).cuda()
+    ref = A[rows].float() @ W.float().T + bias
+    if scale:
+        ref = ref * 0.35
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    err = float((out2[rows].float() - ref).abs().max() / ref.abs().max())
+    print(f"{tag:8s} {name}: {ms * 1e3:8.1f} us  {tf:7.1f} TF/s  min-traffic {gb:5.2f} GB -> {gb / (ms * 1e-3) / 1e3:5.2f} TB/s  err {err:.2e}", flush=True)
+    del A, W, out, out2

@@ -1017,6 +1017,183 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------
+// 256 x 256 tile, bf16, phase-interleaved (WIPA_GEMM_TILE=2568 selects it for A/B runs).  Same LDS image as gemm_nt256_kernel
+// (two buffers of [W tile | A tile], 128-byte rows, swizzled 16-byte chunks, filled by LDS-DMA) and the same wave grid
+// (2 x 4, 128 x 64 per wave), but the K loop never drains the DMA queue:
+//   * a K-tile (64 elements) is FOUR phases, one C quadrant (64 x 32 of the wave's 128 x 64) each: 16 MFMAs between two raw
+//     s_barriers, preceded by the LDS fragment reads of that quadrant and ONE half-tile (16 KiB: 2 DMA pieces per wave) of
+//     prefetch;
+//   * the tile's halves are cut ACROSS the waves -- A half x = rows wm*128 + 64x .. +63 of both wave rows, W half y = columns
+//     wn*64 + 32y .. +31 of all four wave columns -- so the four halves are first needed in phases 1, 1, 2, 3 and last read in
+//     phases 1, 1, 2, 3 (A fragments are re-read per half, W half 0 stays in registers for phase 4): each half is re-staged
+//     two phases after its last read, for the tile TWO ahead, and is read five phases after its issue;
+//   * every phase ends its load segment with s_waitcnt vmcnt(8): the four youngest half-tiles stay in flight across the
+//     barriers, the one issued four phases ago has landed, and after the barrier the next phase may read it;
+//   * the two wave rows run half a phase apart (wave row 1 takes one barrier more before the loop, wave row 0 one more after
+//     it), so on every SIMD one wave is in its MFMA segment while the other issues LDS reads and DMA.
+// K must be a multiple of 128 elements (an even number of K-tiles: the loop body is two tiles so that buffer indices are
+// compile-time constants).
+template <typename OutT>
+__global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p) {
+    typedef __bf16 T;
+    typedef Mma<T>::Frag Frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][W tile | A tile]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nblocks = p.tiles_m * p.tiles_n;
+    int id;
+    {
+        const int bid = blockIdx.x;
+        const int q = nblocks >> 3, r = nblocks & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int group_size = GROUP_M * p.tiles_n;
+    const int group = id / group_size;
+    const int first_m = group * GROUP_M;
+    const int gm = min(p.tiles_m - first_m, GROUP_M);
+    const int in_group = id - group * group_size;
+    const int tile_m = first_m + in_group % gm;
+    const int tile_n = in_group / gm;
+    const int m0 = tile_m * LBM, n0 = tile_n * LBN;
+
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (int64_t)n0 * p.ldw_b), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)m0 * p.lda_b), 0, 0x7fffffff, 0x00020000);
+    // DMA pieces (8 rows x 128 B per wave instruction).  A half x, piece s: rows 128 s + 64 x + 8 wave + (lane >> 3).
+    // W half y, piece s: rows 128 s + 64 (wave >> 2) + 32 y + 8 (wave & 3) + (lane >> 3).
+    int oA[2][2], oW[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+            const int ra = 128 * sp + 64 * h + 8 * wave + (lane >> 3);
+            const int rw = 128 * sp + 64 * (wave >> 2) + 32 * h + 8 * (wave & 3) + (lane >> 3);
+            oA[h][sp] = (min(m0 + ra, p.M - 1) - m0) * (int)p.lda_b + (((lane & 7) ^ ((ra >> 1) & 7)) << 4);
+            oW[h][sp] = (min(n0 + rw, p.N - 1) - n0) * (int)p.ldw_b + (((lane & 7) ^ ((rw >> 1) & 7)) << 4);
+        }
+    const int rowA = 8 * wave, rowW = 64 * (wave >> 2) + 8 * (wave & 3);  // wave-uniform first rows of the pieces (+ 128 s + 64 x / 32 y)
+    auto stage_a = [&](int h, int kt, int buf) {
+        char* base = smem + buf * (2 * LTILE) + LTILE + (64 * h + rowA) * ROWB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(base), 16, oA[h][0], kt * ROWB, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(base + 128 * ROWB), 16, oA[h][1], kt * ROWB, 0, 0);
+    };
+    auto stage_w = [&](int h, int kt, int buf) {
+        char* base = smem + buf * (2 * LTILE) + (32 * h + rowW) * ROWB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)(base), 16, oW[h][0], kt * ROWB, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)(base + 128 * ROWB), 16, oW[h][1], kt * ROWB, 0, 0);
+    };
+
+    f32x4 acc[4][8];  // [n tile i][m tile j]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15;
+    const int fsw = (lane >> 1) & 7;
+    const int fq = lane >> 4;
+    const int c0 = (fq ^ fsw) << 4, c1 = ((fq + 4) ^ fsw) << 4;
+    const int nk = p.K * (int)sizeof(T) / ROWB;  // even (dispatcher)
+    const char* wfrag = smem + (wn * 64 + frow) * ROWB;
+    const char* afrag = smem + LTILE + (wm * 128 + frow) * ROWB;
+    Frag fa[4][2], fb0[2][2], fb1[2][2];
+    auto read_a = [&](int x, int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const char* r = afrag + buf * (2 * LTILE) + (64 * x + 16 * j) * ROWB;
+            fa[j][0] = *reinterpret_cast<const Frag*>(r + c0);
+            fa[j][1] = *reinterpret_cast<const Frag*>(r + c1);
+        }
+    };
+    auto read_b = [&](Frag (&fb)[2][2], int y, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const char* r = wfrag + buf * (2 * LTILE) + (32 * y + 16 * i) * ROWB;
+            fb[i][0] = *reinterpret_cast<const Frag*>(r + c0);
+            fb[i][1] = *reinterpret_cast<const Frag*>(r + c1);
+        }
+    };
+#define WIPA_QUADRANT(X, Y, FB)                                                                  \
+    do {                                                                                         \
+        __builtin_amdgcn_s_barrier();                                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        __builtin_amdgcn_s_setprio(1);                                                           \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                         \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                        \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                    \
+                    Mma<T>::run(FB[i][kk], fa[j][kk], acc[2 * (Y) + i][4 * (X) + j]);            \
+        __builtin_amdgcn_s_setprio(0);                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        __builtin_amdgcn_s_barrier();                                                            \
+    } while (0)
+#define WIPA_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+    // one K-tile kt in buffer BUF.  MODE 0: steady state (all four prefetches, four half-tiles stay in flight);
+    // MODE 1: tile nk-2 (prefetches of tile nk-1 only); MODE 2: tile nk-1 (nothing left to prefetch)
+#define WIPA_KTILE(BUF, MODE, KT)                                                                \
+    do {                                                                                         \
+        read_b(fb0, 0, BUF);                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        read_a(0, BUF);                                                                          \
+        if ((MODE) < 2) stage_w(1, (KT) + 1, (BUF) ^ 1);                                         \
+        if ((MODE) < 2) WIPA_VMCNT(8); else WIPA_VMCNT(2);                                       \
+        WIPA_QUADRANT(0, 0, fb0);                                                                \
+        read_b(fb1, 1, BUF);                                                                     \
+        if ((MODE) < 2) stage_a(1, (KT) + 1, (BUF) ^ 1);                                         \
+        if ((MODE) < 2) WIPA_VMCNT(8); else WIPA_VMCNT(0);                                       \
+        WIPA_QUADRANT(0, 1, fb1);                                                                \
+        read_a(1, BUF);                                                                          \
+        if ((MODE) == 0) stage_a(0, (KT) + 2, BUF);                                              \
+        if ((MODE) == 0) WIPA_VMCNT(8); else if ((MODE) == 1) WIPA_VMCNT(6);                     \
+        WIPA_QUADRANT(1, 1, fb1);                                                                \
+        if ((MODE) == 0) stage_w(0, (KT) + 2, BUF);                                              \
+        if ((MODE) == 0) WIPA_VMCNT(8); else if ((MODE) == 1) WIPA_VMCNT(4);                     \
+        WIPA_QUADRANT(1, 0, fb0);                                                                \
+    } while (0)
+
+    // prologue: the six half-tiles the steady state would have issued before tile 0, in its order
+    stage_a(0, 0, 0);
+    stage_w(0, 0, 0);
+    stage_w(1, 0, 0);
+    stage_a(1, 0, 0);
+    stage_a(0, 1, 1);
+    stage_w(0, 1, 1);
+    WIPA_VMCNT(8);  // A half 0 and W half 0 of tile 0 have landed
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();  // wave row 1 runs one barrier behind wave row 0
+    int kt = 0;
+    for (; kt + 3 < nk; kt += 2) {
+        WIPA_KTILE(0, 0, kt);
+        WIPA_KTILE(1, 0, kt + 1);
+    }
+    WIPA_KTILE(0, 1, kt);
+    WIPA_KTILE(1, 2, kt + 1);
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+#undef WIPA_KTILE
+#undef WIPA_QUADRANT
+#undef WIPA_VMCNT
+    __syncthreads();  // every LDS read has retired: the epilogue reuses the buffers as per-wave scratch
+
+    const bool vec = p.vec_ok != 0;
+    int64_t coff_dev = p.c_offset;
+    if (p.c_offset_dev) coff_dev += *p.c_offset_dev;
+    if (p.stage_ok) {
+        epilogue_staged<OutT, 8>(p, acc, smem + wave * 4096, m0 + wm * 128, n0 + wn * 64, coff_dev, lane);
+        return;
+    }
+    EpiCol cols[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cols[i] = epi_col(p, n0 + wn * 64 + 16 * i + 4 * fq);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const EpiRow row = epi_row(p, m0 + wm * 128 + 16 * j + frow, coff_dev);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) epilogue4<OutT>(p, acc[i][j], row, cols[i], vec);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // 384 (M) x 256 (N) tile (WIPA_GEMM_TILE=384 forces it, =256 forbids it), 8 waves (2 x 4), 192 x 64 per wave = 4 x 12 MFMA tiles
 // (192 accumulator registers).  Stages (256 + 384) x 128 B = 80 KiB per K-step: 1/153.6 byte per FLOP instead of 1/128, and
 // N = 768 gives 750 tiles = 2.93 rounds instead of 4.39.  LDS 2 x 80 KiB = all of it.
@@ -1254,6 +1431,15 @@ int launch384n(GemmParams p, hipStream_t s) {
     return WIPA_OK;
 }
 
+template <typename OutT>
+int launch256p(GemmParams p, hipStream_t s) {
+    p.tiles_m = (p.M + LBM - 1) / LBM;
+    p.tiles_n = (p.N + LBN - 1) / LBN;
+    hipLaunchKernelGGL((gemm_nt256p_kernel<OutT>), dim3(p.tiles_m * p.tiles_n), dim3(512), LSMEM, s, p);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
 template <typename T, typename OutT>
 int launch256(GemmParams p, hipStream_t s) {
     p.tiles_m = (p.M + LBM - 1) / LBM;
@@ -1279,6 +1465,12 @@ int init_attrs() {
                               reinterpret_cast<const void*>(&gemm_nt_kernel<float, float>)};
         for (const void* f : fns) {
             const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+            if (e != hipSuccess) err = e;
+        }
+        const void* phased[2] = {reinterpret_cast<const void*>(&gemm_nt256p_kernel<__bf16>),
+                                 reinterpret_cast<const void*>(&gemm_nt256p_kernel<float>)};
+        for (const void* f : phased) {
+            const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LSMEM);
             if (e != hipSuccess) err = e;
         }
         const void* big[6] = {reinterpret_cast<const void*>(&gemm_nt256_kernel<__bf16, __bf16, false>),
@@ -1480,6 +1672,8 @@ extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
         const double e384n = fill(tm384 * ((d->N + 127) / 128));
         if (e384n >= (d->in_dtype == WIPA_F32 ? 1.10 : 1.25) * (e384 > e256 ? e384 : e256)) use384 = narrow = true;
     }
+    if (big && force_tile == 2568 && d->in_dtype == WIPA_BF16 && d->K % 128 == 0)  // phase-interleaved 256 x 256 (A/B runs)
+        return d->out_dtype == WIPA_BF16 ? launch256p<__bf16>(p, s) : launch256p<float>(p, s);
     if (big && use384) {
         if (narrow) {
             if (d->in_dtype == WIPA_BF16)
