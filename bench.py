@@ -645,7 +645,8 @@ def measure_train(args, rank, world, dist, steps, warmup):
             "roofline": {"kernel": "f32 GEMM set of the step (decoder fwd/dgrad/wgrad + cross-K/V + encoder)", "bound": "mfma",
                          "achieved": round((dec + ckv + enc) / (ms * 1e-3) / 1e12, 1), "peak": f32_peak, "unit": "TFLOP/s",
                          "frac": round((dec + ckv + enc) / (ms * 1e-3) / 1e12 / f32_peak, 4), "traffic": None,
-                         "note": "whole-step FLOPs / whole-step time (includes attention backward, CE, optimiser); f32 MFMA peak"},
+                         "note": "whole-step FLOPs / whole-step time (includes attention backward, CE, optimiser); f32 MFMA peak"
+                                 + ("; --f32 split multiplies on the bf16 MFMA, so this fraction of the F32 peak can exceed 1" if args.f32 == "split" else "")},
             "allreduce_exposed_ms_per_step": round(exposed / steps, 3) if world > 1 else 0.0,
             "grad_bytes": tr.n_params * 4,
         }
@@ -654,6 +655,7 @@ def measure_train(args, rank, world, dist, steps, warmup):
 
 
 def main():
+    global DECODE_SPLIT, ENCODER_CUS, NEW_TOKENS
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
@@ -671,6 +673,8 @@ def main():
                     help="log-mel + encoder of every pass on a HIP stream limited to this many CUs (multiple of 8), the decode loop "
                          "on an unrestricted one: the decode loops of the other passes in flight keep the remaining CUs")
     ap.add_argument("--decoder-cus", type=int, default=None, help="EXPERIMENT: limit the decode streams to this many CUs")
+    ap.add_argument("--new-tokens", type=int, default=NEW_TOKENS,
+                    help="decode positions per clip: 64 is the benchmark setting (SURVEY.md 8d), 224 the reference's cap (secondary)")
     ap.add_argument("--decode-group", type=int, default=1,
                     help="EXPERIMENT: decode this many consecutive 64-clip batches together (encoder still per batch)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"],
@@ -688,8 +692,7 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
-    global DECODE_SPLIT, ENCODER_CUS
-    DECODE_SPLIT, ENCODER_CUS = args.decode_split, args.encoder_cus
+    DECODE_SPLIT, ENCODER_CUS, NEW_TOKENS = args.decode_split, args.encoder_cus, args.new_tokens
     torch.set_num_threads(host_cores())
     if args.mode == "train":
         return run_train(args)
