@@ -146,8 +146,11 @@ int wipa_embed_tokens(const int32_t* tokens, int64_t ld_tok, int B, int T, int t
 /* ------------------------------------------------------------------ attention
  * MultiHeadAttention.qkv_attention with head_dim 64; q and k arrive already
  * scaled by 64**-0.25 (GEMM epilogue col_scale), softmax in f32.
- * generic kernel (f32 math): encoder self-attn in f32, decoder causal self-attn,
- * teacher-forced cross-attn.  Element (b, t, h, d) of X is at
+ * decoder causal self-attention and teacher-forced cross-attention (mlx_whisper
+ * TextDecoder blocks behind scripts/train_whisper_ipa.py:232), any Tq / Tk.  float32 with
+ * Tq >= 16 and no device-side offsets runs on the f32 MFMA (exact f32 products, 64 queries
+ * per workgroup); the few-row prompt prefill and bf16 use the f32-math VALU kernel.
+ * Element (b, t, h, d) of X is at
  *   X + b*x_bs + t*x_rs + h*x_hs + d.
  * Tk = (tk_dev ? *tk_dev : 0) + Tk;  causal: query i sees keys <= i + (Tk - Tq). */
 typedef struct wipa_attn_desc {

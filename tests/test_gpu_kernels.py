@@ -580,15 +580,16 @@ def test_cu_limited_stream_runs_the_same_gemm(ops):
     assert _lib.lib().wipa_stream_create_cu_limited(100000, C.byref(raw)) == -1
 
 
+@pytest.mark.parametrize("N", [768, 700])
 @pytest.mark.parametrize("dtype,act,with_res", [(torch.float32, 0, True), (torch.float32, 1, False), (torch.bfloat16, 0, True),
                                                 (torch.bfloat16, 1, False)])
-def test_gemm_384x128_tiles_on_a_badly_quantised_grid(ops, dtype, act, with_res, f32_mode):
+def test_gemm_384x128_tiles_on_a_badly_quantised_grid(ops, dtype, act, with_res, f32_mode, N):
     """48 000 x 768 (32 clips of encoder rows, as in a fine-tune batch) is 375 tiles of 384 x 256 -- 1.46 rounds on 256 CUs --
     so the dispatcher takes 384 x 128 tiles; checked on the whole matrix, ragged last row tile included (M = 47 990)."""
     if dtype == torch.bfloat16 and f32_mode == "split":
         pytest.skip("one bf16 run is enough")
     g = torch.Generator().manual_seed(11)
-    M, N, K = 47990, 768, 128
+    M, K = 47990, 128  # N = 700: a ragged last column tile (6 tiles of 128, the last 60 wide)
     A = torch.randn(M, K, generator=g).to(dtype)
     W = (torch.randn(N, K, generator=g) * 0.1).to(dtype)
     bias = torch.randn(N, generator=g)

@@ -9,11 +9,6 @@ out=gpurun_out/r02_cu_sweep.txt; : > $out
 run() { echo "## WIPA_BENCH_ENC_STREAMS=$WIPA_BENCH_ENC_STREAMS $*" >> $out; python bench.py --no-cpu-baseline --no-finetune --steps 12 --warmup 1 "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d['ms_per_pass_single_in_flight'])" >> $out; }
 export WIPA_BENCH_ENC_STREAMS=3
 run
-run --encoder-cus 256
-run --encoder-cus 224
-run --encoder-cus 160
-run --encoder-cus 128
+for n in 256 248 240 232 224 192 160 128; do run --encoder-cus $n; done
 run --encoder-cus 192 --pipeline 3
-run --encoder-cus 128 --pipeline 3
-run --encoder-cus 192 --pipeline 6
 cat $out
