@@ -736,23 +736,24 @@ def main():
     # --pipeline P > 1: pass i runs on stream set (i % P) and is only collected when its stream set is needed
     # again, so the encoder of pass i+1 can overlap the decode loop of pass i (each pass still does all its work
     # inside the timed region; every pass owns separate workspaces / KV caches)
-    inflight = []
+    inflight, collected = [], []  # collected: every pass's ids (host arrays), compared after the timed region
     if args.decode_group > 1:
         i, gi = 0, 0
         while i < args.steps:
             g = min(args.decode_group, args.steps - i)
             if len(inflight) == args.pipeline:
-                tokens = pass_collect(inflight.pop(0))
+                collected.append(pass_collect(inflight.pop(0)))
             inflight.append(group_launch(model, audio_chunks[0], setup, gi % args.pipeline, g))
             i += g
             gi += 1
     else:
         for i in range(args.steps):
             if len(inflight) == args.pipeline:
-                tokens = pass_collect(inflight.pop(0))
+                collected.append(pass_collect(inflight.pop(0)))
             inflight.append(pass_launch(model, audio_chunks, setup, (i % args.pipeline) * args.streams))
     while inflight:
-        tokens = pass_collect(inflight.pop(0))
+        collected.append(pass_collect(inflight.pop(0)))
+    tokens = collected[-1]
     timed_barrier(dist)
     elapsed = max_over_ranks(dist, time.perf_counter() - t0)
 
@@ -780,6 +781,8 @@ def main():
                        "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "parallelism": f"dp{world} (clip sharding, no collective)"},
             "tokens_checksum": int(tokens.sum() % 1000003),
+            # every timed pass transcribes the same clips: identical ids in all of them (a race in a kernel would show here)
+            "passes_identical": bool(all(t.shape == collected[0].shape and (t == collected[0]).all() for t in collected)),
         }
         log(f"timed region done: {elapsed:.3f} s for {args.steps} passes")
         # ---- everything below is OUTSIDE the timed region, one pass in flight
@@ -788,6 +791,7 @@ def main():
         single = one_pass(model, audio_chunks, setup)
         out["ms_per_pass_single_in_flight"] = round((time.perf_counter() - t1) * 1e3, 2)
         assert args.decode_group > 1 or (single == tokens).all(), "the pipelined and the single pass disagree on the ids"
+        assert args.decode_group > 1 or out["passes_identical"], "timed passes over the same clips produced different ids"
         if args.decode_split == 1:
             out["roofline"] = roofline_cross_attn(model, audio_chunks[0].shape[0])
         if args.streams == 1 and args.decode_split == 1:

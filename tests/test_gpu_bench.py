@@ -32,7 +32,7 @@ CONTRACT = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 def test_bench_single_rank_contract_and_rooflines():
     out = _run(["--steps", "3", "--warmup", "1", "--model", "tiny", "--batch", "8", "--pipeline", "2"])
     assert CONTRACT <= set(out)
-    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["unit"] == "audio-s/s" and out["value"] > 0
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["unit"] == "audio-s/s" and out["value"] > 0 and out["passes_identical"] is True
     assert abs(out["value"] - 8 * 30.0 * 3 / (out["ms_per_step"] * 3e-3)) / out["value"] < 0.02
     assert "workload" in out["config"] and "model" not in out["config"]
     for key in ("roofline", "roofline_mfma", "decode_step"):
