@@ -92,6 +92,16 @@ def test_load_audio_wav_and_resample(tmp_path):
     assert np.abs(b[mid] - a[: len(b)][mid]).max() < 2e-2  # same 440 Hz tone after 8k -> 16k
     assert pad_or_trim(a).shape == (480000,) and pad_or_trim(np.zeros(500000, np.float32)).shape == (480000,)
     assert pad_or_trim(torch.zeros(2, 10), 16).shape == (2, 16)
+    # 44.1 kHz -> 16 kHz (up 160 / down 441) in bounded time, tone kept, a 10 kHz component (above the new Nyquist) removed
+    t44 = np.arange(3 * 44100) / 44100.0
+    x44 = 0.5 * np.sin(2 * np.pi * 440 * t44) + 0.25 * np.sin(2 * np.pi * 10000 * t44)
+    _write_wav(tmp_path / "c.wav", (x44 * 32767).astype("<i2").tobytes(), 44100)
+    import time
+    t0 = time.perf_counter()
+    c = load_audio(str(tmp_path / "c.wav"))
+    assert time.perf_counter() - t0 < 10.0 and abs(len(c) - 48000) <= 1
+    ref = 0.5 * np.sin(2 * np.pi * 440 * np.arange(len(c)) / 16000.0)
+    assert np.abs(c[2000:-2000] - ref[2000:-2000]).max() < 5e-3
 
 
 def test_hf_key_conversion_roundtrip():

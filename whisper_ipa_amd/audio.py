@@ -48,19 +48,30 @@ def load_audio(file: str, sr: int = SAMPLE_RATE) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
-def _resample(a: np.ndarray, src: int, dst: int) -> np.ndarray:
-    """Windowed-sinc polyphase resampling (host side, numpy)."""
-    from math import gcd
-
-    g = gcd(src, dst)
-    up, down = dst // g, src // g
-    half = 16 * max(up, down)
-    t = np.arange(-half, half + 1, dtype=np.float64)
-    cutoff = 1.0 / max(up, down)
-    h = cutoff * np.sinc(cutoff * t) * np.hanning(2 * half + 1) * up
-    z = np.zeros(len(a) * up, dtype=np.float64)
-    z[::up] = a
-    y = np.convolve(z, h, mode="same")[::down]
+def _resample(a: np.ndarray, src: int, dst: int, zero_crossings: int = 16) -> np.ndarray:
+    """Windowed-sinc (Hann, ``zero_crossings`` lobes each side) resampling, evaluated per OUTPUT sample -- the polyphase
+    form: output m sits at input position m*src/dst and sums the 2*zero_crossings/cutoff input samples around it, so the work
+    is n_out x taps whatever the ratio (44.1 kHz -> 16 kHz is up 160 / down 441: the zero-stuffed form would convolve
+    211 M samples with a 14 k-tap filter).  Host side, numpy, chunked to bound memory."""
+    n_in = len(a)
+    n_out = int(np.ceil(n_in * dst / src))
+    if n_in == 0 or n_out == 0:
+        return np.zeros(0, dtype=np.float32)
+    cutoff = min(1.0, dst / src)              # of the input Nyquist: low-pass at the lower of the two rates
+    half = zero_crossings / cutoff            # filter half-width in input samples
+    k = np.arange(-int(np.ceil(half)), int(np.ceil(half)) + 1)
+    x = np.asarray(a, dtype=np.float64)
+    y = np.empty(n_out, dtype=np.float64)
+    step = max(1, (1 << 22) // len(k))        # ~32 MB of float64 per chunk
+    for m0 in range(0, n_out, step):
+        m = np.arange(m0, min(m0 + step, n_out))
+        pos = m * (src / dst)
+        base = np.floor(pos).astype(np.int64)
+        idx = base[:, None] + k[None, :]
+        dt = pos[:, None] - idx                # distance of every tap from the output position, in input samples
+        w = cutoff * np.sinc(cutoff * dt) * (0.5 + 0.5 * np.cos(np.pi * np.clip(dt / half, -1.0, 1.0)))
+        ok = (idx >= 0) & (idx < n_in)
+        y[m] = (w * np.where(ok, x[np.clip(idx, 0, n_in - 1)], 0.0)).sum(axis=1)
     return y.astype(np.float32)
 
 
