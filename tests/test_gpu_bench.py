@@ -42,6 +42,18 @@ def test_bench_single_rank_contract_and_rooflines():
     assert out["decode_step"]["bytes_per_step"] > out["decode_step"]["cross_kv_bytes"] > 0
 
 
+def test_bench_experiment_flags_keep_the_ids():
+    """--encoder-cus (log-mel + encoder on a CU-limited stream, decode on the pass's own stream) and --new-tokens change the
+    schedule / the length, not the transcription: same checksum as the plain run at equal length."""
+    base = ["--steps", "2", "--warmup", "1", "--model", "tiny", "--batch", "8", "--pipeline", "2", "--no-cpu-baseline"]
+    plain = _run(base)
+    limited = _run(base + ["--encoder-cus", "64"])
+    assert limited["config"]["encoder_cus"] == 64 and limited["passes_identical"]
+    assert limited["tokens_checksum"] == plain["tokens_checksum"]
+    longer = _run(base + ["--new-tokens", "100"])
+    assert longer["config"]["new_tokens"] == 100 and longer["passes_identical"]
+
+
 def test_bench_gpus_2_launches_two_ranks():
     """`python bench.py --gpus 2` (no launcher, no WORLD_SIZE): the parent starts two ranks and relays rank 0's line."""
     out = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--model", "tiny", "--batch", "8", "--pipeline", "2",

@@ -680,3 +680,31 @@ print("OK", worst)
     env = dict(os.environ, WIPA_GEMM_TILE="2568", PYTHONPATH=root)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:] + r.stdout[-500:]
+
+
+@pytest.mark.parametrize("n,slices", [(2048 * 768, 3), (1000 * 77 + 3, 4), (5, 1)])
+def test_sum_slabs_ex_scale_and_residual(n, slices):
+    """wipa_sum_slabs_ex: out = scale * (slabs summed in slab order) + residual, residual aliasing out allowed, tails that
+    are not a multiple of 4; wipa_sum_slabs (accumulate / overwrite) on the same data."""
+    from whisper_ipa_amd import _lib
+    from whisper_ipa_amd.runtime import on_stream, ptr, sptr
+
+    g = torch.Generator().manual_seed(n % 1000 + slices)
+    stride = (n + 3) // 4 * 4
+    slabs = torch.randn(slices, stride, generator=g).cuda()
+    res = torch.randn(n, generator=g).cuda()
+    ref = slabs[0, :n].clone()
+    for k in range(1, slices):
+        ref += slabs[k, :n]  # the kernel's order: 0, 1, 2, ... in float32
+    L = _lib.lib()
+    with on_stream() as s:
+        out = torch.full((n,), 7.0, device="cuda")
+        _lib.check(L.wipa_sum_slabs_ex(ptr(slabs), slices, stride, ptr(out), n, None, 0.5, sptr(s)), "wipa_sum_slabs_ex")
+        acc = res.clone()
+        _lib.check(L.wipa_sum_slabs_ex(ptr(slabs), slices, stride, ptr(acc), n, ptr(acc), 1.0, sptr(s)), "wipa_sum_slabs_ex")
+        plain = torch.full((n,), 7.0, device="cuda")
+        _lib.check(L.wipa_sum_slabs(ptr(slabs), slices, stride, ptr(plain), n, 0, sptr(s)), "wipa_sum_slabs")
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref * 0.5)
+    assert torch.equal(acc, res + ref)
+    assert torch.equal(plain, ref)
