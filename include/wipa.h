@@ -120,6 +120,12 @@ typedef struct wipa_gemm_desc {
     int32_t stream_weights; /* 1: the rows are decode rows (one or a few per clip) and W is a weight matrix: use the
                              * weight-streaming kernel up to M = 1024 instead of 256, so that a prompt prefill of
                              * 4 rows per clip rounds exactly like the single-row steps (batch invariance) */
+    /* K-major operands (float32 in and out, 128x128 tile kernel, k_slices allowed): a_trans: A is stored [K][M] (lda =
+     * elements per k-row, M a multiple of 4); w_trans: W is stored [K][N] (ldw likewise, N a multiple of 4).  The staging
+     * pass transposes into LDS, so the backward pass of a linear layer multiplies by W^T (input gradient) and by dy^T, x^T
+     * (weight gradient) without a transposed copy: nn.value_and_grad at scripts/train_whisper_ipa.py:284. */
+    int32_t a_trans;
+    int32_t w_trans;
 } wipa_gemm_desc;
 int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t s);
 

@@ -708,3 +708,29 @@ def test_sum_slabs_ex_scale_and_residual(n, slices):
     assert torch.equal(out, ref * 0.5)
     assert torch.equal(acc, res + ref)
     assert torch.equal(plain, ref)
+
+
+@pytest.mark.parametrize("a_trans,w_trans", [(True, True), (True, False), (False, True)])
+@pytest.mark.parametrize("M,N,K,slices", [(768, 768, 2048, 1), (300, 132, 96, 1), (1536, 768, 4096, 7), (2048, 3072, 768, 1)])
+def test_gemm_k_major_operands(ops, a_trans, w_trans, M, N, K, slices, f32_mode):
+    """float32 GEMM with A stored [K, M] and / or W stored [K, N] (what a linear layer's backward has: dy^T, x^T, W^T) ==
+    the same product on explicitly transposed copies, bit for bit, and within f32 round-off of an fp64 reference."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).cuda()
+    W = (torch.randn(N, K, generator=g) * 0.1).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    At, Wt = A.t().contiguous(), W.t().contiguous()  # [K, M], [K, N]
+    kw = dict(M=M, N=N, K=K, ldc=N, bias=bias, f32_split=(f32_mode == "split"))
+    if slices > 1:
+        kw.update(k_slices=slices, slab_stride=M * N)
+    shape = (slices, M, N) if slices > 1 else (M, N)
+    ref = torch.empty(shape, device="cuda")
+    ops.gemm(A, W, ref, lda=K, ldw=K, **kw)
+    out = torch.full(shape, 7.0, device="cuda")
+    ops.gemm(At if a_trans else A, Wt if w_trans else W, out, lda=(M if a_trans else K), ldw=(N if w_trans else K),
+             a_trans=a_trans, w_trans=w_trans, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)  # same LDS image, same MFMA order
+    full = out.sum(0) if slices > 1 else out
+    exact = A.double() @ W.double().T + bias.double()
+    assert _rel(full, exact) < (4e-6 if f32_mode == "exact" else 2e-5)  # contractions of up to 4096 terms

@@ -34,7 +34,7 @@ class GemmDesc(C.Structure):
         ("f32_split", C.c_int32),
         ("w_scale", c_void_p), ("w_dtype", C.c_int32),
         ("ln_x", c_void_p), ("ln_w", c_void_p), ("ln_b", c_void_p), ("ln_ldx", c_int64), ("ln_eps", c_float),
-        ("stream_weights", C.c_int32),
+        ("stream_weights", C.c_int32), ("a_trans", C.c_int32), ("w_trans", C.c_int32),
     ]
 
 

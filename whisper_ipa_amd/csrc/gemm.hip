@@ -43,6 +43,7 @@ struct GemmParams {
     int stage_ok;  // epilogue_staged may be used (16-byte row-major stores are legal for this output mapping)
     int k_slices;
     int64_t slab_stride;
+    int a_trans = 0, w_trans = 0;    // operand given K-major ([K][rows], lda_b / ldw_b = bytes per k-row): 128x128 f32 kernel only
     const float* w_scale = nullptr;  // fp8 (e4m3) weights: per-output-column dequantisation scale
     // LayerNorm prologue (weight-streaming kernel only): A = LayerNorm(ln_x) computed in the kernel
     const float* ln_x = nullptr;
@@ -315,8 +316,12 @@ constexpr int BM = 128, BN = 128, ROWB = 128;  // ROWB: bytes of K per LDS row
 constexpr int TILE_BYTES = BM * ROWB;          // 16 KiB per operand tile
 constexpr int GROUP_M = 8;
 
-template <typename T, typename OutT>
+// TA / TW (float32 only): the operand arrives K-major -- A as [K][M], W as [K][N] -- and is transposed by the staging pass
+// (16-byte loads along the rows of one k, four 4-byte LDS writes into the usual [row][k] image), so a backward pass can
+// multiply by x^T, dy^T or W^T without a transpose kernel and a second copy in HBM.
+template <typename T, typename OutT, bool TA = false, bool TW = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
+    static_assert(!(TA || TW) || sizeof(T) == 4, "K-major operands: float32 only");
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][W tile | A tile]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -355,21 +360,46 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams p) {
         gW[i] = p.W + (int64_t)n * p.ldw_b + schunk * 16;
         lds_off[i] = row * ROWB + ((schunk ^ ((row >> 1) & 7)) << 4);
     }
+    // K-major operand: thread (k = tid >> 3 of the step's 32, vector v = (tid & 7) + 8 i) loads rows 4v .. 4v+3 of that k
+    const int tk = tid >> 3;
+    const char* tA[4];
+    const char* tW[4];
+    int t_off[4];  // LDS offset of (row 4v, k): row e adds e*ROWB and its own chunk swizzle
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 4 * ((tid & 7) + 8 * i);
+        if constexpr (TA) tA[i] = p.A + (int64_t)tk * p.lda_b + (int64_t)min(m0 + r, p.M - 4) * 4;
+        if constexpr (TW) tW[i] = p.W + (int64_t)tk * p.ldw_b + (int64_t)min(n0 + r, p.N - 4) * 4;
+        t_off[i] = r * ROWB + (tk & 3) * 4;
+    }
     f32x4 ra[4], rw[4];
     auto gload = [&](int kt) {
         const int64_t kb = (int64_t)kt * ROWB;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            rw[i] = *reinterpret_cast<const f32x4*>(gW[i] + kb);
-            ra[i] = *reinterpret_cast<const f32x4*>(gA[i] + kb);
+            if constexpr (TW) rw[i] = *reinterpret_cast<const f32x4*>(tW[i] + (int64_t)kt * 32 * p.ldw_b);
+            else rw[i] = *reinterpret_cast<const f32x4*>(gW[i] + kb);
+            if constexpr (TA) ra[i] = *reinterpret_cast<const f32x4*>(tA[i] + (int64_t)kt * 32 * p.lda_b);
+            else ra[i] = *reinterpret_cast<const f32x4*>(gA[i] + kb);
         }
+    };
+    auto swrite_t = [&](char* tile, const f32x4 (&v)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = 4 * ((tid & 7) + 8 * i) + e;
+                *reinterpret_cast<float*>(tile + t_off[i] + e * ROWB + (((tk >> 2) ^ ((row >> 1) & 7)) << 4)) = v[i][e];
+            }
     };
     auto swrite = [&](int buf) {
         char* base = smem + buf * (2 * TILE_BYTES);
+        if constexpr (TW) swrite_t(base, rw);
+        if constexpr (TA) swrite_t(base + TILE_BYTES, ra);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(base + lds_off[i]) = rw[i];
-            *reinterpret_cast<f32x4*>(base + TILE_BYTES + lds_off[i]) = ra[i];
+            if constexpr (!TW) *reinterpret_cast<f32x4*>(base + lds_off[i]) = rw[i];
+            if constexpr (!TA) *reinterpret_cast<f32x4*>(base + TILE_BYTES + lds_off[i]) = ra[i];
         }
     };
 
@@ -1459,10 +1489,13 @@ int init_attrs() {
     static std::once_flag once;
     static hipError_t err = hipSuccess;
     std::call_once(once, [] {
-        const void* fns[4] = {reinterpret_cast<const void*>(&gemm_nt_kernel<__bf16, __bf16>),
+        const void* fns[7] = {reinterpret_cast<const void*>(&gemm_nt_kernel<__bf16, __bf16>),
                               reinterpret_cast<const void*>(&gemm_nt_kernel<__bf16, float>),
                               reinterpret_cast<const void*>(&gemm_nt_kernel<float, __bf16>),
-                              reinterpret_cast<const void*>(&gemm_nt_kernel<float, float>)};
+                              reinterpret_cast<const void*>(&gemm_nt_kernel<float, float>),
+                              reinterpret_cast<const void*>(&gemm_nt_kernel<float, float, true, true>),
+                              reinterpret_cast<const void*>(&gemm_nt_kernel<float, float, true, false>),
+                              reinterpret_cast<const void*>(&gemm_nt_kernel<float, float, false, true>)};
         for (const void* f : fns) {
             const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
             if (e != hipSuccess) err = e;
@@ -1532,6 +1565,15 @@ int init_attrs() {
 template <typename T, typename OutT>
 int launch(const GemmParams& p, hipStream_t s) {
     hipLaunchKernelGGL((gemm_nt_kernel<T, OutT>), dim3(p.tiles_m * p.tiles_n, p.k_slices), dim3(256), SMEM_BYTES, s, p);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+int launch_kmajor(const GemmParams& p, hipStream_t s) {  // float32 -> float32 with K-major A and / or W
+    const dim3 grid(p.tiles_m * p.tiles_n, p.k_slices);
+    if (p.a_trans && p.w_trans) hipLaunchKernelGGL((gemm_nt_kernel<float, float, true, true>), grid, dim3(256), SMEM_BYTES, s, p);
+    else if (p.a_trans) hipLaunchKernelGGL((gemm_nt_kernel<float, float, true, false>), grid, dim3(256), SMEM_BYTES, s, p);
+    else hipLaunchKernelGGL((gemm_nt_kernel<float, float, false, true>), grid, dim3(256), SMEM_BYTES, s, p);
     WIPA_LAUNCH_CHECK();
     return WIPA_OK;
 }
@@ -1616,6 +1658,15 @@ extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
     {
         const int rc = init_attrs();
         if (rc != WIPA_OK) return rc;
+    }
+    if (d->a_trans || d->w_trans) {
+        WIPA_REQUIRE(d->in_dtype == WIPA_F32 && d->out_dtype == WIPA_F32 && d->w_dtype == 0 && !d->ln_x,
+                     "wipa_gemm: K-major operands (a_trans / w_trans): float32 in and out only");
+        WIPA_REQUIRE((!d->a_trans || (d->M % 4 == 0 && d->M >= 4)) && (!d->w_trans || (d->N % 4 == 0 && d->N >= 4)),
+                     "wipa_gemm: a K-major operand needs a row count that is a multiple of 4 (M=%d N=%d)", d->M, d->N);
+        p.a_trans = d->a_trans ? 1 : 0;
+        p.w_trans = d->w_trans ? 1 : 0;
+        return launch_kmajor(p, s);
     }
     if (d->w_dtype == WIPA_FP8_E4M3)
         return d->out_dtype == WIPA_BF16 ? launch_skinny_w8<__bf16>(p, s) : launch_skinny_w8<float>(p, s);

@@ -17,9 +17,11 @@ def gemm(A: torch.Tensor, W: torch.Tensor, C_out: torch.Tensor, *, M: int, N: in
          residual: Optional[torch.Tensor] = None, pos: Optional[torch.Tensor] = None, ldpos: int = 0,
          col_scale_n: int = 0, col_scale: float = 1.0, rg_in: int = 0, rg_valid: int = 0, rg_stride: int = 0,
          cg_in: int = 0, cg_stride: int = 0, c_offset: int = 0, c_offset_dev: Optional[torch.Tensor] = None,
-         zero_invalid_rows: bool = False, k_slices: int = 0, slab_stride: int = 0, f32_split: bool = False) -> torch.Tensor:
+         zero_invalid_rows: bool = False, k_slices: int = 0, slab_stride: int = 0, f32_split: bool = False,
+         a_trans: bool = False, w_trans: bool = False) -> torch.Tensor:
     """C = epilogue(A @ W^T); see wipa_gemm in include/wipa.h for the addressing rules.  ``f32_split``: float32 operands
-    multiplied as three bf16 MFMA terms (faster, ~5e-6 relative) instead of exact f32 products."""
+    multiplied as three bf16 MFMA terms (faster, ~5e-6 relative) instead of exact f32 products.  ``a_trans`` / ``w_trans``
+    (float32): the operand is stored K-major, [K, M] / [K, N], with lda / ldw its row length."""
     L = _lib.lib()
     d = _lib.GemmDesc()
     d.A, d.W, d.C = ptr(A), ptr(W), ptr(C_out)
@@ -34,6 +36,7 @@ def gemm(A: torch.Tensor, W: torch.Tensor, C_out: torch.Tensor, *, M: int, N: in
     d.col_scale_n, d.col_scale = col_scale_n, col_scale
     d.k_slices, d.slab_stride = k_slices, slab_stride
     d.f32_split = int(f32_split)
+    d.a_trans, d.w_trans = int(a_trans), int(w_trans)
     with on_stream() as s:
         _lib.check(L.wipa_gemm(C.byref(d), sptr(s)), "wipa_gemm")
     return C_out

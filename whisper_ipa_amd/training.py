@@ -113,7 +113,7 @@ class DecoderTrainer:
         out = torch.empty(x.shape[0], N, dtype=torch.float32, device=x.device) if out is None else out
         return self._mm(x, W, out, M, N, K, x.stride(0), W.stride(0), bias=bias, scale=scale, residual=residual)
 
-    def _mm(self, A, W, out, M, N, K, lda, ldw, bias=None, scale=None, residual=None):
+    def _mm(self, A, W, out, M, N, K, lda, ldw, bias=None, scale=None, residual=None, w_trans=False):
         """out[M,N] = (A[M,K] W[N,K]^T + bias) * scale (+ residual).  The decoder's GEMMs over the B*T token rows (2048 x 768)
         are 96 tiles of 128 x 128 -- a third of the chip -- so K is cut into slices computed by separate workgroups (slabs
         summed in a fixed order, then scale / residual: wipa_sum_slabs_ex) whenever the tile grid alone leaves CUs idle."""
@@ -125,13 +125,14 @@ class DecoderTrainer:
             need = slices * M * N
             if self._mm_slabs is None or self._mm_slabs.numel() < need:
                 self._mm_slabs = torch.empty(need, dtype=torch.float32, device=out.device)
-            self._gemm(A, W, self._mm_slabs, M=M, N=N, K=K, lda=lda, ldw=ldw, ldc=N, bias=bias, k_slices=slices, slab_stride=M * N)
+            self._gemm(A, W, self._mm_slabs, M=M, N=N, K=K, lda=lda, ldw=ldw, ldc=N, bias=bias, k_slices=slices, slab_stride=M * N,
+                       w_trans=w_trans)
             with on_stream() as s:
                 _lib.check(self.L.wipa_sum_slabs_ex(ptr(self._mm_slabs), slices, M * N, ptr(out), M * N, ptr(residual),
                                                     float(scale) if scale is not None else 1.0, sptr(s)), "wipa_sum_slabs_ex")
         else:
             self._gemm(A, W, out, M=M, N=N, K=K, lda=lda, ldw=ldw, ldc=out.stride(0), bias=bias, residual=residual,
-                       col_scale_n=(N if scale is not None else 0), col_scale=(scale or 1.0))
+                       col_scale_n=(N if scale is not None else 0), col_scale=(scale or 1.0), w_trans=w_trans)
         return out
 
     def _transpose(self, a, rows, cols, rows_pad):
@@ -147,15 +148,26 @@ class DecoderTrainer:
         dy [M(+pad), N], x [M, K]; xT = transpose(x) [K, Mp] may be passed to share it between linears."""
         Mp = _ceil(M, 32)
         out_dx = None
+        # wipa_gemm reads K-major operands (a_trans / w_trans): W as it is stored is the K-major form of W^T, dy and x as they
+        # are stored are the K-major forms of dy^T and x^T -- no transposed copies.  Needs whole 32-float K-steps and row
+        # counts that are multiples of 4; anything else takes the transposing path.
+        kmajor = M % 32 == 0 and N % 32 == 0 and K % 4 == 0 and W.stride(1) == 1 and dy.stride(1) == 1 and x.stride(1) == 1
         if need_dx:
-            Np = _ceil(N, 32)
-            WT = self._transpose(W, N, K, Np)  # [K, Np]
             out_dx = dx if dx is not None else torch.empty(dy.shape[0], K, dtype=torch.float32, device=dy.device)
-            # contraction over n: A = dy (row stride ld, first Np columns must be readable and zero beyond N)
-            self._mm(dy, WT, out_dx, M, K, Np, dy.stride(0), Np, residual=(out_dx if accumulate_dx else None))
-        dyT = self._transpose(dy, M, N, Mp)  # [N, Mp]
-        if xT is None:
-            xT = self._transpose(x, M, K, Mp)
+            if kmajor:
+                self._mm(dy, W, out_dx, M, K, N, dy.stride(0), W.stride(0), residual=(out_dx if accumulate_dx else None), w_trans=True)
+            else:
+                Np = _ceil(N, 32)
+                WT = self._transpose(W, N, K, Np)  # [K, Np]
+                # contraction over n: A = dy (row stride ld, first Np columns must be readable and zero beyond N)
+                self._mm(dy, WT, out_dx, M, K, Np, dy.stride(0), Np, residual=(out_dx if accumulate_dx else None))
+        if kmajor:
+            A_op, W_op, lda, ldw, Kc, flags = dy, x, dy.stride(0), x.stride(0), M, dict(a_trans=True, w_trans=True)
+        else:
+            dyT = self._transpose(dy, M, N, Mp)  # [N, Mp]
+            if xT is None:
+                xT = self._transpose(x, M, K, Mp)
+            A_op, W_op, lda, ldw, Kc, flags = dyT, xT, Mp, xT.stride(0), Mp, {}
         # weight gradient: small [N, K] output, contraction over all M tokens.  When the tile grid alone cannot fill the
         # chip (768 x 768 over 48 000 encoder positions is 36 tiles), K is split into slabs that are summed in order.
         tiles = ((N + 127) // 128) * ((K + 127) // 128)
@@ -164,11 +176,11 @@ class DecoderTrainer:
             need = slices * N * K
             if self._dw_slabs is None or self._dw_slabs.numel() < need:
                 self._dw_slabs = torch.empty(need, dtype=torch.float32, device=dy.device)
-            self._gemm(dyT, xT, self._dw_slabs, M=N, N=K, K=Mp, lda=Mp, ldw=xT.stride(0), ldc=K, k_slices=slices, slab_stride=N * K)
+            self._gemm(A_op, W_op, self._dw_slabs, M=N, N=K, K=Kc, lda=lda, ldw=ldw, ldc=K, k_slices=slices, slab_stride=N * K, **flags)
             with on_stream() as s:
                 _lib.check(self.L.wipa_sum_slabs(ptr(self._dw_slabs), slices, N * K, ptr(dW), N * K, 0, sptr(s)), "wipa_sum_slabs")
         else:
-            self._gemm(dyT, xT, dW, M=N, N=K, K=Mp, lda=Mp, ldw=xT.stride(0), ldc=dW.stride(0))
+            self._gemm(A_op, W_op, dW, M=N, N=K, K=Kc, lda=lda, ldw=ldw, ldc=dW.stride(0), **flags)
         if db is not None:
             self._colsum(dy, M, N, db)
         return out_dx
@@ -235,7 +247,8 @@ class DecoderTrainer:
             tok = tokens.to(device=dev, dtype=torch.int32).contiguous()
             tok_in = tok[:, :-1].contiguous()
             feats = audio_features.to(device=dev, dtype=torch.float32).contiguous().view(B * Ta, d)
-            featsT = self._transpose(feats, B * Ta, d, _ceil(B * Ta, 32))  # [d, ceil32(B*Ta)], shared by all layers
+            # [d, ceil32(B*Ta)], shared by all layers; not needed when the weight-gradient GEMM reads feats K-major
+            featsT = None if (B * Ta) % 32 == 0 else self._transpose(feats, B * Ta, d, _ceil(B * Ta, 32))
             x = torch.empty(M, d, dtype=torch.float32, device=dev)
             _lib.check(L.wipa_embed_tokens(ptr(tok_in), T, B, T, 0, None, ptr(P("decoder.token_embedding.weight")), 0, None,
                                            ptr(P("decoder.positional_embedding")), ptr(x), d, sptr(s)), "wipa_embed_tokens")
@@ -336,7 +349,7 @@ class DecoderTrainer:
                 dk = torch.empty(M, d, dtype=torch.float32, device=dev)
                 dv = torch.empty(M, d, dtype=torch.float32, device=dev)
                 self._attn_bwd(S["desc1"], S["a"], da, S["lse1"], dq, dk, dv)
-                h1T = self._transpose(S["h1"], M, d, Mp)
+                h1T = None if M % 32 == 0 else self._transpose(S["h1"], M, d, Mp)  # shared by the three projections
                 dh1 = self._lin_bwd(dq, M, d, S["h1"], h1T, d, P(f"{pre}.attn.query.weight"), G(f"{pre}.attn.query.weight"),
                                     G(f"{pre}.attn.query.bias"))
                 self._lin_bwd(dk, M, d, S["h1"], h1T, d, P(f"{pre}.attn.key.weight"), G(f"{pre}.attn.key.weight"), None, dx=dh1,
