@@ -15,6 +15,7 @@ it, and the per-tensor clip runs on the reduced gradients -- single-process sema
 """
 from __future__ import annotations
 
+
 import ctypes as C
 from typing import Dict, List, Optional, Tuple
 
@@ -118,7 +119,9 @@ class DecoderTrainer:
         are 96 tiles of 128 x 128 -- a third of the chip -- so K is cut into slices computed by separate workgroups (slabs
         summed in a fixed order, then scale / residual: wipa_sum_slabs_ex) whenever the tile grid alone leaves CUs idle."""
         tiles = ((M + 127) // 128) * ((N + 127) // 128)
-        slices = min(4 if K < 8192 else 8, 768 // max(tiles, 1), K // 256) if (M >= 512 and tiles < 192) else 1
+        # two workgroups of this kernel fit a CU: aim at (just under) 512 of them, at least four K-steps each.  Measured on the
+        # fine-tune step: 480 workgroups (5 slices of a 96-tile GEMM) 144.9 ms, 288 (3 slices) 147.1, 768 (8 slices) 148.1
+        slices = max(1, min(16, 512 // max(tiles, 1), K // 128)) if M >= 512 else 1
         plain = out.dim() == 2 and out.shape[0] == M and out.shape[1] == N and out.is_contiguous() and (
             residual is None or (residual.is_contiguous() and residual.shape == out.shape))
         if slices > 1 and plain:
