@@ -1516,7 +1516,7 @@ int init_attrs() {
             const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LSMEM);
             if (e != hipSuccess) err = e;
         }
-        const void* wide[24] = {reinterpret_cast<const void*>(&gemm_nt384_kernel<__bf16, __bf16, false, false>),
+        const void* wide[20] = {reinterpret_cast<const void*>(&gemm_nt384_kernel<__bf16, __bf16, false, false>),
                                 reinterpret_cast<const void*>(&gemm_nt384_kernel<__bf16, float, false, false>),
                                 reinterpret_cast<const void*>(&gemm_nt384_kernel<float, __bf16, false, false>),
                                 reinterpret_cast<const void*>(&gemm_nt384_kernel<float, float, false, false>),
@@ -1528,19 +1528,15 @@ int init_attrs() {
                                 reinterpret_cast<const void*>(&gemm_nt384_kernel<float, float, false, true>),
                                 reinterpret_cast<const void*>(&gemm_nt384_kernel<float, __bf16, true, true>),
                                 reinterpret_cast<const void*>(&gemm_nt384_kernel<float, float, true, true>),
-                                reinterpret_cast<const void*>(&gemm_nt384n_kernel<__bf16, __bf16, false, false>),
-                                reinterpret_cast<const void*>(&gemm_nt384n_kernel<__bf16, float, false, false>),
                                 reinterpret_cast<const void*>(&gemm_nt384n_kernel<float, __bf16, false, false>),
                                 reinterpret_cast<const void*>(&gemm_nt384n_kernel<float, float, false, false>),
-                                reinterpret_cast<const void*>(&gemm_nt384n_kernel<__bf16, __bf16, true, false>),
-                                reinterpret_cast<const void*>(&gemm_nt384n_kernel<__bf16, float, true, false>),
                                 reinterpret_cast<const void*>(&gemm_nt384n_kernel<float, __bf16, true, false>),
                                 reinterpret_cast<const void*>(&gemm_nt384n_kernel<float, float, true, false>),
                                 reinterpret_cast<const void*>(&gemm_nt384n_kernel<float, __bf16, false, true>),
                                 reinterpret_cast<const void*>(&gemm_nt384n_kernel<float, float, false, true>),
                                 reinterpret_cast<const void*>(&gemm_nt384n_kernel<float, __bf16, true, true>),
                                 reinterpret_cast<const void*>(&gemm_nt384n_kernel<float, float, true, true>)};
-        for (int i = 0; i < 24; ++i) {
+        for (int i = 0; i < 20; ++i) {
             const hipError_t e = hipFuncSetAttribute(wide[i], hipFuncAttributeMaxDynamicSharedMemorySize, i < 12 ? X384<4>::SMEM : X384<2>::SMEM);
             if (e != hipSuccess) err = e;
         }
@@ -1718,19 +1714,16 @@ extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
         const double e384 = fill(tm384 * ((d->N + LBN - 1) / LBN));
         use384 = e384 >= 0.95 * e256;
         // 384 x 128 tiles when the wide grids leave a large part of the last round empty (48 000 x 768: 375 or 564 tiles, 0.73
-        // either way, against 750 narrow ones, 0.98).  Float32 runs at the f32 MFMA's pace whatever the tile; bf16 pays for the
-        // extra staged bytes per FLOP, so it needs a bigger gain.
+        // either way, against 750 narrow ones, 0.98).  Float32 only: it runs at the f32 MFMA's pace whatever the tile (1077 ->
+        // 845 us per GEMM); bf16 pays for the extra staged bytes per FLOP and measured no gain even at a fill ratio of 1.33
+        // (whisper-small, 32 clips: 12.99 ms of GEMMs per pass with narrow tiles, 12.81 ms with wide ones).
         const double e384n = fill(tm384 * ((d->N + 127) / 128));
-        if (e384n >= (d->in_dtype == WIPA_F32 ? 1.10 : 1.25) * (e384 > e256 ? e384 : e256)) use384 = narrow = true;
+        if (d->in_dtype == WIPA_F32 && e384n >= 1.10 * (e384 > e256 ? e384 : e256)) use384 = narrow = true;
     }
     if (big && force_tile == 2568 && d->in_dtype == WIPA_BF16 && d->K % 128 == 0)  // phase-interleaved 256 x 256 (A/B runs)
         return d->out_dtype == WIPA_BF16 ? launch256p<__bf16>(p, s) : launch256p<float>(p, s);
     if (big && use384) {
-        if (narrow) {
-            if (d->in_dtype == WIPA_BF16)
-                return d->out_dtype == WIPA_BF16 ? launch384n<__bf16, __bf16>(p, s) : launch384n<__bf16, float>(p, s);
-            return d->out_dtype == WIPA_BF16 ? launch384n<float, __bf16>(p, s) : launch384n<float, float>(p, s);
-        }
+        if (narrow) return d->out_dtype == WIPA_BF16 ? launch384n<float, __bf16>(p, s) : launch384n<float, float>(p, s);
         if (d->in_dtype == WIPA_BF16)
             return d->out_dtype == WIPA_BF16 ? launch384<__bf16, __bf16>(p, s) : launch384<__bf16, float>(p, s);
         return d->out_dtype == WIPA_BF16 ? launch384<float, __bf16>(p, s) : launch384<float, float>(p, s);
