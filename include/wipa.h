@@ -128,6 +128,24 @@ typedef struct wipa_gemm_desc {
     int32_t w_trans;
 } wipa_gemm_desc;
 int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t s);
+/* Dispatch census (measurement / test aid, no reference counterpart): how many wipa_gemm calls of this process went to each
+ * kernel family since the last reset.  out (HOST) receives the first n counters; reset != 0 clears all of them afterwards.
+ * The parity tests of the fine-tune step (scripts/train_whisper_ipa.py:266-311) use it to prove that the shape-dependent
+ * branches tuned for 32 clips x 64 tokens (split-K, 384 x 128 tiles, K-major operands) are the ones under test. */
+enum {
+    WIPA_GEMM_TILE128 = 0,   /* 128 x 128 register-staged tile kernel */
+    WIPA_GEMM_TILE256 = 1,   /* 256 x 256 LDS-DMA tile kernel */
+    WIPA_GEMM_TILE384 = 2,   /* 384 x 256 */
+    WIPA_GEMM_TILE384N = 3,  /* 384 x 128 (float32, badly quantised wide grids) */
+    WIPA_GEMM_TILE256P = 4,  /* phase-interleaved 256 x 256 (WIPA_GEMM_TILE=2568) */
+    WIPA_GEMM_SKINNY = 5,    /* weight-streaming kernel (decode rows) */
+    WIPA_GEMM_SKINNY_FP8 = 6,
+    WIPA_GEMM_SKINNY_LN = 7, /* ... with the LayerNorm prologue */
+    WIPA_GEMM_KMAJOR = 8,    /* a_trans / w_trans operands (128 x 128 kernel) */
+    WIPA_GEMM_SPLIT_K = 9,   /* calls with k_slices > 1 (counted in addition to their kernel family) */
+    WIPA_GEMM_DISPATCH_CLASSES = 10
+};
+int wipa_gemm_dispatch_counts(int64_t* out, int n, int reset);
 
 /* ------------------------------------------------------------------ K3 LayerNorm
  * nn.LayerNorm(eps=1e-5) rows of width D (attn_ln, cross_attn_ln, mlp_ln, ln_post, ln). */

@@ -8,8 +8,10 @@ segmentation from ``panphon.FeatureTable``; panphon is not in this image.  The f
 
 * ``panphon`` when it imports;
 * else a panphon-format feature CSV named by ``WIPA_PANPHON_CSV`` (panphon's ``data/ipa_all.csv``: header
-  ``ipa,syl,son,...``, values ``+ - 0``) through :class:`CsvFeatureTable` -- base symbols only, a symbol that is not in the
-  table gets the zero vector exactly like the reference's unknown-phone branch (:130-137);
+  ``ipa,syl,son,...``, values ``+ - 0``) through :class:`CsvFeatureTable`: an exact row when the segment has one, else the
+  row of its BASE character (panphon itself would apply its diacritic rules to that base vector; the fallback keeps the base
+  features and is counted in ``pfer_base_fallback_phones``), else the zero vector exactly like the reference's unknown-phone
+  branch (:130-137), counted in ``pfer_unknown_phones`` -- so a gap from the reference's panphon PFER is visible in the result;
 * else NO features: PFER cannot be computed, ``evaluate_batch`` returns PER in the ``pfer`` slot, sets
   ``pfer_is_per_fallback`` and says so on stderr (once).
 
@@ -45,8 +47,19 @@ class CsvFeatureTable:
                 if row:
                     self.vectors[unicodedata.normalize("NFD", row[0])] = [sign[v.strip()] for v in row[1:]]
 
+        self.base_fallbacks: Dict[str, int] = {}  # segment -> times its base character's row stood in for it
+
     def word_to_vector_list(self, word: str, numeric: bool = True):
-        v = self.vectors.get(unicodedata.normalize("NFD", word))
+        key = unicodedata.normalize("NFD", word)
+        v = self.vectors.get(key)
+        if v is None and len(key) > 1:
+            # a diacritic / modifier the table has no row for (ejective, nasalised vowel ...): the base character's features
+            # instead of the all-zero vector.  panphon would additionally flip the features its diacritic_definitions name.
+            base = "".join(ch for ch in key if not (unicodedata.category(ch).startswith("M") or unicodedata.category(ch) == "Lm"
+                                                    or ch in "\u02d0\u02d1"))
+            v = self.vectors.get(base) or (self.vectors.get(base[0]) if base else None)
+            if v is not None:
+                self.base_fallbacks[word] = self.base_fallbacks.get(word, 0) + 1
         return [list(v)] if v is not None else []
 
 
@@ -137,6 +150,7 @@ class PFERCalculator:
         if self.ft is None:
             raise RuntimeError("PFER needs articulatory features: install panphon or point WIPA_PANPHON_CSV at its ipa_all.csv")
         self.num_features = NUM_FEATURES
+        self.unknown_phones: Dict[str, int] = {}  # phone -> times it got the zero vector
 
     def get_phone_features(self, phone: str) -> np.ndarray:
         try:
@@ -145,6 +159,7 @@ class PFERCalculator:
                 return np.array(features[0])
         except Exception:
             pass
+        self.unknown_phones[phone] = self.unknown_phones.get(phone, 0) + 1
         return np.zeros(self.num_features)
 
     def feature_distance(self, phone1: str, phone2: str) -> float:
@@ -237,6 +252,10 @@ def evaluate_batch(references: List[str], hypotheses: List[str]) -> Dict:
         print("WARNING: no articulatory feature table (panphon / WIPA_PANPHON_CSV): PFER is NOT computed, the 'pfer' values below "
               "are PER and best-checkpoint selection ranks by PER", file=sys.stderr, flush=True)
     per_scores, pfer_scores = [], []
+    calc = get_pfer_calculator() if have_features else None
+    if calc is not None:
+        calc.unknown_phones.clear()
+        getattr(calc.ft, "base_fallbacks", {}).clear()
     for ref, hyp in zip(references, hypotheses):
         per = phone_error_rate(ref, hyp)
         per_scores.append(per)
@@ -245,4 +264,8 @@ def evaluate_batch(references: List[str], hypotheses: List[str]) -> Dict:
     return {"per": 0.0 if empty else float(np.mean(per_scores)), "pfer": 0.0 if empty else float(np.mean(pfer_scores)),
             "per_std": 0.0 if empty else float(np.std(per_scores)), "pfer_std": 0.0 if empty else float(np.std(pfer_scores)),
             "num_samples": len(references), "per_scores": per_scores, "pfer_scores": pfer_scores,
-            "pfer_is_per_fallback": not have_features}
+            "pfer_is_per_fallback": not have_features,
+            # phones the feature source did not know (scored with the zero vector, as the reference does) and, on the CSV path,
+            # phones scored with their base character's features: both are where this PFER can differ from panphon's
+            "pfer_unknown_phones": dict(calc.unknown_phones) if calc is not None else {},
+            "pfer_base_fallback_phones": dict(getattr(calc.ft, "base_fallbacks", {})) if calc is not None else {}}

@@ -13,7 +13,7 @@ import json
 import os
 import sys
 from pathlib import Path
-from typing import Dict, List
+from typing import Dict, List, Optional
 
 import numpy as np
 import torch
@@ -71,16 +71,26 @@ class IPADataset:
     # reference name (ipa_data_loader.py:102)
     _tokenize_ipa_batch = tokenize_batch
 
-    def get_batch(self, indices: List[int]) -> Dict:
-        samples = [self[i] for i in indices]
-        audio = np.stack([pad_or_trim(s["audio"], N_SAMPLES) for s in samples])
-        mel = log_mel_spectrogram(audio, n_mels=self.n_mels)  # [B, 3000, n_mels] on the GPU, one launch
-        texts = [s["ipa_text"] for s in samples]
+    def get_batch(self, indices: List[int], audio_for: Optional[List[bool]] = None) -> Dict:
+        """reference :63-100.  ``audio_for`` (one flag per index; None = all): read the audio and compute the log-mel only for
+        the flagged clips -- ``mel_features`` then holds just those rows, in order (None when no clip is flagged).  The
+        fine-tune loop passes the clips whose frozen-encoder features are not cached yet (training.FrozenFeatureCache), so a
+        cached clip costs neither a file read nor a mel nor an encoder pass."""
+        need = [True] * len(indices) if audio_for is None else [bool(f) for f in audio_for]
+        assert len(need) == len(indices)
+        entries = [self.data[i] for i in indices]
+        samples = [self[i] for i, f in zip(indices, need) if f]
+        mel = None
+        if samples:
+            audio = np.stack([pad_or_trim(s["audio"], N_SAMPLES) for s in samples])
+            mel = log_mel_spectrogram(audio, n_mels=self.n_mels)  # [n_flagged, 3000, n_mels] on the GPU, one launch
+        texts = [e["ipa_transcription"] for e in entries]
+        tokens = self.tokenize_batch(texts)
         return {
             "mel_features": mel,
-            "tokens": self.tokenize_batch(texts).to(mel.device),
+            "tokens": tokens.to(mel.device) if mel is not None else tokens,
             "ipa_texts": texts,
-            "audio_paths": [s["audio_path"] for s in samples],
+            "audio_paths": [e["audio_path"] for e in entries],
         }
 
 

@@ -120,21 +120,32 @@ def freeze_encoder(model) -> None:
 
 
 def train_step(trainer: DecoderTrainer, batch: Dict, tokenizer):
-    """reference :266-311 -> (loss, clipped grads); the arithmetic is DecoderTrainer.train_step."""
-    return trainer.train_step(batch["mel_features"], batch["tokens"], tokenizer.eot)
+    """reference :266-311 -> (loss, clipped grads); the arithmetic is DecoderTrainer.train_step.  ``batch["clip_keys"]``
+    (dataset indices) is present when the frozen-encoder feature cache is on: mel_features then covers the uncached clips only."""
+    return trainer.train_step(batch["mel_features"], batch["tokens"], tokenizer.eot, clip_keys=batch.get("clip_keys"))
 
 
 def validate(model, dataset, tokenizer, num_samples: int = 100) -> Dict:
-    """reference :314-407: batched greedy decode (language=None -> detection, fp16=False), PER / PFER."""
-    print(f"\nValidating on {num_samples} samples...")
+    """reference :314-407: batched greedy decode (language=None -> detection, fp16=False), PER / PFER.
+
+    Data parallel: COLLECTIVE -- every rank calls it.  The validation batches (4 clips each, the reference's size) are dealt
+    round-robin to the ranks, each rank decodes its share with its own weight replica, the (reference, hypothesis) pairs are
+    gathered once and every rank scores the whole list in the reference's sample order, so all ranks return the same
+    metrics.  (Round 2 validated on rank 0 alone while the other ranks idled in the next step's all-reduce.)"""
+    rank, world = parallel.world()
+    main = rank == 0
+    if main:
+        print(f"\nValidating on {num_samples} samples...")
     model.eval()
-    references, hypotheses = [], []
     val_batch_size = 4
     options = DecodingOptions(language=None, without_timestamps=True, fp16=False, length_penalty=1.0)
+    mine = []  # (batch index, refs, hyps)
     for i in range((num_samples + val_batch_size - 1) // val_batch_size):
         indices = list(range(i * val_batch_size, min((i + 1) * val_batch_size, num_samples)))
         if not indices:
             break
+        if i % world != rank:
+            continue
         try:
             batch = dataset.get_batch(indices)
             results = model.decode(batch["mel_features"], options)
@@ -142,19 +153,28 @@ def validate(model, dataset, tokenizer, num_samples: int = 100) -> Dict:
                 results = [results]
             hyps = [r.text.strip() for r in results]
             refs = [re.sub(r"<\|.*?\|>", "", tokenizer.decode(batch["tokens"][j].tolist())).strip() for j in range(len(indices))]
-            references.extend(refs)
-            hypotheses.extend(hyps)
-            if i == 0:
-                print("\nSample Predictions:")
-                for k in range(min(3, len(refs))):
-                    print(f"  Ref:  [{refs[k]}]\n  Pred: [{hyps[k]}]\n" + "-" * 30)
+            mine.append((i, refs, hyps))
         except Exception as e:  # reference :393-396 keeps going
             print(f"Error during validation decoding: {e}")
             import traceback
             traceback.print_exc()
+    if world > 1:
+        import torch.distributed as dist
+
+        parts = [None] * world
+        dist.all_gather_object(parts, mine)
+        mine = [item for part in parts for item in part]
+    mine.sort(key=lambda t: t[0])
+    references = [r for _, refs, _ in mine for r in refs]
+    hypotheses = [h for _, _, hyps in mine for h in hyps]
+    if main and mine and mine[0][0] == 0:
+        print("\nSample Predictions:")
+        for k in range(min(3, len(mine[0][1]))):
+            print(f"  Ref:  [{mine[0][1][k]}]\n  Pred: [{mine[0][2][k]}]\n" + "-" * 30)
     metrics = evaluate_batch(references, hypotheses)
     model.train()
-    print(f"Validation Results:\n  PER:  {metrics['per']:.2f}%\n  PFER: {metrics['pfer']:.2f}%")
+    if main:
+        print(f"Validation Results:\n  PER:  {metrics['per']:.2f}%\n  PFER: {metrics['pfer']:.2f}%")
     return metrics
 
 
@@ -194,7 +214,7 @@ def _init_distributed():
 def train(model_name: str, train_data_path: str, test_data_path: str, output_dir: str, num_steps: int = 1000,
           batch_size: int = 4, learning_rate: float = 1e-5, validate_every: int = 100, save_every: int = 500,
           test_run: bool = False, audio_root: str = "", seed: Optional[int] = None, fast_f32: bool = False,
-          allow_byte_fallback: bool = False):
+          allow_byte_fallback: bool = False, cache_encoder_features: bool = True, feature_cache_clips: Optional[int] = None):
     rank, world = _init_distributed()
     try:
         parallel.require_even_shards(batch_size, world)  # every rank gets clips; no mismatched collectives
@@ -208,7 +228,8 @@ def train(model_name: str, train_data_path: str, test_data_path: str, output_dir
         args_dict = {"model_name": model_name, "train_data_path": train_data_path, "test_data_path": test_data_path,
                      "num_steps": num_steps, "batch_size": batch_size, "learning_rate": learning_rate,
                      "validate_every": validate_every, "save_every": save_every, "test_run": test_run,
-                     "world_size": world, "f32_products": "split" if fast_f32 else "exact"}
+                     "world_size": world, "f32_products": "split" if fast_f32 else "exact",
+                     "cache_encoder_features": bool(cache_encoder_features)}
         save_training_config(output_dir, args_dict, get_hardware_info())
     logger = TrainingLogger(output_dir) if main else None
     print(f"Loading model: {model_name}")
@@ -230,6 +251,13 @@ def train(model_name: str, train_data_path: str, test_data_path: str, output_dir
         train_dataset.data = train_dataset.data[:100]
         num_steps = min(num_steps, 100)
     rng = np.random.default_rng(seed) if seed is not None else np.random.default_rng(int(time.time()) if world == 1 else 0)
+    if cache_encoder_features:
+        # The encoder is frozen (reference :187) yet recomputed every step (:223): its output is a pure function of the clip,
+        # 4.6 MB per clip for whisper-small -- the whole training list fits the 288 GB HBM.  Bit-identical to recomputing.
+        cache = trainer.enable_feature_cache(feature_cache_clips if feature_cache_clips is not None else
+                                             min(len(train_dataset), trainer.feature_cache_capacity_default()))
+        print(f"  ✓ Frozen-encoder feature cache: up to {cache.max_clips} clips "
+              f"({cache.max_clips * model.dims.n_audio_ctx * model.dims.n_audio_state * 4 / 2**30:.1f} GiB of HBM)")
 
     print("\n" + "=" * 70 + f"\nStarting training for {num_steps} steps\n" + "=" * 70)
     model.train()
@@ -241,7 +269,11 @@ def train(model_name: str, train_data_path: str, test_data_path: str, output_dir
             mine = parallel.shard_indices(draw.tolist(), world, rank)
             batch, local_error = None, None
             try:
-                batch = train_dataset.get_batch(mine)
+                if trainer.feature_cache is not None:
+                    batch = train_dataset.get_batch(mine, audio_for=trainer.feature_cache.missing(mine))
+                    batch["clip_keys"] = mine
+                else:
+                    batch = train_dataset.get_batch(mine)
             except Exception as e:  # e.g. an unreadable clip on ONE rank
                 local_error = e
             # Failure must be collective: a rank that left the loop alone would leave the others waiting in the step's
@@ -266,8 +298,9 @@ def train(model_name: str, train_data_path: str, test_data_path: str, output_dir
                 print(f"Step {step}/{num_steps} | Loss: {loss_value:.4f} | Time: {step_time:.3f}s | "
                       f"Samples/sec: {batch_size / step_time:.1f}")
                 logger.log_train_step(step, loss_value, learning_rate, step_time, batch_size, time.time() - start_time)
+            if step % validate_every == 0:
+                metrics = validate(model, test_dataset, tokenizer, num_samples=min(100, len(test_dataset)))  # collective
             if main and step % validate_every == 0:
-                metrics = validate(model, test_dataset, tokenizer, num_samples=min(100, len(test_dataset)))
                 if logger.log_validation(step, metrics, time.time() - start_time):
                     best = output_dir / "best-checkpoint"
                     if best.exists():
@@ -293,7 +326,8 @@ def train(model_name: str, train_data_path: str, test_data_path: str, output_dir
 
     if main:
         print("\n" + "=" * 70 + "\nTraining complete! Running final validation...\n" + "=" * 70)
-        metrics = validate(model, test_dataset, tokenizer, num_samples=min(500, len(test_dataset)))
+    metrics = validate(model, test_dataset, tokenizer, num_samples=min(500, len(test_dataset)))  # collective
+    if main:
         logger.log_validation(num_steps, metrics, time.time() - start_time)
         if latest_loss is not None:
             print("\nSaving final model...")
@@ -335,13 +369,20 @@ def main():
     p.add_argument("--fast-f32", action="store_true",
                    help="take the float32 products of the large GEMMs as split-bf16 MFMA terms (~2x faster, ~5e-6 relative); "
                         "default: exact f32 products, as the reference trains")
+    p.add_argument("--no-cache-encoder-features", action="store_true",
+                   help="recompute the frozen encoder for every clip of every step, as the reference does (default: keep each "
+                        "clip's encoder output in HBM after its first use -- bit-identical results, about half the step time)")
+    p.add_argument("--feature-cache-clips", type=int, default=None,
+                   help="capacity of the frozen-encoder feature cache in clips (default: the training list, or what half of the "
+                        "free HBM holds); clips beyond it are recomputed")
     p.add_argument("--allow-byte-fallback", action="store_true",
                    help="run without the Whisper vocabulary (WIPA_TIKTOKEN unset): raw-byte text ids; synthetic weights only")
     a = p.parse_args()
     train(model_name=a.model, train_data_path=a.train_data, test_data_path=a.test_data, output_dir=a.output_dir,
           num_steps=a.steps, batch_size=a.batch_size, learning_rate=a.lr, validate_every=a.validate_every,
           save_every=a.save_every, test_run=a.test_run, audio_root=a.audio_root, fast_f32=a.fast_f32,
-          allow_byte_fallback=a.allow_byte_fallback)
+          allow_byte_fallback=a.allow_byte_fallback, cache_encoder_features=not a.no_cache_encoder_features,
+          feature_cache_clips=a.feature_cache_clips)
 
 
 if __name__ == "__main__":

@@ -20,6 +20,7 @@ import pytest
 import torch
 
 from oracle import whisper_ref as R
+from parity_util import BF16_LOGIT_ERR_CEILING, check_low_precision_decode, divergence_report
 
 pytestmark = pytest.mark.gpu
 
@@ -38,20 +39,6 @@ def _setup():
     sp = R.SpecialTokens.multilingual()
     always, first = R.suppress_lists(sp)
     return sp, always, first, list(sp.sot_sequence_including_notimestamps(0))
-
-
-def divergence_report(got: np.ndarray, ref: "R.GreedyResult", n_init: int):
-    """token-match rate and, per row, the first step where the ids differ with the oracle's margin at that step."""
-    body_g, body_r = got[:, n_init:], ref.tokens[:, n_init:]
-    n = min(body_g.shape[1], body_r.shape[1])
-    eq = body_g[:, :n] == body_r[:, :n]
-    firsts = []
-    for b in range(eq.shape[0]):
-        bad = np.flatnonzero(~eq[b])
-        firsts.append(None if bad.size == 0 else (int(bad[0]), float(ref.margins[b, bad[0]])))
-    # rows are compared up to their first divergence: later ids follow a different history
-    prefix = sum((n if f is None else f[0]) for f in firsts)
-    return {"token_match": float(eq.mean()), "prefix_match": prefix / float(eq.size), "first_divergence": firsts}
 
 
 @pytest.fixture(scope="module")
@@ -102,33 +89,60 @@ def test_small_full_depth_f32_matches_oracle(small_full, f32_mode):
     assert (res.tokens == S["ref"].tokens).all(), rep
 
 
-def test_small_full_depth_bf16_token_match_and_first_divergence(small_full):
+def test_small_full_depth_bf16_logit_error_bound_and_divergences(small_full):
     """The benchmark arithmetic (bf16 matrices / activations / KV caches, f32 residual stream and accumulation) on the
-    full-depth model against the f32 oracle.  bf16 cannot be bit-identical to an f32 path on random-init weights (the
-    top-1 margins are a few percent of the logit spread), so: features within bf16 tolerance, and every row must follow
-    the oracle's ids up to a step whose oracle margin is below the bf16 noise gate; match rate and first divergence are
-    printed (bench.py reports the same figures as `parity_vs_cpu`)."""
-    from whisper_ipa_amd.decoding import greedy_decode_tokens
-
+    full-depth model against the f32 oracle.  VERDICT r2 weak #2: no adjustable margin gate -- the bf16 logit error is
+    MEASURED: the decode-step path (prefill + replayed step graph) is driven along the ORACLE's 64-token history, every
+    step's logits are compared with the f32 oracle's, and both the teacher-forced choices and the free-running greedy ids may
+    part from the oracle's only at a (row, step) whose oracle margin is <= 2 x the error measured there (parity_util.py).
+    Features within bf16 tolerance; the numbers are printed and recorded in DESIGN.md section 2."""
     S = small_full
     sp, always, first, init = _setup()
+    ref = S["ref"]
     m = _model(S["dims"], S["W"], torch.bfloat16)
     feats = m.encoder(torch.from_numpy(S["mels"]).cuda())
     rel = ((feats.float().cpu() - S["xa"]).abs().max() / S["xa"].abs().max()).item()
     rms = ((feats.float().cpu() - S["xa"]).pow(2).mean().sqrt() / S["xa"].pow(2).mean().sqrt()).item()
-    res = greedy_decode_tokens(m, feats, init, always, first, sp.eot, max_new_tokens=N_NEW, stop_on_eot=False)
-    ref = S["ref"]
-    rep = divergence_report(res.tokens, ref, 4)
-    finite = ref.step_logits[np.isfinite(ref.step_logits)]
-    gate = 0.05 * float(finite.std())
-    print(f"\nsmall 12+12 bf16: feature max rel err {rel:.3e} (rms {rms:.3e}), margin gate {gate:.3f}, {rep}")
     assert rel < 5e-2, rel
     assert rms < 1e-2, rms
-    for b, f in enumerate(rep["first_divergence"]):
-        if f is not None:
-            step, margin = f
-            # the divergence must sit at (or after) a step the oracle itself decides by less than the gate
-            assert ref.margins[b, : step + 1].min() < gate, (b, step, margin, gate)
+    err, rep = check_low_precision_decode(m, feats, ref, init, always, first, sp.eot, "whisper-small 12+12 bf16")
+    print(f"\nsmall 12+12 bf16: feature max rel err {rel:.3e} (rms {rms:.3e}); along the oracle's history: max logit error "
+          f"{rep['max_logit_err']:.4f} (mean of per-step maxima {err.mean():.4f}), logit std {rep['logit_std']:.3f} -> {rep['rel_err']:.4f} "
+          f"relative; {rep['forced_flips']} of {rep['steps']} teacher-forced choices differ (largest oracle margin among them "
+          f"{rep['largest_flipped_margin']:.4f}), min oracle margin {ref.margins.min():.4f}; free-running: token match "
+          f"{rep['token_match']:.4f}, first divergences {rep['first_divergence']}")
+
+
+def test_small_full_depth_bf16_peaky_preset_ids_bit_exact(small_full):
+    """The "peaky" preset (oracle.peaky_positional_table: a confident model, top-1 margins of several logit standard
+    deviations, as a trained Whisper has and a random-init one has not): the bf16 path -- the benchmark's arithmetic -- must
+    reproduce the f32 oracle's 64 greedy ids of every clip BIT FOR BIT, and it must do so with room to spare: the smallest
+    oracle margin is at least ten times the largest measured bf16 logit error (so the equality is not luck), while the
+    logits still carry the audio: their error is measured against the oracle over the whole vocabulary at every step.
+    north_star: "greedy IPA output bit-identical to the CPU reference" (scripts/transcribe_single.py:49-56)."""
+    from whisper_ipa_amd.decoding import greedy_decode_tokens
+
+    S = small_full
+    sp, always, first, init = _setup()
+    Wp = dict(S["W"])
+    Wp["decoder.positional_embedding"] = R.peaky_positional_table(S["W"], S["dims"], 0, always)
+    assert torch.equal(Wp["decoder.positional_embedding"], R.synthetic_weights(S["dims"], seed=0, preset="peaky")["decoder.positional_embedding"])
+    with torch.no_grad():  # the preset leaves the encoder alone: the oracle's features are those of the lively preset
+        ref = R.greedy_decode(Wp, S["dims"], S["xa"], init, always, first, sp.eot, sample_len=N_NEW, stop_on_eot=False, keep_logits=True)
+    m = _model(S["dims"], Wp, torch.bfloat16)
+    feats = m.encoder(torch.from_numpy(S["mels"]).cuda())
+    err, rep = check_low_precision_decode(m, feats, ref, init, always, first, sp.eot, "whisper-small 12+12 bf16, peaky preset")
+    res = greedy_decode_tokens(m, feats, init, always, first, sp.eot, max_new_tokens=N_NEW, stop_on_eot=False)
+    print(f"\nsmall 12+12 bf16, peaky preset: min oracle margin {ref.margins.min():.3f}, max logit error {rep['max_logit_err']:.4f} "
+          f"({rep['rel_err']:.4f} of the logit std {rep['logit_std']:.3f}), distinct ids in row 0: {len(set(ref.tokens[0, 4:].tolist()))}")
+    assert (res.tokens == ref.tokens).all(), rep
+    assert rep["forced_flips"] == 0
+    assert ref.margins.min() > 10.0 * err.max(), (ref.margins.min(), err.max())
+    assert len(set(ref.tokens[0, 4:].tolist())) == N_NEW  # not the degenerate "repeat the last token" of a std-0.02 init
+    # the f32 path on the same preset: bit-exact as well
+    m32 = _model(S["dims"], Wp, torch.float32)
+    r32 = greedy_decode_tokens(m32, m32.encoder(torch.from_numpy(S["mels"]).cuda()), init, always, first, sp.eot, max_new_tokens=N_NEW, stop_on_eot=False)
+    assert (r32.tokens == ref.tokens).all()
 
 
 def test_tiny_full_model_f32_matches_oracle(f32_mode):
@@ -190,7 +204,7 @@ def medium_rows():
 
 def test_medium_width_more_than_64_decode_rows_f32_and_bf16(medium_rows):
     """configs[3] decodes 256 rows at d = 1024: rows beyond the first 64 ride on grid.y of the weight-streaming GEMM.
-    72 rows, f32: ids bit-exact vs the oracle for every row (incl. 64..71); bf16: margin-gated."""
+    72 rows, f32: ids bit-exact vs the oracle for every row (incl. 64..71); bf16: row-group invariance (64 + 8 rows == 72)."""
     from whisper_ipa_amd.decoding import greedy_decode_tokens
 
     W, xa, ref = medium_rows
@@ -204,18 +218,9 @@ def test_medium_width_more_than_64_decode_rows_f32_and_bf16(medium_rows):
         last_ref = ref.step_logits[:, -1]
         ok = np.isfinite(last_ref)
         assert np.abs(res.last_logits.cpu().numpy()[ok] - last_ref[ok]).max() < 2e-3
+    # bf16 on these rows: test_medium_width_bf16_logit_error_explains_the_r2_divergence (measured error, no margin gate)
     mb = _model(MEDIUM2, W, torch.bfloat16)
     rb = greedy_decode_tokens(mb, xa.cuda().to(torch.bfloat16), init, always, first, sp.eot, max_new_tokens=12, stop_on_eot=False)
-    finite = ref.step_logits[np.isfinite(ref.step_logits)]
-    # 8 % of the logit spread here (5 % in the tests on real encoder outputs): the cross-attention keys of this test are white
-    # noise, so its softmax is nearly flat over 1500 keys and bf16 rounding of the scores moves the output more than it does on
-    # encoder features (observed: a divergence at an oracle margin of 0.36 with a spread of 6.4)
-    gate = 0.08 * float(finite.std())
-    rep = divergence_report(rb.tokens, ref, 4)
-    print(f"\nmedium width, 72 rows, bf16: {rep['token_match']:.3f} token match, prefix match {rep['prefix_match']:.3f}")
-    for b, f in enumerate(rep["first_divergence"]):
-        if f is not None:
-            assert ref.margins[b, : f[0] + 1].min() < gate, (b, f, gate)
     # the same rows decoded in two smaller batches (64 + 8) give the same ids: row-group invariance at this width
     ra = greedy_decode_tokens(mb, xa[:64].cuda().to(torch.bfloat16), init, always, first, sp.eot, max_new_tokens=12, stop_on_eot=False)
     rc = greedy_decode_tokens(mb, xa[64:].cuda().to(torch.bfloat16), init, always, first, sp.eot, max_new_tokens=12, stop_on_eot=False)
@@ -261,3 +266,93 @@ def test_medium_full_model_bf16_batch_256_properties():
     assert body.min() >= 0 and body.max() < dims.n_vocab
     assert not np.isin(body, np.array(always)).any() and not np.isin(body[:, 0], np.array(first)).any()
     assert torch.isfinite(f256.float()).all() and len({tuple(r) for r in body[:32].tolist()}) > 4
+
+
+def test_medium_width_bf16_logit_error_explains_the_r2_divergence(medium_rows):
+    """The round-2 failure (gpurun_out/r2_t10.log: row 29 parted at step 8 where the oracle's margin was 0.363, above the 5 %
+    gate, and the gate was widened to 8 %): measure the bf16 logit error of those rows at those steps instead.  72 rows x 12
+    steps at whisper-medium width with white-noise features (a nearly flat cross-attention softmax over 1500 keys)."""
+    from whisper_ipa_amd.decoding import forced_decode_logits
+    from parity_util import step_logit_errors
+
+    W, xa, ref = medium_rows
+    sp, always, first, init = _setup()
+    mb = _model(MEDIUM2, W, torch.bfloat16)
+    err, rep = check_low_precision_decode(mb, xa.cuda().to(torch.bfloat16), ref, init, always, first, sp.eot, "whisper-medium width bf16")
+    worst = np.unravel_index(np.argmax(err), err.shape)
+    print(f"\nmedium width bf16, 72 rows along the oracle's history: max logit error {rep['max_logit_err']:.4f} at (row, step) {worst}, "
+          f"logit std {rep['logit_std']:.3f} -> {rep['rel_err']:.4f} relative; {rep['forced_flips']} of {rep['steps']} choices differ, "
+          f"largest oracle margin among them {rep['largest_flipped_margin']:.4f}; row 29 step 8: margin {ref.margins[29, 8]:.4f}, "
+          f"error {err[29, 8]:.4f}; free-running token match {rep['token_match']:.3f}")
+    # the f32 path on the same rows: error orders of magnitude lower, and the same rule holds with it
+    m32 = _model(MEDIUM2, W, torch.float32)
+    t32, c32 = forced_decode_logits(m32, xa.cuda(), ref.tokens, 4, always, first, sp.eot)
+    e32 = step_logit_errors(t32, ref.step_logits)
+    f32flips = c32 != ref.tokens[:, 4:]
+    assert e32.max() < 2e-3 and (ref.margins[f32flips] <= 2.0 * e32[f32flips]).all(), (e32.max(), int(f32flips.sum()))
+
+
+def test_large_v3_full_model_fp8_batch_128_properties():
+    """BASELINE.json configs[4] at FULL size: whisper-large-v3 (128 mels, d = 1280, 20 heads, 32+32 layers, 51 866 tokens),
+    fp8 e4m3 weights, 128 clips x 30 s (cross-KV 31.5 GB resident).  The CPU oracle cannot run this size in test time, so
+    size-independent properties, as for configs[3]: batch invariance (clips 0..3 alone == rows 0..3 of the 128-clip batch,
+    features and ids bit for bit), identical clips in different 64-row groups, determinism, suppression -- and the fp8 model
+    equals the SAME model on its dequantised bf16 weights (features bit-identical: both encoders multiply the same numbers;
+    ids equal: the fp8 weight-streaming GEMM widens each code exactly)."""
+    import bench
+    from whisper_ipa_amd import audio as A
+    from whisper_ipa_amd.decoding import greedy_decode_tokens
+    from whisper_ipa_amd.whisper import Whisper
+
+    dims, W = bench.synthetic_weights_small(0, "large-v3")
+    assert (dims.n_mels, dims.n_audio_state, dims.n_audio_layer, dims.n_text_layer, dims.n_vocab) == (128, 1280, 32, 32, 51866)
+    m = Whisper(dims, dtype=torch.bfloat16)
+    m.load_weights(W)
+    del W
+    m.quantize_weights("fp8_e4m3")
+    assert m.weights_format == "fp8_e4m3"
+    from whisper_ipa_amd.tokenizer import get_tokenizer
+    from whisper_ipa_amd.decoding import DecodingOptions, _suppress_lists
+
+    tok = get_tokenizer(True, num_languages=m.num_languages)
+    always, first = _suppress_lists(DecodingOptions(language="en", without_timestamps=True), tok)
+    init, eot = list(tok.sot_sequence_including_notimestamps), tok.eot
+    base = bench.synthetic_audio(0, 32)
+    audio = torch.from_numpy(np.concatenate([base] * 4)).cuda()  # 128 clips; rows r and r + 32k are the same clip
+    audio[5, 16000 * 5:] = 0
+
+    def run(model, a, n_new=8):
+        mel = A.log_mel_padded(a, dims.n_mels, torch.bfloat16)
+        feats = model.encode_padded(mel, a.shape[0])
+        res = greedy_decode_tokens(model, feats, init, always, first, eot, max_new_tokens=n_new, stop_on_eot=False)
+        return feats, res.tokens, res.last_logits.clone()
+
+    f128, t128, l128 = run(m, audio)
+    f4, t4, _ = run(m, audio[:4].contiguous())
+    assert torch.equal(f4, f128[:4]), (f4.float() - f128[:4].float()).abs().max()
+    assert (t4 == t128[:4]).all()
+    assert torch.equal(f128[32:64], f128[96:128]) and (t128[32:64] == t128[96:128]).all()  # other 64-row group, same clips
+    assert (t128[6] == t128[6 + 64]).all() and not (t128[5] == t128[5 + 32]).all()  # row 5 was shortened
+    _, t128b, _ = run(m, audio)
+    assert (t128 == t128b).all()
+    assert t128.shape == (128, 4 + 8) and (t128[:, :4] == np.array(init)).all()
+    body = t128[:, 4:]
+    assert body.min() >= 0 and body.max() < dims.n_vocab
+    assert not np.isin(body, np.array(always)).any() and not np.isin(body[:, 0], np.array(first)).any()
+    assert torch.isfinite(f128.float()).all() and len({tuple(r) for r in body[:32].tolist()}) > 4
+    # the same model on the dequantised bf16 weights (no fp8 codes: bf16 weight-streaming GEMMs in the decode step)
+    mb = Whisper(dims, dtype=torch.bfloat16)
+    mb.load_weights({k: v.clone() for k, v in m.flat_parameters().items()})
+    assert mb.weights_format == "bfloat16"
+    m._invalidate()  # drop the fp8 model's decode state (45 GB) before the second model allocates its own
+    m._dec_states.clear()
+    torch.cuda.empty_cache()
+    fb, tb, lb = run(mb, audio)
+    assert torch.equal(fb, f128)
+    # same rounding points; only the f32 summation order inside a projection differs (split-K of the two weight-streaming
+    # kernels), so the ids agree until a near-tie: the first four generated tokens must, and the match rate is printed
+    same = np.cumprod(tb == t128, axis=1).astype(bool)
+    assert same[:, : 4 + 4].all(), (tb[~same.all(axis=1)][:4].tolist(), t128[~same.all(axis=1)][:4].tolist())
+    print(f"\nlarge-v3 32+32 fp8 vs dequantised bf16, 128 clips x 8 tokens: ids equal in {float((tb == t128).mean()):.4f} of the positions")
+    if same.all():
+        assert (lb - l128).abs().max().item() < 0.15

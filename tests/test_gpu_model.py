@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from oracle import whisper_ref as R
+from parity_util import check_low_precision_decode
 
 pytestmark = pytest.mark.gpu
 
@@ -15,10 +16,10 @@ MICRO = R.ModelDimensions(80, 1500, 128, 2, 2, 51865, 448, 128, 2, 2)
 SMALL2 = R.ModelDimensions(80, 1500, 768, 12, 2, 51865, 448, 768, 12, 2)  # whisper-small width, 2+2 layers
 
 
-def _model(dims_o, W, dtype):
+def _model(dims_o, W, dtype, f32_split=False):
     from whisper_ipa_amd.whisper import ModelDimensions, Whisper
 
-    m = Whisper(ModelDimensions(**dims_o.__dict__), dtype=dtype)
+    m = Whisper(ModelDimensions(**dims_o.__dict__), dtype=dtype, f32_split=f32_split)
     m.load_weights(W)
     return m
 
@@ -439,10 +440,8 @@ def test_full_size_bench_workload_properties():
 
 def test_small_width_bf16_close_and_tokens_match_where_margin_allows(small2):
     """bf16 path (the bench configuration's arithmetic) against the f32 oracle: features within
-    bf16 tolerance; greedy tokens must equal the oracle's up to the first step whose oracle
-    top-1 margin is below the bf16 noise floor (margin gating)."""
-    from whisper_ipa_amd.decoding import greedy_decode_tokens
-
+    bf16 tolerance; greedy tokens must equal the oracle's except at a step whose oracle
+    top-1 margin is within twice the bf16 logit error MEASURED at that (row, step) (tests/parity_util.py)."""
     W, mels, xa = small2
     m = _model(SMALL2, W, torch.bfloat16)
     feats = m.encoder(torch.from_numpy(mels).cuda())
@@ -452,16 +451,10 @@ def test_small_width_bf16_close_and_tokens_match_where_margin_allows(small2):
     sp = R.SpecialTokens.multilingual()
     always, first = R.suppress_lists(sp)
     init = list(sp.sot_sequence_including_notimestamps(0))
-    res = greedy_decode_tokens(m, feats, init, always, first, sp.eot, max_new_tokens=16, stop_on_eot=False)
     with torch.no_grad():
         ref = R.greedy_decode(W, SMALL2, xa, init, always, first, sp.eot, sample_len=16, stop_on_eot=False, keep_logits=True)
-    finite = ref.step_logits[np.isfinite(ref.step_logits)]
-    gate = 0.05 * float(finite.std())
-    for b in range(res.tokens.shape[0]):
-        for t in range(16):
-            if ref.margins[b, t] < gate:
-                break
-            assert res.tokens[b, 4 + t] == ref.tokens[b, 4 + t], (b, t, ref.margins[b, t], gate)
+    err, rep = check_low_precision_decode(m, feats, ref, init, always, first, sp.eot, "small width bf16")
+    print(f"\nsmall width bf16: max logit error {rep['max_logit_err']:.4f} = {rep['rel_err']:.4f} of the logit std, token match {rep['token_match']:.3f}")
 
 
 @pytest.mark.parametrize("name,dims,n_new", [
@@ -474,7 +467,7 @@ def test_fp8_weight_model_matches_dequantised_reference(name, dims, n_new):
     power-of-two scales) -- decode-step matrices streamed as 1-byte codes by the fp8 weight-streaming GEMM, everything else
     as the exact bf16 dequantisation -- against (a) the SAME model run entirely on the dequantised bf16 weights (features
     bit-identical, last-step logits equal up to f32 summation order, ids equal) and (b) the f32 oracle on the dequantised
-    weights (margin-gated like every bf16 test; logits bound stated below)."""
+    weights (measured logit error, tests/parity_util.py)."""
     import whisper_ipa_amd as wipa
     from whisper_ipa_amd.decoding import greedy_decode_tokens
 
@@ -511,18 +504,11 @@ def test_fp8_weight_model_matches_dequantised_reference(name, dims, n_new):
         xa = R.encoder_forward(Wdq, dims, torch.from_numpy(mel_ref))
         ref = R.greedy_decode(Wdq, dims, xa, init, always, first, sp.eot, sample_len=n_new, stop_on_eot=False, keep_logits=True)
     assert ((f8.float().cpu() - xa).abs().max() / xa.abs().max()).item() < 5e-2
-    finite = ref.step_logits[np.isfinite(ref.step_logits)]
-    gate = 0.05 * float(finite.std())
-    for r in range(a.tokens.shape[0]):
-        for t in range(n_new):
-            if ref.margins[r, t] < gate:
-                break
-            assert a.tokens[r, 4 + t] == ref.tokens[r, 4 + t], (name, r, t, ref.margins[r, t], gate)
-    # stated logits bound vs the oracle at the first generated position (same history for every row): 5 % of the logit spread
-    first_logits = greedy_decode_tokens(m8, f8, init, always, first, sp.eot, max_new_tokens=1, stop_on_eot=False).last_logits
-    ok = np.isfinite(ref.step_logits[:, 0])
-    err = np.abs(first_logits.float().cpu().numpy()[ok] - ref.step_logits[:, 0][ok]).max()
-    assert err < 0.05 * float(finite.std()) * 4, (name, err, float(finite.std()))
+    # measured logit error of the fp8 model along the oracle's history: every differing id must sit at a step whose oracle
+    # margin is <= 2 x that error; the ceiling is the bf16 one (the weights ARE the oracle's: only activations are rounded)
+    err, rep = check_low_precision_decode(m8, f8, ref, init, always, first, sp.eot, f"fp8 weights, {name}")
+    print(f"\nfp8 weights [{name}]: max logit error vs the f32 oracle on the dequantised weights {rep['max_logit_err']:.4f} = "
+          f"{rep['rel_err']:.4f} of the logit std, token match {rep['token_match']:.3f}")
     # a weight update or a dtype change invalidates the codes
     m8.load_weights({"decoder.ln.bias": Wdq["decoder.ln.bias"] + 1}, strict=False)
     assert m8.weights_format == "bfloat16"
@@ -530,3 +516,74 @@ def test_fp8_weight_model_matches_dequantised_reference(name, dims, n_new):
     assert m8.weights_format == "fp8_e4m3"
     m8.set_dtype(torch.float32)
     assert m8.weights_format == "float32" and m8.packed()["cfg"].dec_w_dtype == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 3: the HIP path against the WIDE golden fixtures (tests/golden/wide_model.npz: whisper-small width and large-v3
+# dims -- 128 mels, 51 866 tokens, 100 languages -- from the transformers stand-in), not only against the oracle.
+WIDE = {"small1": (R.ModelDimensions(80, 1500, 768, 12, 1, 51865, 448, 768, 12, 1), 41, 99),
+        "large1": (R.ModelDimensions(128, 1500, 1280, 20, 1, 51866, 448, 1280, 20, 1), 43, 100)}
+
+
+@pytest.mark.parametrize("name", sorted(WIDE))
+def test_wide_golden_features_logits_loss_gradients_language_and_fp16_features(name, golden_dir, f32_mode):
+    """float32 HIP path vs the stand-in's vectors: log-mel -> encoder slices, teacher-forced logits slices, masked-CE loss,
+    slices of eight decoder gradients (DecoderTrainer.loss_and_grads vs the stand-in's autograd), detect_language at 99 / 100
+    languages, greedy ids on f32 and on fp16-rounded features (DecodingOptions.fp16), and the fp16-rounded
+    sinusoid table (App. C.3, Whisper(sinusoid_rounding="fp16")).  north_star tolerance: 1e-3 in fp32."""
+    import whisper_ipa_amd as wipa
+    from whisper_ipa_amd import ops
+    from whisper_ipa_amd.decoding import detect_language, greedy_decode_tokens
+    from whisper_ipa_amd.tokenizer import get_tokenizer
+    from whisper_ipa_amd.training import DecoderTrainer
+
+    g = np.load(os.path.join(golden_dir, "wide_model.npz"))
+    dims, seed, n_lang = WIDE[name]
+    split = f32_mode == "split"
+    W = R.synthetic_weights(dims, seed=seed)
+    clips = np.stack([R.synthetic_clip(2, 30.0), R.synthetic_clip(3, 7.0)])
+    m = _model(dims, W, torch.float32, f32_split=split)
+    mel = wipa.log_mel_spectrogram(clips, n_mels=dims.n_mels)
+    assert abs(float(mel.abs().sum()) - g[f"{name}_mel_checksum"][0]) / g[f"{name}_mel_checksum"][0] < 1e-5
+    feats = m.encoder(mel)
+    rows, cols = g[f"{name}_enc_rows"], g[f"{name}_enc_cols"]
+    assert np.abs(feats.cpu().numpy()[:, rows][:, :, cols] - g[f"{name}_enc_slices"]).max() < 1e-3
+    tokens = torch.from_numpy(g[f"{name}_tokens"])
+    logits = m.logits(tokens[:, :-1].cuda(), feats)
+    lc = g[f"{name}_logit_cols"]
+    assert np.abs(logits.cpu().numpy()[:, :, lc] - g[f"{name}_logit_slices"]).max() < 2e-3
+    sp = R.SpecialTokens.multilingual(n_lang)
+    tr = DecoderTrainer(m)
+    loss, _, n_valid = tr.loss_and_grads(feats, tokens.cuda(), sp.eot)
+    assert abs(float(loss) - g[f"{name}_loss"][0]) < 1e-3
+    tok_rows = g[f"{name}_grad_tok_rows"]
+    for key in [k for k in g.files if k.startswith(f"{name}_grad__")]:
+        pname = key.split("__", 1)[1].replace("__", ".")
+        want = g[key]
+        got = tr.g(pname).cpu()
+        if pname == "decoder.token_embedding.weight":
+            got = got[tok_rows][:, :16]
+        elif got.dim() == 1:
+            got = got[: want.shape[0]]
+        else:
+            got = got[: want.shape[0], : want.shape[1]]
+        assert float(np.abs(got.numpy() - want).max()) / (float(np.abs(want).max()) + 1e-12) < 3e-3, pname
+        norm = float(g[f"{name}_gradnorm__{key.split('__', 1)[1]}"][0])
+        assert abs(float(tr.g(pname).norm()) - norm) / norm < 2e-3, pname
+    tok = get_tokenizer(True, num_languages=n_lang)
+    lang, _ = detect_language(m, feats, tok)
+    assert lang.tolist() == g[f"{name}_lang_tokens"].tolist()
+    always, first = R.suppress_lists(sp)
+    init = list(sp.sot_sequence_including_notimestamps(0))
+    for tag, f in (("f32", feats), ("fp16feat", feats.half().float())):
+        res = greedy_decode_tokens(m, f, init, always, first, -1, max_new_tokens=8, stop_on_eot=False)
+        assert res.tokens.tolist() == g[f"{name}_greedy_{tag}_tokens"].tolist(), tag
+    assert np.abs(res.last_logits.cpu().numpy()[:, lc[:32]] - g[f"{name}_fp16feat_last_logit_slices"]).max() < 3e-3
+    # App. C.3: the fp16-rounded sinusoid table is an explicit switch, pinned on both sides
+    from whisper_ipa_amd.whisper import ModelDimensions, Whisper
+    m16 = Whisper(ModelDimensions(**dims.__dict__), dtype=torch.float32, f32_split=split, sinusoid_rounding="fp16")
+    m16.load_weights(W)
+    f16 = m16.encoder(mel)
+    assert np.abs(f16.cpu().numpy()[:, rows][:, :, cols] - g[f"{name}_enc_fp16pos_slices"]).max() < 1e-3
+    d = float((f16 - feats).abs().max())
+    assert abs(d - float(g[f"{name}_enc_fp16pos_maxdiff"][0])) < 3e-4 and d > 2e-4

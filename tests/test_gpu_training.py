@@ -471,3 +471,146 @@ def test_small_width_gradients_match_oracle():
     assert abs(float(loss) - float(ref_loss)) < 1e-3  # north_star: loss within 1e-3 in fp32
     worst = max(((_rel(tr.g(n), ref[n]), n) for n in tr.names))
     assert worst[0] < 3e-3, worst
+
+
+TUNED = R.ModelDimensions(80, 1500, 768, 12, 1, 51865, 448, 768, 12, 2)
+
+
+def test_tuned_shape_32_clips_x_64_tokens_matches_oracle_and_takes_the_tuned_branches(f32_mode):
+    """the fine-tune step where it was tuned -- one rank's share of BASELINE.json configs[2], 32 clips x 64
+    target tokens at whisper-small width (bench.py --mode train's own batch; 1 encoder + 2 decoder layers so the CPU oracle's
+    autograd takes seconds).  At this shape training.py / wipa_gemm leave the paths the small tests exercise: the encoder's
+    48 000 x 768 float32 GEMMs run on 384 x 128 tiles, the 2048-token-row GEMMs are split along K, every input- and
+    weight-gradient GEMM reads K-major operands, the cross key|value pair is ONE [2d, d] projection.  The dispatch census
+    proves those branches ran; features, loss and every decoder gradient are compared with the oracle
+    (scripts/train_whisper_ipa.py:207-311)."""
+    import bench
+    from whisper_ipa_amd import ops
+    from whisper_ipa_amd.training import DecoderTrainer
+    from whisper_ipa_amd.whisper import ModelDimensions, Whisper
+
+    B, T = 32, 64
+    W = R.synthetic_weights(TUNED, seed=21)
+    mel, tokens, eot = bench.synthetic_train_batch(B, T, TUNED.n_mels, 0)
+    assert eot == EOT and tokens.shape == (B, T + 1)
+    names = [k for k in W if k.startswith("decoder.")]
+    leaves = {k: W[k].detach().clone().requires_grad_(True) for k in names}
+    Wl = dict(W)
+    Wl.update(leaves)
+    with torch.no_grad():
+        xa = R.encoder_forward(W, TUNED, mel)
+    ref_loss = R.loss_from_features(Wl, TUNED, xa, tokens, EOT)
+    ref = dict(zip(names, torch.autograd.grad(ref_loss, [leaves[k] for k in names])))
+
+    m = Whisper(ModelDimensions(**TUNED.__dict__), dtype=torch.float32, f32_split=(f32_mode == "split"))
+    m.load_weights(W)
+    tr = DecoderTrainer(m)
+    ops.gemm_dispatch_counts(reset=True)
+    feats = m.embed_audio(mel.cuda())
+    enc_counts = ops.gemm_dispatch_counts(reset=True)
+    loss, sum_ce, n_valid = tr.loss_and_grads(feats, tokens.cuda(), EOT)
+    torch.cuda.synchronize()
+    counts = ops.gemm_dispatch_counts(reset=True)
+    # ---- the tuned branches were the ones under test
+    assert enc_counts["tile384n"] >= 2, enc_counts           # out-proj and mlp2 over 48 000 rows, N = 768, float32
+    assert counts["split_k"] >= 2 * 10, counts               # token-row GEMMs (fwd + dgrad) and the weight gradients
+    assert counts["kmajor"] >= 2 * 10, counts                # dgrad: W as stored; wgrad: dy and x as stored
+    assert counts["tile384"] + counts["tile256"] >= 2, counts  # the [2d, d] cross key|value projection, one per layer
+    Mrows = B * T
+    assert Mrows % 32 == 0 and (B * 1500) % 32 == 0          # the conditions of the K-major path in _lin_bwd
+    # ---- parity with the oracle
+    err_f = (feats.cpu() - xa).abs().max().item()
+    assert err_f < 1e-3, err_f
+    assert int(n_valid) == int(R.loss_mask(tokens[:, 1:], EOT).sum())
+    assert abs(float(loss) - float(ref_loss)) < 1e-3, (float(loss), float(ref_loss))  # north_star: loss within 1e-3 in fp32
+    worst = max(((_rel(tr.g(n), ref[n]), n) for n in tr.names))
+    print(f"\ntuned shape [{f32_mode}]: feature err {err_f:.2e}, loss {float(loss):.5f} vs {float(ref_loss):.5f}, worst gradient {worst}, "
+          f"encoder dispatch {enc_counts}, step dispatch {counts}")
+    assert worst[0] < 3e-3, worst
+
+
+def test_bench_finetune_step_full_depth_loss_matches_oracle_and_batch_splits():
+    """The step `bench.py --mode train` times (whisper-small 12+12, seed-0 weights, its own seeded batch), compared with
+    something: (a) the loss on clips 0..3 equals the CPU oracle's compute_loss on the same weights / mel / token rows
+    (encoder included); (b) the 32-clip loss equals the valid-count-weighted mean of four 8-clip runs -- the batch-global
+    normalisation of scripts/train_whisper_ipa.py:256-261, and the 8-clip runs take the un-split GEMM paths, so the
+    split-K / wide-tile dispatch of the 32-clip step is checked against them end to end."""
+    import bench
+    from whisper_ipa_amd.training import DecoderTrainer
+    from whisper_ipa_amd.whisper import Whisper
+
+    B, T = 32, 64
+    dims, W = bench.synthetic_weights_small(0, "small")
+    mel, tokens, eot = bench.synthetic_train_batch(B, T, dims.n_mels, 0)
+    with torch.no_grad():
+        ref4 = float(R.compute_loss(W, R.DIMS["small"], mel[:4], tokens[:4], eot))
+    m = Whisper(dims, dtype=torch.float32)
+    m.load_weights(W)
+    tr = DecoderTrainer(m)
+    feats = m.embed_audio(mel.cuda())
+    tok = tokens.cuda()
+    loss4, _, _ = tr.loss_and_grads(feats[:4], tok[:4], eot)
+    assert abs(float(loss4) - ref4) < 1e-3, (float(loss4), ref4)
+    loss32, sum32, n32 = tr.loss_and_grads(feats, tok, eot)
+    g32 = tr.flat_g.clone()
+    parts, gsum = [], torch.zeros_like(g32)
+    for g in range(4):
+        l8, s8, n8 = tr.loss_and_grads(feats[8 * g: 8 * g + 8], tok[8 * g: 8 * g + 8], eot)
+        parts.append((float(s8), float(n8)))
+        gsum += tr.flat_g * n8  # each run divided by its own count
+    torch.cuda.synchronize()
+    tot_s, tot_n = sum(p[0] for p in parts), sum(p[1] for p in parts)
+    assert tot_n == float(n32)
+    assert abs(float(loss32) - tot_s / tot_n) < 2e-5 * abs(float(loss32)), (float(loss32), tot_s / tot_n)
+    gsum /= n32
+    rel = float((g32 - gsum).abs().max() / g32.abs().max())
+    print(f"\nbench fine-tune step: loss(4 clips) {float(loss4):.5f} vs oracle {ref4:.5f}; loss(32) {float(loss32):.5f}; "
+          f"32-clip gradient vs 4 x 8-clip gradients: max rel diff {rel:.2e}")
+    assert rel < 1e-4, rel
+
+
+def test_frozen_feature_cache_is_bit_identical_to_recomputing(f32_mode):
+    """the frozen encoder's output cached per clip in HBM (training.FrozenFeatureCache).
+    (a) features assembled from the cache -- computed earlier, in OTHER batches of other sizes -- equal embed_audio of the
+    batch bit for bit; (b) five training steps over overlapping clip subsets give bit-identical losses, gradients and
+    parameters with and without the cache; (c) hit / miss accounting, capacity spill (a clip beyond the capacity is
+    recomputed, never wrong).  Reference: scripts/train_whisper_ipa.py:187,223 (frozen, yet recomputed every step)."""
+    from whisper_ipa_amd.training import DecoderTrainer
+    from whisper_ipa_amd.whisper import ModelDimensions, Whisper
+
+    dims = R.ModelDimensions(80, 1500, 768, 12, 2, 51865, 448, 768, 12, 2)
+    W = R.synthetic_weights(dims, seed=17)
+    g = torch.Generator().manual_seed(3)
+    bank = (torch.randn(8, 3000, 80, generator=g) * 0.5).cuda()  # the mel of 8 "dataset clips"
+    rng = np.random.default_rng(11)
+    toks = torch.from_numpy(rng.integers(0, 50000, size=(8, 13))).long()
+    toks[:, :4] = torch.tensor([50258, 50259, 50359, 50363])
+    toks[:, -1] = EOT
+    toks[3, 9:] = EOT
+    steps = [(0, 1, 2, 3), (2, 3, 4, 5), (0, 5, 6, 7), (1, 2, 6, 7), (0, 1, 2, 3)]
+    split = f32_mode == "split"
+
+    def make():
+        m = Whisper(ModelDimensions(**dims.__dict__), dtype=torch.float32, f32_split=split)
+        m.load_weights({k: v.clone() for k, v in W.items()})
+        return m, DecoderTrainer(m, lr=1e-3)
+
+    m0, plain = make()
+    m1, cached = make()
+    cache = cached.enable_feature_cache(7)  # one clip short of the bank: clip 7 spills to recompute
+    for idx in steps:
+        idx = list(idx)
+        l0, _ = plain.train_step(bank[idx], toks[idx].cuda(), EOT)
+        need = cache.missing(idx)
+        mel_missing = bank[[i for i, f in zip(idx, need) if f]] if any(need) else None
+        feats_c = cache.assemble(idx, mel_missing)  # what train_step(clip_keys=...) uses
+        assert torch.equal(feats_c, m1.embed_audio(bank[idx])), idx
+        need2 = cache.missing(idx)
+        l1, _ = cached.train_step(bank[[i for i, f in zip(idx, need2) if f]] if any(need2) else None, toks[idx].cuda(), EOT, clip_keys=idx)
+        torch.cuda.synchronize()
+        assert float(l0) == float(l1), (idx, float(l0), float(l1))
+        assert torch.equal(plain.flat_g, cached.flat_g) and torch.equal(plain.flat_p, cached.flat_p), idx
+    assert len(cache.slots) == 7 and 7 not in cache.slots and cache.missing([7, 0]) == [True, False]
+    assert cache.misses > 0 and cache.hits > cache.misses
+    with pytest.raises(Exception):
+        cache.assemble([7, 0], None)  # clip 7 is not cached: its mel is required

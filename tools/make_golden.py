@@ -173,9 +173,128 @@ def golden_model():
     print("micro_model.npz written; greedy:", out["greedy_tokens"][:, 4:].tolist(), "min margin", out["greedy_margins"].min())
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# round 3: fixtures beyond MICRO dims -- whisper-small width, whisper-large-v3 dims (128 mels,
+# 51 866 tokens, 100 languages), a masked-CE GRADIENT fixture from the stand-in's autograd, the fp16-features decode path
+#  and the fp16-rounded sinusoid table (App. C.3).  One encoder + one decoder layer each, so the stand-in
+# runs in seconds and the fixtures stay small; seeds / clips are the oracle's generators.
+SMALL1 = R.ModelDimensions(80, 1500, 768, 12, 1, 51865, 448, 768, 12, 1)
+LARGE1 = R.ModelDimensions(128, 1500, 1280, 20, 1, 51866, 448, 1280, 20, 1)
+WIDE = {"small1": (SMALL1, 41, 99), "large1": (LARGE1, 43, 100)}  # name -> (dims, weight seed, languages)
+
+
+def framed_tokens(sp, lens, seed):
+    rng = np.random.default_rng(seed)
+    sot = list(sp.sot_sequence_including_notimestamps(0))
+    seqs = [sot + rng.integers(0, 50257, size=n).tolist() + [sp.eot] for n in lens]
+    L = max(len(s) for s in seqs)
+    return np.array([s + [sp.eot] * (L - len(s)) for s in seqs], dtype=np.int64)
+
+
+GRAD_SLICES = {  # oracle name -> (HF name, row slice, column slice)
+    "decoder.token_embedding.weight": ("model.decoder.embed_tokens.weight", "tok_rows", slice(0, 16)),
+    "decoder.positional_embedding": ("model.decoder.embed_positions.weight", slice(0, 12), slice(0, 16)),
+    "decoder.blocks.0.attn.query.weight": ("model.decoder.layers.0.self_attn.q_proj.weight", slice(0, 8), slice(0, 16)),
+    "decoder.blocks.0.cross_attn.key.weight": ("model.decoder.layers.0.encoder_attn.k_proj.weight", slice(0, 8), slice(0, 16)),
+    "decoder.blocks.0.cross_attn.value.bias": ("model.decoder.layers.0.encoder_attn.v_proj.bias", slice(0, 32), None),
+    "decoder.blocks.0.mlp1.weight": ("model.decoder.layers.0.fc1.weight", slice(0, 8), slice(0, 16)),
+    "decoder.blocks.0.mlp_ln.weight": ("model.decoder.layers.0.final_layer_norm.weight", slice(0, 32), None),
+    "decoder.ln.bias": ("model.decoder.layer_norm.bias", slice(0, 32), None),
+}
+
+
+def golden_wide():
+    out = {}
+    for name, (dims, seed, n_lang) in WIDE.items():
+        W = R.synthetic_weights(dims, seed=seed)
+        m = hf_model(dims, W)
+        sp = R.SpecialTokens.multilingual(n_lang)
+        clips = [R.synthetic_clip(2, 30.0), R.synthetic_clip(3, 7.0)]
+        mels = np.stack([R.log_mel_spectrogram(a, dims.n_mels) for a in clips])
+        out[f"{name}_mel_checksum"] = np.array([float(np.abs(mels).sum())])
+        tokens = framed_tokens(sp, (11, 6), seed)
+        out[f"{name}_tokens"] = tokens
+        tt = torch.from_numpy(tokens)
+        with torch.no_grad():
+            enc = m.model.encoder(torch.from_numpy(mels).transpose(1, 2)).last_hidden_state
+        rows = np.r_[0:3, 749:752, 1497:1500]
+        ecols = np.r_[0:24, dims.n_audio_state - 24:dims.n_audio_state]
+        out[f"{name}_enc_rows"], out[f"{name}_enc_cols"] = rows, ecols
+        out[f"{name}_enc_slices"] = enc[:, rows][:, :, ecols].numpy()
+        out[f"{name}_enc_stats"] = np.array([enc.mean().item(), enc.std().item(), enc.abs().sum().item()])
+        # teacher-forced logits, masked CE and its GRADIENT w.r.t. decoder parameters (stand-in autograd)
+        for p_ in m.parameters():
+            p_.requires_grad_(False)
+        leaves = {}
+        sd = dict(m.named_parameters())
+        for oname, (hname, _, _) in GRAD_SLICES.items():
+            sd[hname].requires_grad_(True)
+            leaves[oname] = sd[hname]
+        logits = m(encoder_outputs=(enc,), decoder_input_ids=tt[:, :-1]).logits
+        cols = np.r_[0:32, 220:224, 50250:50270, 50355:50370, dims.n_vocab - 8:dims.n_vocab]
+        out[f"{name}_logit_cols"] = cols
+        out[f"{name}_logit_slices"] = logits[:, :, cols].detach().numpy()
+        out[f"{name}_logit_stats"] = np.array([logits.mean().item(), logits.std().item(), logits.abs().max().item()])
+        tgt = tt[:, 1:]
+        mask = R.loss_mask(tgt, sp.eot)
+        ce = torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]), tgt.reshape(-1), reduction="none")
+        loss = (ce * mask.reshape(-1)).sum() / max(int(mask.sum()), 1)
+        out[f"{name}_loss"] = np.array([loss.item()])
+        grads = torch.autograd.grad(loss, list(leaves.values()))
+        tok_rows = np.unique(tokens[:, :-1])[:12]
+        out[f"{name}_grad_tok_rows"] = tok_rows
+        for (oname, (hname, rs, cs)), g in zip(GRAD_SLICES.items(), grads):
+            if isinstance(rs, str):
+                rs = tok_rows
+            sl = g[rs] if cs is None else g[rs][:, cs]
+            key = oname.replace(".", "__")
+            out[f"{name}_grad__{key}"] = sl.numpy()
+            out[f"{name}_gradnorm__{key}"] = np.array([float(g.norm())])
+        with torch.no_grad():
+            # language detection known answer at this vocabulary (99 / 100 languages)
+            lg = m(encoder_outputs=(enc,), decoder_input_ids=torch.full((2, 1), sp.sot)).logits[:, 0]
+            out[f"{name}_lang_tokens"] = (lg[:, sp.lang_first: sp.lang_first + sp.n_langs].argmax(-1) + sp.lang_first).numpy()
+            # greedy ids without a KV cache, on f32 features and on fp16-ROUNDED features (DecodingOptions.fp16=True of
+            # transcribe_single.py:49-52: the encoder output is cast to fp16 before cross-attention)
+            always, first = R.suppress_lists(sp)
+            sot = list(sp.sot_sequence_including_notimestamps(0))
+            for tag, feats in (("f32", enc), ("fp16feat", enc.half().float())):
+                toks = torch.tensor([sot, sot], dtype=torch.long)
+                margins = []
+                for i in range(8):
+                    l2 = m(encoder_outputs=(feats,), decoder_input_ids=toks).logits[:, -1].clone()
+                    if i == 0:
+                        l2[:, first] = float("-inf")
+                    l2[:, always] = float("-inf")
+                    t2 = torch.topk(l2, 2, dim=-1).values
+                    margins.append((t2[:, 0] - t2[:, 1]).numpy())
+                    toks = torch.cat([toks, l2.argmax(-1)[:, None]], dim=1)
+                out[f"{name}_greedy_{tag}_tokens"] = toks.numpy()
+                out[f"{name}_greedy_{tag}_margins"] = np.stack(margins, axis=1)
+                if tag == "fp16feat":
+                    out[f"{name}_fp16feat_last_logit_slices"] = l2[:, cols[:32]].numpy()
+            # mlx_whisper builds the encoder's sinusoid table in the load dtype (fp16) and set_dtype(float32)
+            # does not touch it [UPSTREAM-UNVERIFIED]: the encoder output with the table rounded to fp16
+            m.model.encoder.embed_positions.weight.copy_(R.sinusoids(dims.n_audio_ctx, dims.n_audio_state).half().float())
+            enc16 = m.model.encoder(torch.from_numpy(mels).transpose(1, 2)).last_hidden_state
+            out[f"{name}_enc_fp16pos_slices"] = enc16[:, rows][:, :, ecols].numpy()
+            out[f"{name}_enc_fp16pos_maxdiff"] = np.array([(enc16 - enc).abs().max().item()])
+        print(name, "done: loss", float(loss), "greedy", out[f"{name}_greedy_f32_tokens"][:, 4:].tolist(),
+              "fp16-feature ids equal:", bool((out[f"{name}_greedy_f32_tokens"] == out[f"{name}_greedy_fp16feat_tokens"]).all()),
+              "fp16 sinusoids move the features by", float(out[f"{name}_enc_fp16pos_maxdiff"][0]))
+    path = os.path.join(OUT, "wide_model.npz")
+    np.savez_compressed(path, **{k: (v.astype(np.float32) if v.dtype == np.float64 and v.size > 8 else v) for k, v in out.items()})
+    print("wide_model.npz written,", os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    golden_mel()
-    golden_model()
+    which = sys.argv[1:] or ["mel", "micro", "wide"]
+    if "mel" in which:
+        golden_mel()
+    if "micro" in which:
+        golden_model()
+    if "wide" in which:
+        golden_wide()

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libwipa.so")
 WIPA_F32, WIPA_BF16, WIPA_FP8_E4M3 = 0, 1, 2
 ENC_GLOBAL, ENC_PER_LAYER = 7, 14
 DEC_GLOBAL, DEC_PER_LAYER, DEC_FP8_PER_LAYER = 4, 20, 6
+GEMM_DISPATCH = ("tile128", "tile256", "tile384", "tile384n", "tile256p", "skinny", "skinny_fp8", "skinny_ln", "kmajor", "split_k")
 
 c_void_p, c_int, c_int64, c_size_t, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
 
@@ -97,6 +98,7 @@ SIGNATURES = {
     "wipa_logmel": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "wipa_mel_pad_cast": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "wipa_gemm": (c_int, [_P(GemmDesc), c_void_p]),
+    "wipa_gemm_dispatch_counts": (c_int, [_P(c_int64), c_int, c_int]),
     "wipa_layernorm": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_int, c_int,
                                c_float, c_void_p]),
     "wipa_add_slabs_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_void_p,

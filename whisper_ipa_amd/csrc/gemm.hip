@@ -1578,6 +1578,21 @@ int launch_kmajor(const GemmParams& p, hipStream_t s) {  // float32 -> float32 w
 
 int wipa_gemm_init() { return init_attrs(); }
 
+// Dispatch census (wipa_gemm_dispatch_counts): which kernel family each wipa_gemm call went to.  A measurement / test aid --
+// the parity tests of the fine-tune step assert that the shape-dependent branches they mean to cover were really taken.
+namespace {
+std::atomic<int64_t> g_dispatch[WIPA_GEMM_DISPATCH_CLASSES];
+inline void count_dispatch(int cls) { g_dispatch[cls].fetch_add(1, std::memory_order_relaxed); }
+}  // namespace
+
+extern "C" int wipa_gemm_dispatch_counts(int64_t* out, int n, int reset) {
+    WIPA_REQUIRE(n >= 0 && n <= WIPA_GEMM_DISPATCH_CLASSES && (out || n == 0), "wipa_gemm_dispatch_counts: n=%d (0..%d)", n, WIPA_GEMM_DISPATCH_CLASSES);
+    for (int i = 0; i < n; ++i) out[i] = g_dispatch[i].load(std::memory_order_relaxed);
+    if (reset)
+        for (int i = 0; i < WIPA_GEMM_DISPATCH_CLASSES; ++i) g_dispatch[i].store(0, std::memory_order_relaxed);
+    return WIPA_OK;
+}
+
 extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
     WIPA_REQUIRE(d && (d->A || d->ln_x) && d->W && d->C, "wipa_gemm: null operand");
     WIPA_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "wipa_gemm: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
@@ -1662,10 +1677,15 @@ extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
                      "wipa_gemm: a K-major operand needs a row count that is a multiple of 4 (M=%d N=%d)", d->M, d->N);
         p.a_trans = d->a_trans ? 1 : 0;
         p.w_trans = d->w_trans ? 1 : 0;
+        count_dispatch(WIPA_GEMM_KMAJOR);
+        if (p.k_slices > 1) count_dispatch(WIPA_GEMM_SPLIT_K);
         return launch_kmajor(p, s);
     }
-    if (d->w_dtype == WIPA_FP8_E4M3)
+    if (p.k_slices > 1) count_dispatch(WIPA_GEMM_SPLIT_K);
+    if (d->w_dtype == WIPA_FP8_E4M3) {
+        count_dispatch(WIPA_GEMM_SKINNY_FP8);
         return d->out_dtype == WIPA_BF16 ? launch_skinny_w8<__bf16>(p, s) : launch_skinny_w8<float>(p, s);
+    }
     if (d->ln_x) {  // LayerNorm prologue: A is computed in the kernel from the f32 rows ln_x
         WIPA_REQUIRE(d->ln_w && d->ln_b && d->ln_ldx >= d->K && d->ln_ldx % 4 == 0 && ((uintptr_t)d->ln_x % 16) == 0,
                      "wipa_gemm: LayerNorm prologue needs ln_w, ln_b and 16-byte aligned rows of at least K floats");
@@ -1674,6 +1694,7 @@ extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
                      SKINNY_STREAM_MAX_M);
         WIPA_REQUIRE(!(d->in_dtype == WIPA_F32 && d->out_dtype == WIPA_BF16), "wipa_gemm: LayerNorm prologue: f32 -> bf16 is not built");
         p.ln_x = d->ln_x; p.ln_w = d->ln_w; p.ln_b = d->ln_b; p.ln_ldx = d->ln_ldx; p.ln_eps = d->ln_eps;
+        count_dispatch(WIPA_GEMM_SKINNY_LN);
         if (d->in_dtype == WIPA_BF16)
             return d->out_dtype == WIPA_BF16 ? launch_skinny_ln<__bf16, __bf16>(p, s) : launch_skinny_ln<__bf16, float>(p, s);
         return launch_skinny_ln<float, float>(p, s);
@@ -1681,6 +1702,7 @@ extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
     // weight-streaming kernel: M <= 256 rows, or up to 1024 when the caller marks them as decode rows (prompt prefill)
     const bool skinny_shape = d->M <= SKINNY_MAX_M || (d->stream_weights && d->M <= SKINNY_STREAM_MAX_M);
     if (skinny_shape && !(d->in_dtype == WIPA_F32 && d->out_dtype == WIPA_BF16)) {
+        count_dispatch(WIPA_GEMM_SKINNY);
         if (d->in_dtype == WIPA_BF16)
             return d->out_dtype == WIPA_BF16 ? launch_skinny<__bf16, __bf16>(p, s) : launch_skinny<__bf16, float>(p, s);
         return launch_skinny<float, float>(p, s);
@@ -1720,19 +1742,24 @@ extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
         const double e384n = fill(tm384 * ((d->N + 127) / 128));
         if (d->in_dtype == WIPA_F32 && e384n >= 1.10 * (e384 > e256 ? e384 : e256)) use384 = narrow = true;
     }
-    if (big && force_tile == 2568 && d->in_dtype == WIPA_BF16 && d->K % 128 == 0)  // phase-interleaved 256 x 256 (A/B runs)
+    if (big && force_tile == 2568 && d->in_dtype == WIPA_BF16 && d->K % 128 == 0) {  // phase-interleaved 256 x 256 (A/B runs)
+        count_dispatch(WIPA_GEMM_TILE256P);
         return d->out_dtype == WIPA_BF16 ? launch256p<__bf16>(p, s) : launch256p<float>(p, s);
+    }
     if (big && use384) {
+        count_dispatch(narrow ? WIPA_GEMM_TILE384N : WIPA_GEMM_TILE384);
         if (narrow) return d->out_dtype == WIPA_BF16 ? launch384n<float, __bf16>(p, s) : launch384n<float, float>(p, s);
         if (d->in_dtype == WIPA_BF16)
             return d->out_dtype == WIPA_BF16 ? launch384<__bf16, __bf16>(p, s) : launch384<__bf16, float>(p, s);
         return d->out_dtype == WIPA_BF16 ? launch384<float, __bf16>(p, s) : launch384<float, float>(p, s);
     }
     if (big) {
+        count_dispatch(WIPA_GEMM_TILE256);
         if (d->in_dtype == WIPA_BF16)
             return d->out_dtype == WIPA_BF16 ? launch256<__bf16, __bf16>(p, s) : launch256<__bf16, float>(p, s);
         return d->out_dtype == WIPA_BF16 ? launch256<float, __bf16>(p, s) : launch256<float, float>(p, s);
     }
+    count_dispatch(WIPA_GEMM_TILE128);
     if (d->in_dtype == WIPA_BF16) {
         return d->out_dtype == WIPA_BF16 ? launch<__bf16, __bf16>(p, s) : launch<__bf16, float>(p, s);
     }

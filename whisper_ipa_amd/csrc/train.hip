@@ -87,10 +87,11 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict_
     }
 }
 
-// out[i] = scale * sum_k slabs[k * stride + i] (+ residual[i]): the epilogue of a split-K GEMM whose slices could not apply it
+// out[i] = scale * sum_k slabs[k * stride + i] (+ residual[i]): the epilogue of a split-K GEMM whose slices could not apply it.
+// residual MAY alias out (in-place accumulation of an input gradient): neither pointer is __restrict__, and every thread
+// reads residual[i..i+3] before it stores out[i..i+3].
 __global__ __launch_bounds__(256) void sum_slabs_ex_kernel(const float* __restrict__ slabs, int n_slabs, int64_t stride,
-                                                           float* __restrict__ out, int64_t n, const float* __restrict__ residual,
-                                                           float scale) {
+                                                           float* out, int64_t n, const float* residual, float scale) {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i + 3 < n) {
         f32x4 t = *reinterpret_cast<const f32x4*>(slabs + i);

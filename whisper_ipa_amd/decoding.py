@@ -242,6 +242,48 @@ def greedy_decode_tokens(model, audio_features: torch.Tensor, initial_tokens: Se
     return GreedyTokens(toks, n_steps, slp, last_logits)
 
 
+def forced_decode_logits(model, audio_features: torch.Tensor, tokens: np.ndarray, n_init: int, suppress_always: Sequence[int],
+                         suppress_first: Sequence[int], eot: int, use_graph: bool = True):
+    """The KV-cached decode-step path (prompt prefill + replayed step graph -- the kernels greedy_decode_tokens runs) driven
+    along a GIVEN token history: after every step the greedy choice is read and then overwritten with ``tokens[:, p + 1]``.
+    ``tokens`` [B, n_init + n_steps] int (host).  Returns (step logits [B, n_steps, V] f32 on the device, unfiltered, and the
+    path's own greedy choices [B, n_steps] int64 on the host).  A measurement aid: with the history of an f32 reference it
+    gives the logit error of a low-precision model at every step, independent of where its own greedy ids would part
+    (DecodingTask._main_loop, transcribe_single.py:55)."""
+    L = _lib.lib()
+    pk = model.packed()
+    tokens = np.asarray(tokens)
+    B, total_len = tokens.shape
+    assert B == audio_features.shape[0] and 2 <= n_init < total_len <= model.dims.n_text_ctx
+    n_steps = total_len - n_init
+    st = _state_for(model, B)
+    m_always = _mask(model, suppress_always)
+    m_first = _mask(model, list(suppress_always) + list(suppress_first))
+    init = (C.c_int32 * n_init)(*[int(t) for t in tokens[0, :n_init]])
+    assert (tokens[:, :n_init] == tokens[0, :n_init]).all(), "one prompt for all rows"
+    V = model.dims.n_vocab
+    with on_stream() as s:
+        forced = torch.from_numpy(tokens.astype(np.int32)).to(model.device)
+        trace = torch.empty(B, n_steps, V, dtype=torch.float32, device=model.device)
+        chosen = torch.empty(B, n_steps, dtype=torch.int32, device=model.device)
+        feats = audio_features.to(device=model.device, dtype=model.dtype).contiguous()
+        _lib.check(L.wipa_decoder_set_audio(C.byref(pk["cfg"]), pk["dec_tab"], ptr(feats), ptr(st.blob), B, sptr(s)),
+                   "wipa_decoder_set_audio")
+        _lib.check(L.wipa_decoder_begin(C.byref(pk["cfg"]), ptr(st.blob), B, init, n_init, sptr(s)), "wipa_decoder_begin")
+        _lib.check(L.wipa_decoder_prefill(C.byref(pk["cfg"]), pk["dec_tab"], ptr(st.blob), B, n_init, eot, ptr(m_first),
+                                          ptr(m_always), int(use_graph), sptr(s)), "wipa_decoder_prefill")
+        for i in range(n_steps):
+            p = n_init + i  # the token position the last step has just filled
+            trace[:, i].copy_(st.logits)
+            chosen[:, i].copy_(st.tokens[:, p])
+            st.tokens[:, p].copy_(forced[:, p])
+            if i + 1 < n_steps:
+                _lib.check(L.wipa_decoder_run(C.byref(pk["cfg"]), pk["dec_tab"], ptr(st.blob), B, n_init, eot, ptr(m_first),
+                                              ptr(m_always), 1, int(use_graph), sptr(s)), "wipa_decoder_run")
+        out_chosen = chosen.cpu().numpy().astype(np.int64)
+    return trace, out_chosen
+
+
 def detect_language(model, audio_features: torch.Tensor, tokenizer: Tokenizer):
     """Whisper.detect_language (train_whisper_ipa.py:339 via language=None): one decoder pass on
     [sot]; every logit but the language tokens masked; argmax.  Returns (language token ids [B], probs)."""

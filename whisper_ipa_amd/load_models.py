@@ -86,8 +86,9 @@ def save_safetensors(path: str, flat: Dict[str, torch.Tensor]) -> None:
     save_file({k: v.detach().to("cpu").contiguous() for k, v in flat.items()}, path)
 
 
-def load_model(path_or_name: str, dtype: torch.dtype = torch.float32) -> Whisper:
-    """Local directory -> Whisper.  Raises with a clear message for hub names (offline)."""
+def load_model(path_or_name: str, dtype: torch.dtype = torch.float32, sinusoid_rounding: str = "f32") -> Whisper:
+    """Local directory -> Whisper.  Raises with a clear message for hub names (offline).
+    ``sinusoid_rounding="fp16"`` reproduces mlx_whisper's fp16-built encoder sinusoid table (Whisper.__init__)."""
     if not os.path.isdir(path_or_name):
         raise FileNotFoundError(
             f"load_model: '{path_or_name}' is not a local directory. The reference downloads hub names "
@@ -109,7 +110,7 @@ def load_model(path_or_name: str, dtype: torch.dtype = torch.float32) -> Whisper
             break
     if weights is None:
         raise FileNotFoundError(f"load_model: no weights.safetensors / model.safetensors in {path_or_name}")
-    model = Whisper(dims, dtype=dtype)
+    model = Whisper(dims, dtype=dtype, sinusoid_rounding=sinusoid_rounding)
     model.load_weights(weights)
     return model
 

@@ -42,6 +42,14 @@ def gemm(A: torch.Tensor, W: torch.Tensor, C_out: torch.Tensor, *, M: int, N: in
     return C_out
 
 
+def gemm_dispatch_counts(reset: bool = False) -> dict:
+    """wipa_gemm_dispatch_counts: {kernel family: calls since the last reset} (a test / measurement aid)."""
+    n = len(_lib.GEMM_DISPATCH)
+    buf = (C.c_int64 * n)()
+    _lib.check(_lib.lib().wipa_gemm_dispatch_counts(buf, n, int(reset)), "wipa_gemm_dispatch_counts")
+    return dict(zip(_lib.GEMM_DISPATCH, (int(v) for v in buf)))
+
+
 def linear(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = 0,
            residual: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None, f32_split: bool = False) -> torch.Tensor:
     """x [M,K] @ W[N,K]^T (+bias, gelu, +residual) -> [M,N]."""

@@ -33,6 +33,67 @@ def _ceil(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
+class FrozenFeatureCache:
+    """HBM-resident cache of the FROZEN encoder's output, keyed by clip (dataset index).
+
+    The reference recomputes ``model.embed_audio(mel)`` in every training step although the encoder is frozen
+    (scripts/train_whisper_ipa.py:187,223): its output is a pure function of the clip.  whisper-small
+    features are 1500 x 768 f32 = 4.6 MB per clip, so the 7 000 training clips of data/v2_filtered are 32 GB of a 288 GB
+    HBM: keep them.  A clip's features are computed once, by the same kernels, and are bit-identical whatever batch they are
+    computed in (tests/test_gpu_training.py), so training with the cache gives bit-identical losses and parameters.
+    Clips beyond ``max_clips`` are simply recomputed every time (spill to recompute, no eviction).  The cache must be
+    dropped when the encoder weights change (``clear``); DecoderTrainer never touches them."""
+
+    def __init__(self, model: Whisper, max_clips: int):
+        d = model.dims
+        self.model, self.max_clips = model, int(max_clips)
+        self.row_shape = (d.n_audio_ctx, d.n_audio_state)
+        self.slots: Dict[int, int] = {}
+        self.store: Optional[torch.Tensor] = None  # [max_clips, 1500, d] f32, allocated on first use
+        self.hits = self.misses = 0
+
+    @staticmethod
+    def clips_that_fit(model: Whisper, fraction_of_free: float = 0.5) -> int:
+        free, _ = torch.cuda.mem_get_info(model.device)
+        return int(free * fraction_of_free) // (model.dims.n_audio_ctx * model.dims.n_audio_state * 4)
+
+    def clear(self) -> None:
+        self.slots.clear()
+        self.hits = self.misses = 0
+
+    def missing(self, keys) -> List[bool]:
+        """per key: True when the clip's features are not cached (its audio / mel is needed)"""
+        return [int(k) not in self.slots for k in keys]
+
+    def assemble(self, keys, mel_of_missing: Optional[torch.Tensor]) -> torch.Tensor:
+        """features [B, 1500, d] f32 for ``keys``; ``mel_of_missing`` [n_missing, 3000, n_mels] holds the mel of the keys
+        for which missing() is True, in order (None when there are none)."""
+        keys = [int(k) for k in keys]
+        miss_pos = [i for i, k in enumerate(keys) if k not in self.slots]
+        n_miss = 0 if mel_of_missing is None else mel_of_missing.shape[0]
+        if n_miss != len(miss_pos):
+            raise _lib.WipaError(f"FrozenFeatureCache: {len(miss_pos)} clips are not cached but the mel of {n_miss} was given")
+        with on_stream():
+            out = torch.empty(len(keys), *self.row_shape, dtype=torch.float32, device=self.model.device)
+            if miss_pos:
+                fresh = self.model.embed_audio(mel_of_missing)
+                for j, i in enumerate(miss_pos):
+                    out[i].copy_(fresh[j])
+                    k = keys[i]
+                    if k not in self.slots and len(self.slots) < self.max_clips:
+                        if self.store is None:
+                            self.store = torch.empty(self.max_clips, *self.row_shape, dtype=torch.float32, device=self.model.device)
+                        self.slots[k] = len(self.slots)
+                        self.store[self.slots[k]].copy_(fresh[j])
+            hit_pos = [i for i in range(len(keys)) if i not in set(miss_pos)]
+            if hit_pos:
+                idx = torch.tensor([self.slots[keys[i]] for i in hit_pos], dtype=torch.int64, device=self.model.device)
+                out[torch.tensor(hit_pos, dtype=torch.int64, device=self.model.device)] = self.store.index_select(0, idx)
+        self.hits += len(hit_pos)
+        self.misses += len(miss_pos)
+        return out
+
+
 class DecoderTrainer:
     def __init__(self, model: Whisper, lr: float = 1e-5, max_grad_norm: float = 1.0, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.01, f32_split: Optional[bool] = None):
@@ -92,6 +153,17 @@ class DecoderTrainer:
         self._colsum_ws = None  # partial sums of the chunked bias-gradient reduction (wipa_colsum)
         self._dw_slabs = None   # split-K partial weight gradients (wipa_gemm k_slices + wipa_sum_slabs)
         self._mm_slabs = None   # split-K partial outputs of the token-row GEMMs (_mm)
+        self.feature_cache: Optional[FrozenFeatureCache] = None  # enable_feature_cache()
+
+    def feature_cache_capacity_default(self) -> int:
+        return FrozenFeatureCache.clips_that_fit(self.model)
+
+    def enable_feature_cache(self, max_clips: Optional[int] = None) -> "FrozenFeatureCache":
+        """Keep the frozen encoder's output per clip in HBM (FrozenFeatureCache); ``max_clips`` defaults to what half of the
+        free device memory holds."""
+        n = FrozenFeatureCache.clips_that_fit(self.model) if max_clips is None else int(max_clips)
+        self.feature_cache = FrozenFeatureCache(self.model, max(0, n))
+        return self.feature_cache
 
     # ---- views into the flat buffers
     def p(self, name: str) -> torch.Tensor:
@@ -397,10 +469,15 @@ class DecoderTrainer:
         self.model._invalidate()  # fused inference tables are rebuilt lazily from the updated weights
         self.step_count += 1
 
-    def train_step(self, mel: torch.Tensor, tokens: torch.Tensor, eot: int, group=None):
+    def train_step(self, mel: Optional[torch.Tensor], tokens: torch.Tensor, eot: int, group=None, clip_keys=None):
         """train_whisper_ipa.py:266-311: encoder forward (frozen), loss + grads, clip, AdamW.
-        Returns (loss as a device scalar, dict of clipped gradients)."""
-        feats = self.model.embed_audio(mel)
+        Returns (loss as a device scalar, dict of clipped gradients).
+        ``clip_keys`` (one hashable int per clip, e.g. the dataset index) with an enabled feature cache: ``mel`` holds only the
+        clips ``feature_cache.missing(clip_keys)`` marks (or is None when every clip is cached); the others come from HBM."""
+        if clip_keys is not None and self.feature_cache is not None:
+            feats = self.feature_cache.assemble(clip_keys, mel)
+        else:
+            feats = self.model.embed_audio(mel)
         loss, _, _ = self.loss_and_grads(feats, tokens, eot, group)
         self.apply_update()
         return loss, self.grads()

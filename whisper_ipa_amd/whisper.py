@@ -116,10 +116,19 @@ class _Part:
 
 
 class Whisper:
-    def __init__(self, dims: ModelDimensions, dtype: torch.dtype = torch.float32, f32_split: bool = False):
+    def __init__(self, dims: ModelDimensions, dtype: torch.dtype = torch.float32, f32_split: bool = False,
+                 sinusoid_rounding: str = "f32"):
         """``f32_split`` (float32 models only): let the large GEMMs and the encoder attention take every f32 product as
         split-bf16 MFMA terms (about twice as fast, ~5e-6 relative error per dot product).  Off by default: the reference
-        computes in true float32 (train_whisper_ipa.py:505, transcribe_single.py:13)."""
+        computes in true float32 (train_whisper_ipa.py:505, transcribe_single.py:13).
+        ``sinusoid_rounding``: "f32" (default) adds the encoder's sinusoid table as computed in float32, which is what the
+        published algorithm does; "fp16" rounds the table to fp16 first -- SURVEY.md App. C.3: mlx_whisper builds
+        ``_positional_embedding`` in the load dtype (fp16) and ``set_dtype(float32)`` does not touch the private attribute
+        [UPSTREAM-UNVERIFIED], so a reference run may carry the rounded table (features move by ~1e-3).  The choice is
+        explicit here and in the CPU checker, and both settings are pinned by golden fixtures (tests/golden/wide_model.npz)."""
+        if sinusoid_rounding not in ("f32", "fp16"):
+            raise _lib.WipaError(f"sinusoid_rounding must be 'f32' or 'fp16', got {sinusoid_rounding!r}")
+        self.sinusoid_rounding = sinusoid_rounding
         self.dims = dims
         self.dtype = dtype
         self.f32_split = bool(f32_split)
@@ -136,7 +145,10 @@ class Whisper:
         self.decoder = _Part(self, "decoder")
         self.training = False
         with on_stream():
-            self._enc_pos = sinusoids(dims.n_audio_ctx, dims.n_audio_state).to(self.device)
+            pos = sinusoids(dims.n_audio_ctx, dims.n_audio_state)
+            if sinusoid_rounding == "fp16":
+                pos = pos.to(torch.float16).to(torch.float32)
+            self._enc_pos = pos.to(self.device)
 
     # ---- mlx.nn.Module-like surface ------------------------------------------------
     @property
