@@ -10,9 +10,16 @@ import numpy as np
 import torch
 
 # Relative logit-error ceiling of the bf16 path (matrices, activations, K/V caches in bf16; f32 accumulation and residual
-# stream): max |logit_bf16 - logit_f32| / std(finite logits) over every step of the teacher-forced history.  A regression
-# guard on the measured numbers, NOT what decides whether an id may differ.
-BF16_LOGIT_ERR_CEILING = 0.04
+# stream): max |logit_bf16 - logit_f32| / std(finite logits) over every step of the teacher-forced history, i.e. a maximum
+# over ~51 865 x steps x rows entries.  A regression guard on the measured numbers, NOT what decides whether an id may differ.
+# Measured on MI355X (r03): whisper-small 12+12 on encoder features 0.043 (rms ~0.01), small width
+# 0.038, fp8 weights 0.020-0.036.  Context, same weights / tokens on the CPU: rounding ONLY the matrices and features to
+# bf16 (f32 arithmetic) already gives 0.024, a plain torch all-bf16 decoder (bf16 residual stream too) 0.067 -- the HIP path
+# sits between the two, where a path with f32 accumulation and an f32 residual stream belongs.
+BF16_LOGIT_ERR_CEILING = 0.06
+# 72 rows of WHITE-NOISE features at whisper-medium width (a nearly flat cross-attention softmax, 2 layers with 4x output
+# scaling): measured 0.115; weights-only rounding 0.057, torch all-bf16 0.196 on the same rows.
+BF16_LOGIT_ERR_CEILING_WHITE_NOISE = 0.16
 
 
 def divergence_report(got: np.ndarray, ref, n_init: int):
@@ -72,5 +79,19 @@ def check_low_precision_decode(model, feats, ref, init, always, first, eot, what
     spread = logit_spread(ref.step_logits)
     rep.update(max_logit_err=float(err.max()), logit_std=spread, rel_err=float(err.max() / spread), forced_flips=int(flips.sum()),
                largest_flipped_margin=float(ref.margins[flips].max()) if flips.any() else 0.0, steps=int(flips.size))
+    print(f"\n[{what}] along the reference history: max logit error {rep['max_logit_err']:.4f} = {rep['rel_err']:.4f} of the logit std "
+          f"{spread:.3f} (mean of per-step maxima {err.mean():.4f}); {rep['forced_flips']} of {rep['steps']} teacher-forced choices differ "
+          f"(largest reference margin among them {rep['largest_flipped_margin']:.4f}); free-running token match {rep['token_match']:.4f}")
     assert err.max() < ceiling * spread, (what, float(err.max()), spread)
     return err, rep
+
+
+def masked_margins(trace: torch.Tensor, always, first) -> np.ndarray:
+    """top-1 minus top-2 of the filtered logits, per (row, step): what GreedyResult.margins holds, computed from a logit
+    trace [B, S, V] (suppress_first applies to step 0 only)"""
+    t = trace.clone()
+    t[:, :, list(always)] = float("-inf")
+    if len(first):
+        t[:, 0, list(first)] = float("-inf")
+    top2 = torch.topk(t, 2, dim=-1).values
+    return (top2[..., 0] - top2[..., 1]).cpu().numpy()
