@@ -126,6 +126,11 @@ typedef struct wipa_gemm_desc {
      * (weight gradient) without a transposed copy: nn.value_and_grad at scripts/train_whisper_ipa.py:284. */
     int32_t a_trans;
     int32_t w_trans;
+    /* fp8 ACTIVATIONS x fp8 weights on the block-scaled fp8 matrix instruction (BASELINE.json configs[4]: "CDNA4 fp8 MFMA").
+     * in_dtype = WIPA_FP8_E4M3: A [M, K] and W [N, K] both hold OCP e4m3fn codes (lda / ldw in bytes = elements), the values
+     * are code * a_scale[m] and code * w_scale[n] (power-of-two scales from wipa_layernorm_fp8 / wipa_rowquant_fp8 and the
+     * weight quantiser); K a multiple of 128.  256 x 256 tile kernel, every epilogue option except k_slices. */
+    const float* a_scale;
 } wipa_gemm_desc;
 int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t s);
 /* Dispatch census (measurement / test aid, no reference counterpart): how many wipa_gemm calls of this process went to each
@@ -143,7 +148,8 @@ enum {
     WIPA_GEMM_SKINNY_LN = 7, /* ... with the LayerNorm prologue */
     WIPA_GEMM_KMAJOR = 8,    /* a_trans / w_trans operands (128 x 128 kernel) */
     WIPA_GEMM_SPLIT_K = 9,   /* calls with k_slices > 1 (counted in addition to their kernel family) */
-    WIPA_GEMM_DISPATCH_CLASSES = 10
+    WIPA_GEMM_TILE_FP8 = 10, /* fp8 x fp8 on v_mfma_scale_f32_16x16x128_f8f6f4 (in_dtype = WIPA_FP8_E4M3) */
+    WIPA_GEMM_DISPATCH_CLASSES = 11
 };
 int wipa_gemm_dispatch_counts(int64_t* out, int n, int reset);
 
@@ -151,6 +157,14 @@ int wipa_gemm_dispatch_counts(int64_t* out, int n, int reset);
  * nn.LayerNorm(eps=1e-5) rows of width D (attn_ln, cross_attn_ln, mlp_ln, ln_post, ln). */
 int wipa_layernorm(const void* x, int x_dtype, int64_t ldx, void* y, int y_dtype, int64_t ldy, const float* w,
                    const float* b, int rows, int D, float eps, wipa_stream_t s);
+
+/* fp8 activations (cfg.enc_act_fp8): y = e4m3fn codes of LayerNorm(x) [rows, D] bytes (row stride ldy) with ONE power-of-two
+ * scale per row, y_scale[r] = the smallest power of two with max|LN(x)[r,:]| / y_scale <= 448; value = code * y_scale[r].
+ * x f32 rows; D a multiple of 4. */
+int wipa_layernorm_fp8(const float* x, int64_t ldx, void* y, int64_t ldy, float* y_scale, const float* w, const float* b, int rows,
+                       int D, float eps, wipa_stream_t s);
+/* the same row quantisation of an existing activation matrix x [rows, D] (x_dtype WIPA_BF16 or WIPA_F32; D a multiple of 8). */
+int wipa_rowquant_fp8(const void* x, int x_dtype, int64_t ldx, void* y, int64_t ldy, float* y_scale, int rows, int D, wipa_stream_t s);
 
 /* Decode-step fusion: x[r,:] += sum_s slabs[s][r,:] (fixed order s = 0..n_slabs-1; x f32, in place),
  * then y = LayerNorm(x).  slabs are the k_slices partial outputs of the preceding residual GEMM. */
@@ -318,6 +332,12 @@ typedef struct wipa_model_cfg {
                           * tile GEMM over B*1500 rows); wipa_decoder_logits refuses an fp8 table. */
     int32_t weights_generation; /* bumped by the caller whenever any pointer of a weight table changes: part of the key of
                                  * the cached decode-step graphs (a freed table's host address may be reused) */
+    int32_t enc_act_fp8; /* bf16 models with an fp8 encoder tail (WIPA_ENC_FP8_PER_LAYER): 1 = the encoder's q|k, value, mlp1 and
+                          * mlp2 projections (11/12 of its GEMM FLOPs) run fp8 x fp8 on the block-scaled fp8 MFMA: LayerNorm outputs
+                          * and the GELU output are quantised per row (wipa_layernorm_fp8 / wipa_rowquant_fp8), the weights are the
+                          * e4m3 codes.  Attention, the out projection, the residual stream and everything downstream stay as
+                          * they are.  0 = bf16 activations on the dequantised weights (the default; what the parity tests call
+                          * "the bf16 model on quantised weights"). */
 } wipa_model_cfg;
 
 /* Encoder weight table (const void* [WIPA_ENC_GLOBAL + WIPA_ENC_PER_LAYER * n_layer]):
@@ -329,6 +349,10 @@ typedef struct wipa_model_cfg {
  *              10 mlp1.w [4d,d] 11 mlp1.b 12 mlp2.w [d,4d] 13 mlp2.b */
 #define WIPA_ENC_GLOBAL 7
 #define WIPA_ENC_PER_LAYER 14
+/* fp8 encoder tables (cfg.enc_act_fp8 = 1) append, after the n_layer regular blocks, per layer:
+ *   0 qk codes [2d,d] u8  1 qk scale [2d] f32  2 value codes [d,d]  3 value scale [d]  4 mlp1 codes [4d,d]  5 mlp1 scale [4d]
+ *   6 mlp2 codes [d,4d]  7 mlp2 scale [d]      (value = code * scale[row]) */
+#define WIPA_ENC_FP8_PER_LAYER 8
 /* Decoder weight table (const void* [WIPA_DEC_GLOBAL + WIPA_DEC_PER_LAYER * n_layer]):
  *   0 token_embedding [V, d] T   1 positional_embedding [n_text_ctx, d] f32   2 ln.w   3 ln.b
  *   per layer: 0 attn_ln.w 1 attn_ln.b 2 qkv.w [3d,d] T 3 qkv.b [3d] (key third zero) 4 out.w 5 out.b

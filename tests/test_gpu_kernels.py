@@ -442,6 +442,59 @@ def test_decode_cross_block(dtype, B, H, Tk):
     assert _rel(out, ref) < (2e-5 if dtype == torch.float32 else 2e-2), _rel(out, ref)
 
 
+@pytest.mark.parametrize("B,H,Tk,n_slabs", [(64, 12, 1500, 2), (5, 6, 1500, 1), (3, 12, 200, 4), (2, 8, 40, 2), (7, 12, 191, 3)])
+def test_decode_cross_block_lds_staged_stream(monkeypatch, B, H, Tk, n_slabs):
+    """Round 3: the cross block whose first K / V rows travel to LDS by LDS-DMA under the prologue
+    (decode_cross_block_pre_kernel, WIPA_CROSS_PRE = 4 / 6; default for grids that are resident at once).  Against float64,
+    against the plain kernel (WIPA_CROSS_PRE=0: bit-identical with 4 row groups per step -- the same summation order -- and
+    equal up to the softmax grouping with 6), ragged key counts (Tk not a multiple of a step, shorter than one step of all
+    four waves), 1..4 slabs."""
+    import ctypes as C
+
+    from whisper_ipa_amd import _lib
+    from whisper_ipa_amd.runtime import dt_code, on_stream, ptr, sptr
+
+    L = _lib.lib()
+    dtype = torch.bfloat16
+    d = H * 64
+    g = torch.Generator().manual_seed(B * 100 + H + Tk)
+    x = torch.randn(B, d, generator=g)
+    slabs = torch.randn(n_slabs, B, d, generator=g) * 0.3
+    ln_w, ln_b = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    wq = (torch.randn(d, d, generator=g) * 0.06).to(dtype)
+    bq = torch.randn(d, generator=g) * 0.1
+    kv = torch.randn(B, 2 * H, Tk, 64, generator=g).to(dtype)
+    kv[:, :H] *= 0.5
+    scale = 64 ** -0.25
+    outs = {}
+    with on_stream() as s:
+        xd, sd, lwd, lbd, wqd, bqd, kvd = [t.cuda() for t in (x, slabs, ln_w, ln_b, wq, bq, kv)]
+        for pre in ("0", "4", "6"):
+            monkeypatch.setenv("WIPA_CROSS_PRE", pre)
+            x_out = torch.full((B, d), 7.0, device="cuda")
+            out = torch.zeros(B, d, device="cuda", dtype=dtype)
+            c = _lib.CrossBlockDesc()
+            c.x_in, c.x_out, c.slabs, c.bias_o, c.ln_w, c.ln_b = ptr(xd), ptr(x_out), ptr(sd), None, ptr(lwd), ptr(lbd)
+            c.wq, c.bq, c.kv, c.out = ptr(wqd), ptr(bqd), ptr(kvd), ptr(out)
+            c.slab_stride = B * d
+            c.n_slabs, c.B, c.d, c.H, c.Tk, c.dtype, c.eps, c.qk_scale = n_slabs, B, d, H, Tk, dt_code(dtype), 1e-5, scale
+            _lib.check(L.wipa_decode_cross_block(C.byref(c), sptr(s)), "wipa_decode_cross_block")
+            outs[pre] = (x_out, out)
+    torch.cuda.synchronize()
+    r = x.double() + slabs.double().sum(0)
+    y = _rt(_ln_ref(r, ln_w, ln_b), dtype)
+    q = _rt((y @ wq.double().T + bq.double()) * scale, dtype).view(B, H, 64)
+    Kc, Vc = kv[:, :H].double(), kv[:, H:].double()
+    sc = torch.einsum("bhd,bhtd->bht", q, Kc)
+    ref = torch.einsum("bht,bhtd->bhd", torch.softmax(sc, -1), Vc).reshape(B, d)
+    for pre, (x_out, out) in outs.items():
+        assert _rel(x_out, r) < 2e-6, pre
+        assert _rel(out, ref) < 2e-2, (pre, _rel(out, ref))
+    assert torch.equal(outs["4"][0], outs["0"][0]) and torch.equal(outs["6"][0], outs["0"][0])  # the residual row: same adds
+    assert torch.equal(outs["4"][1], outs["0"][1])       # same query, same row groups, same order: bit-identical
+    assert _rel(outs["6"][1], outs["0"][1]) < 1e-2       # other softmax grouping: equal up to bf16 rounding of the output
+
+
 @pytest.mark.parametrize("in_dtype,out_dtype", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16),
                                                 (torch.bfloat16, torch.float32)])
 @pytest.mark.parametrize("M,N,K,act", [(64, 3072, 768, 1), (5, 200, 128, 0), (100, 1536, 384, 1), (256, 4096, 1024, 1),
@@ -735,3 +788,89 @@ def test_gemm_k_major_operands(ops, a_trans, w_trans, M, N, K, slices, f32_mode)
     full = out.sum(0) if slices > 1 else out
     exact = A.double() @ W.double().T + bias.double()
     assert _rel(full, exact) < (4e-6 if f32_mode == "exact" else 2e-5)  # contractions of up to 4096 terms
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 3: fp8 ACTIVATIONS x fp8 weights on the block-scaled fp8 matrix instruction (BASELINE.json configs[4]).
+def _e4m3(t):
+    from whisper_ipa_amd.whisper import dequantize_fp8_e4m3, quantize_fp8_e4m3
+
+    codes, scale = quantize_fp8_e4m3(t)
+    return codes, scale, dequantize_fp8_e4m3(codes, scale)
+
+
+def test_gemm_fp8_mfma_exact_on_integers_with_asymmetric_operands(ops):
+    """The operand maps of v_mfma_f32_16x16x128_f8f6f4 as the kernel uses them, checked with EXACT data: small integers are
+    exact in e4m3 and their dot products are exact in f32, so C must equal the integer matrix product bit for bit.  A and W
+    are asymmetric (value depends on row AND k differently), ragged M / N, several K-steps; a row <-> column swap, a wrong
+    k-group or a wrong LDS chunk would all show."""
+    g = torch.Generator().manual_seed(5)
+    for M, N, K in ((300, 200, 256), (256, 256, 128), (513, 70, 640)):
+        A = torch.randint(-3, 4, (M, K), generator=g).float()
+        W = torch.randint(-3, 4, (N, K), generator=g).float()
+        A[:, 0] = (torch.arange(M) % 5 - 2).float()          # row-dependent column
+        W[:, 1] = (torch.arange(N) % 7 - 3).float()
+        A[7, :] = (torch.arange(K) % 4).float()               # k-dependent row
+        a_codes = A.to(torch.float8_e4m3fn).view(torch.uint8).cuda()
+        w_codes = W.to(torch.float8_e4m3fn).view(torch.uint8).cuda()
+        ones_m, ones_n = torch.ones(M, device="cuda"), torch.ones(N, device="cuda")
+        out = torch.full((M, N), 9.0, device="cuda")
+        ops.gemm_fp8(a_codes, ones_m, w_codes, ones_n, out)
+        torch.cuda.synchronize()
+        ref = A.double() @ W.double().T
+        assert torch.equal(out.cpu().double(), ref), (M, N, K, (out.cpu().double() - ref).abs().max())
+    assert ops.gemm_dispatch_counts(reset=True)["tile_fp8"] >= 3
+
+
+@pytest.mark.parametrize("M,N,K,act,resid,out_dtype", [(1000, 768, 768, 0, True, torch.float32), (700, 1536, 768, 0, False, torch.bfloat16),
+                                                      (515, 3072, 768, 1, False, torch.bfloat16), (300, 1280, 5120, 0, True, torch.float32)])
+def test_gemm_fp8_mfma_with_row_scales_and_epilogues(ops, M, N, K, act, resid, out_dtype):
+    """random operands quantised per row (power-of-two scales): the kernel equals the float64 product of the DEQUANTISED
+    operands up to f32 accumulation, through bias / column scale / GELU / f32 residual / bf16 output."""
+    g = torch.Generator().manual_seed(M + N)
+    a_codes, a_scale, A = _e4m3(torch.randn(M, K, generator=g) * torch.rand(M, 1, generator=g) * 3)
+    w_codes, w_scale, W = _e4m3(torch.randn(N, K, generator=g) * 0.05)
+    bias = torch.randn(N, generator=g) * 0.1
+    res = torch.randn(M, N, generator=g)
+    out = (res.clone() if resid else torch.zeros(M, N)).to(out_dtype).cuda()
+    ops.gemm_fp8(a_codes.cuda(), a_scale.cuda(), w_codes.cuda(), w_scale.cuda(), out, bias=bias.cuda(), act=act,
+                 residual=out if resid else None, col_scale_n=N if not act else 0, col_scale=0.35)
+    torch.cuda.synchronize()
+    ref = A.double() @ W.double().T + bias.double()
+    if not act:
+        ref = ref * 0.35
+    else:
+        ref = torch.nn.functional.gelu(ref)
+    if resid:
+        ref = ref + res.double()
+    err = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
+    assert err < (2e-5 if out_dtype == torch.float32 else 6e-3), err
+
+
+@pytest.mark.parametrize("rows,D", [(37, 768), (1000, 1280), (5, 384), (64, 5120)])
+def test_layernorm_fp8_and_rowquant_fp8(ops, rows, D):
+    """the row quantisers: codes + power-of-two scales equal the host quantiser's (Whisper.quantize_weights' rule) on the
+    same values -- the LayerNorm variant up to one e4m3 ulp where its f32 rounding of LN(x) sits on a rounding boundary."""
+    from whisper_ipa_amd.whisper import dequantize_fp8_e4m3, quantize_fp8_e4m3
+
+    g = torch.Generator().manual_seed(rows + D)
+    xb = (torch.randn(rows, D, generator=g) * (torch.rand(rows, 1, generator=g) * 20 + 0.01)).to(torch.bfloat16)
+    xb[0] = 0  # an all-zero row
+    codes, scale = ops.rowquant_fp8(xb.cuda())
+    rc, rs = quantize_fp8_e4m3(xb.float())
+    assert torch.equal(scale.cpu()[1:], rs[1:]) and torch.equal(codes.cpu()[1:], rc[1:])
+    assert (codes.cpu()[0].view(torch.float8_e4m3fn).float() == 0).all()
+    xf = torch.randn(rows, D, generator=g)
+    c32, s32 = ops.rowquant_fp8(xf.cuda())
+    rc, rs = quantize_fp8_e4m3(xf)
+    assert torch.equal(s32.cpu(), rs) and torch.equal(c32.cpu(), rc)
+    if D <= 2048:
+        x = torch.randn(rows, D, generator=g) * 3 + 0.5
+        w, b = 1 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+        lc, ls = ops.layernorm_fp8(x.cuda(), w.cuda(), b.cuda())
+        ref = torch.nn.functional.layer_norm(x.double(), (D,), w.double(), b.double(), 1e-5).float()
+        rc, rs = quantize_fp8_e4m3(ref)
+        assert torch.equal(ls.cpu(), rs)
+        got, want = dequantize_fp8_e4m3(lc.cpu(), ls.cpu()), dequantize_fp8_e4m3(rc, rs)
+        assert (got != want).float().mean() < 2e-3                       # boundary cases only
+        assert ((got - want).abs() <= 0.126 * want.abs() + 1e-30).all()  # ... and then by one ulp (2^-3 relative)

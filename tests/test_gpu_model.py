@@ -589,3 +589,99 @@ def test_wide_golden_features_logits_loss_gradients_language_and_fp16_features(n
     assert np.abs(f16.cpu().numpy()[:, rows][:, :, cols] - g[f"{name}_enc_fp16pos_slices"]).max() < 1e-3
     d = float((f16 - feats).abs().max())
     assert abs(d - float(g[f"{name}_enc_fp16pos_maxdiff"][0])) < 3e-4 and d > 2e-4
+
+
+@pytest.mark.parametrize("name,dims", [
+    ("small-width", R.ModelDimensions(80, 1500, 768, 12, 2, 51865, 448, 768, 12, 2)),
+    ("large-v3-width", R.ModelDimensions(128, 1500, 1280, 20, 2, 51866, 448, 1280, 20, 2)),
+])
+def test_fp8_activation_encoder_on_the_fp8_mfma(name, dims):
+    """BASELINE.json configs[4] "(CDNA4 fp8 MFMA)": quantize_weights(activations="fp8") runs the encoder's q|k, value, mlp1
+    and mlp2 projections fp8 x fp8 on v_mfma_scale_f32_16x16x128_f8f6f4 (LayerNorm and GELU outputs quantised per row).
+    Checked against (a) an EMULATION of exactly that arithmetic on the CPU oracle (same e4m3 rounding of the same
+    activations, f32 products): features within bf16 tolerance; (b) the bf16-activation model on the same quantised weights
+    -- the stand-in for "IPA-PER within 0.2 of bf16": feature difference, decode-step logit difference along the bf16
+    model's ids, and the ids themselves, with the measured-error rule (a differing id only where the bf16 model's margin is
+    <= 2 x the logit difference)."""
+    import whisper_ipa_amd as wipa
+    from parity_util import masked_margins
+    from whisper_ipa_amd import ops
+    from whisper_ipa_amd.decoding import forced_decode_logits, greedy_decode_tokens
+    from whisper_ipa_amd.whisper import dequantize_fp8_e4m3, quantize_fp8_e4m3
+
+    W = R.synthetic_weights(dims, seed=33)
+    audio = np.stack([R.synthetic_clip(5, 30.0), R.synthetic_clip(6, 6.0)])
+    mb = _model(dims, W, torch.bfloat16)
+    mb.quantize_weights("fp8_e4m3")                      # bf16 activations on the quantised weights
+    m8 = _model(dims, W, torch.bfloat16)
+    m8.quantize_weights("fp8_e4m3", activations="fp8")   # fp8 activations too
+    assert m8.activations_format == "fp8_e4m3" and m8.packed()["cfg"].enc_act_fp8 == 1 and mb.packed()["cfg"].enc_act_fp8 == 0
+    mel = wipa.log_mel_spectrogram(audio, n_mels=dims.n_mels)
+    ops.gemm_dispatch_counts(reset=True)
+    f8 = m8.encoder(mel)
+    assert ops.gemm_dispatch_counts(reset=True)["tile_fp8"] == 4 * dims.n_audio_layer
+    fb = mb.encoder(mel)
+    # (a) the same arithmetic emulated on the oracle: e4m3-round the LayerNorm outputs and the GELU output per row
+    Wdq = {k: v.float().cpu() for k, v in m8.flat_parameters().items()}
+
+    def q8(t):  # row-wise e4m3 with power-of-two scales, the product's rule
+        shp = t.shape
+        c, s = quantize_fp8_e4m3(t.reshape(-1, shp[-1]))
+        return dequantize_fp8_e4m3(c, s).reshape(shp)
+
+    def emulated_encoder(mel_t):
+        import torch.nn.functional as F
+
+        x = mel_t.transpose(1, 2)
+        x = F.gelu(F.conv1d(x, Wdq["encoder.conv1.weight"].permute(0, 2, 1), Wdq["encoder.conv1.bias"], padding=1))
+        x = F.gelu(F.conv1d(x, Wdq["encoder.conv2.weight"].permute(0, 2, 1), Wdq["encoder.conv2.bias"], stride=2, padding=1))
+        x = x.transpose(1, 2) + R.sinusoids(dims.n_audio_ctx, dims.n_audio_state)
+        H = dims.n_audio_head
+        for i in range(dims.n_audio_layer):
+            p = f"encoder.blocks.{i}"
+            h = q8(R._layer_norm(x, Wdq, p + ".attn_ln"))
+            q = F.linear(h, Wdq[p + ".attn.query.weight"], Wdq[p + ".attn.query.bias"])
+            k = F.linear(h, Wdq[p + ".attn.key.weight"])
+            v = F.linear(h, Wdq[p + ".attn.value.weight"], Wdq[p + ".attn.value.bias"])
+            B_, T_, D_ = q.shape
+            sc = (D_ // H) ** -0.25
+            qh = q.view(B_, T_, H, -1).permute(0, 2, 1, 3) * sc
+            kh = k.view(B_, T_, H, -1).permute(0, 2, 3, 1) * sc
+            a = (torch.softmax(qh @ kh, -1) @ v.view(B_, T_, H, -1).permute(0, 2, 1, 3)).permute(0, 2, 1, 3).reshape(B_, T_, D_)
+            x = x + F.linear(a, Wdq[p + ".attn.out.weight"], Wdq[p + ".attn.out.bias"])
+            h = q8(R._layer_norm(x, Wdq, p + ".mlp_ln"))
+            u = q8(F.gelu(F.linear(h, Wdq[p + ".mlp1.weight"], Wdq[p + ".mlp1.bias"])))
+            x = x + F.linear(u, Wdq[p + ".mlp2.weight"], Wdq[p + ".mlp2.bias"])
+        return R._layer_norm(x, Wdq, "encoder.ln_post")
+
+    with torch.no_grad():
+        mel_ref = np.stack([R.log_mel_spectrogram(x, dims.n_mels) for x in audio])
+        xa8 = emulated_encoder(torch.from_numpy(mel_ref))
+        xa = R.encoder_forward(Wdq, dims, torch.from_numpy(mel_ref))
+    rel_emul = ((f8.float().cpu() - xa8).abs().max() / xa8.abs().max()).item()
+    rms_emul = ((f8.float().cpu() - xa8).pow(2).mean().sqrt() / xa8.pow(2).mean().sqrt()).item()
+    rel_vs_f32 = ((f8.float().cpu() - xa).abs().max() / xa.abs().max()).item()
+    rms_vs_bf16 = ((f8.float() - fb.float()).pow(2).mean().sqrt() / fb.float().pow(2).mean().sqrt()).item()
+    # (b) downstream: decode-step logits of the two models along the bf16-activation model's ids
+    sp = R.SpecialTokens.multilingual(100 if dims.n_vocab == 51866 else 99)
+    always, first = R.suppress_lists(sp)
+    init = list(sp.sot_sequence_including_notimestamps(0))
+    rb = greedy_decode_tokens(mb, fb, init, always, first, sp.eot, max_new_tokens=16, stop_on_eot=False)
+    tb, cb = forced_decode_logits(mb, fb, rb.tokens, 4, always, first, sp.eot)
+    t8, c8 = forced_decode_logits(m8, f8, rb.tokens, 4, always, first, sp.eot)
+    keep = torch.ones(dims.n_vocab, dtype=torch.bool, device=tb.device)
+    keep[list(always)] = False
+    err = (t8 - tb)[:, :, keep].abs().amax(dim=-1).cpu().numpy()
+    spread = float(tb[:, :, keep].std())
+    margins = masked_margins(tb, always, first)
+    flips = c8 != rb.tokens[:, 4:]
+    print(f"\nfp8 activations [{name}]: features vs the emulated fp8 arithmetic {rel_emul:.3e} max / {rms_emul:.3e} rms, vs the f32 oracle {rel_vs_f32:.3e}, "
+          f"vs the bf16-activation model rms {rms_vs_bf16:.3e}; decode logits differ by at most {err.max():.4f} = {err.max() / spread:.4f} of the "
+          f"logit std; {int(flips.sum())} of {flips.size} teacher-forced choices differ (largest margin among them "
+          f"{margins[flips].max() if flips.any() else 0.0:.4f})")
+    # the kernels do what the emulation does: an e4m3 code flips (a 6 % step) wherever the GPU's bf16-path LayerNorm input
+    # and the emulation's f32 one straddle a rounding boundary, so the maximum is a few such flips and the rms is the measure
+    assert rms_emul < 2e-2 and rms_emul < 0.6 * rms_vs_bf16 and rel_emul < 0.1, (rms_emul, rms_vs_bf16, rel_emul)
+    assert rms_vs_bf16 < 0.15, rms_vs_bf16              # e4m3 activations: a few percent of the feature rms
+    assert (margins[flips] <= 2.0 * err[flips]).all()   # ids differ only where the measured logit difference allows it
+    assert err.max() < 0.35 * spread, (err.max(), spread)

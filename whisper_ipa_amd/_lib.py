@@ -16,7 +16,9 @@ LIB_PATH = os.path.join(_HERE, "libwipa.so")
 WIPA_F32, WIPA_BF16, WIPA_FP8_E4M3 = 0, 1, 2
 ENC_GLOBAL, ENC_PER_LAYER = 7, 14
 DEC_GLOBAL, DEC_PER_LAYER, DEC_FP8_PER_LAYER = 4, 20, 6
-GEMM_DISPATCH = ("tile128", "tile256", "tile384", "tile384n", "tile256p", "skinny", "skinny_fp8", "skinny_ln", "kmajor", "split_k")
+GEMM_DISPATCH = ("tile128", "tile256", "tile384", "tile384n", "tile256p", "skinny", "skinny_fp8", "skinny_ln", "kmajor", "split_k",
+                 "tile_fp8")
+ENC_FP8_PER_LAYER = 8
 
 c_void_p, c_int, c_int64, c_size_t, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
 
@@ -36,6 +38,7 @@ class GemmDesc(C.Structure):
         ("w_scale", c_void_p), ("w_dtype", C.c_int32),
         ("ln_x", c_void_p), ("ln_w", c_void_p), ("ln_b", c_void_p), ("ln_ldx", c_int64), ("ln_eps", c_float),
         ("stream_weights", C.c_int32), ("a_trans", C.c_int32), ("w_trans", C.c_int32),
+        ("a_scale", c_void_p),
     ]
 
 
@@ -75,7 +78,8 @@ class AttnDesc(C.Structure):
 class ModelCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n_mels", "n_audio_ctx", "n_audio_state", "n_audio_head", "n_audio_layer",
-        "n_vocab", "n_text_ctx", "n_text_state", "n_text_head", "n_text_layer", "dtype", "f32_split", "dec_w_dtype", "weights_generation")]
+        "n_vocab", "n_text_ctx", "n_text_state", "n_text_head", "n_text_layer", "dtype", "f32_split", "dec_w_dtype", "weights_generation",
+        "enc_act_fp8")]
 
 
 class DecLayout(C.Structure):
@@ -101,6 +105,8 @@ SIGNATURES = {
     "wipa_gemm_dispatch_counts": (c_int, [_P(c_int64), c_int, c_int]),
     "wipa_layernorm": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_int, c_int,
                                c_float, c_void_p]),
+    "wipa_layernorm_fp8": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "wipa_rowquant_fp8": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p]),
     "wipa_add_slabs_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_void_p,
                                          c_void_p, c_int, c_int, c_float, c_void_p]),
     "wipa_embed_tokens": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,

@@ -17,6 +17,7 @@
 //   wipa_gemm (skinny)       mlp2, residual updated in place
 //
 // All reductions run in a fixed order (no float atomics): results do not depend on the batch a row rides in.
+#include <cstdlib>
 #include <mutex>
 
 #include "wipa_common.h"
@@ -552,6 +553,257 @@ __global__ __launch_bounds__(256, 6) void decode_cross_block_kernel(CrossBlockPa
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The cross block with the head of the K/V stream staged in LDS UNDER the prologue (round 3).
+//
+// At the benchmark shape (12 heads x 64 clips = 768 workgroups) every workgroup of a launch is resident at once, all of them
+// run the prologue (slab sum, LayerNorm, 64 x d query GEMV) at the same time, and HBM idles meanwhile: 7.7 us of a 55 us
+// kernel whose streaming loop alone runs at the achievable HBM rate (profiles/r02_pmc_cross_block.json).  Registers cannot
+// carry the stream through the prologue (80 VGPRs per thread at six workgroups per CU), LDS can: three workgroups per CU leave
+// 53 KB each.  So, in program order:
+//   1. every load the prologue needs is issued FIRST -- residual row, slabs, LayerNorm parameters and ALL 24 16-byte chunks of
+//      this thread's query-weight row (96 VGPRs, affordable at three workgroups per CU): nothing the prologue waits for is
+//      younger than the stream (vector-memory loads return in order within a wave);
+//   2. the wave's first U x 8 key rows and value rows go to LDS by LDS-DMA (buffer_load ... lds, 1 KiB per instruction, no
+//      registers, non-temporal): 8U KiB per wave, 32U KiB per workgroup -- 37.7 MB of a launch's 295 MB with U = 6;
+//   3. the prologue computes while those bytes arrive;
+//   4. the streaming loop takes its first step from LDS and every later step from registers loaded ONE STEP AHEAD (K and V
+//      rows of step s + 1 are requested before step s is spent), so HBM never waits for arithmetic.
+// bf16, d <= 768 (24 weight chunks per thread); other shapes and larger grids keep decode_cross_block_kernel.
+typedef __attribute__((address_space(3))) void* lds_ptr_x;
+
+template <int U>
+__global__ __launch_bounds__(256, 3) void decode_cross_block_pre_kernel(CrossBlockParams p) {
+    typedef __bf16 T;
+    constexpr int EPL = 8, LPK = 8, G = 8;
+    constexpr int NQ = 24;            // 16-byte chunks of a query-weight row per thread (d <= 768)
+    constexpr int STEP = 4 * G * U;   // key rows per step of the whole workgroup
+    __shared__ __attribute__((aligned(1024))) char pre[4][2][U][1024];  // [wave][K | V][row group][8 rows x 128 B]
+    __shared__ __attribute__((aligned(16))) float xn[768];
+    __shared__ float s_red[8];
+    __shared__ float q_s[64];
+    __shared__ float s_m[4], s_l[4];
+    __shared__ float s_acc[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int d = p.d;
+    typedef bf16x8 VT;
+
+    // ---- 1. everything the prologue reads, requested before the stream.  Unconditional loads from clamped (always valid)
+    // addresses: a conditional load makes the compiler wait for it on the spot, which would put a vmcnt(0) in front of the
+    // stream; what is out of range is simply not used below.
+    const int qj = tid >> 2, qpart = tid & 3;
+    const T* wr = reinterpret_cast<const T*>(p.wq) + (int64_t)(h * 64 + qj) * d;
+    const int nch = d / EPL;
+    Vec16<T> wq[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) wq[u] = *reinterpret_cast<const Vec16<T>*>(wr + min(qpart + 4 * u, nch - 1) * EPL);
+    const int cc = tid * 4;                 // this thread's four columns of the row (d <= 768 < 1024: one chunk per thread)
+    const int ccl = min(cc, d - 4);         // clamped copy for the loads
+    constexpr int SG = 4;                   // 1 <= n_slabs <= SG and no separate out-bias (checked by the host): the split-K
+                                            // slabs of the default decode step (slab 0 carries the bias)
+    f32x4 v = *reinterpret_cast<const f32x4*>(p.x_in + (int64_t)b * d + ccl);
+    const f32x4 lnw = *reinterpret_cast<const f32x4*>(p.ln_w + ccl);
+    const f32x4 lnb = *reinterpret_cast<const f32x4*>(p.ln_b + ccl);
+    f32x4 sl[SG];
+#pragma unroll
+    for (int s = 0; s < SG; ++s)
+        sl[s] = *reinterpret_cast<const f32x4*>(p.slabs + (int64_t)b * d + ccl + (int64_t)min(s, p.n_slabs - 1) * p.slab_stride);
+    const float bqv = p.bq[h * 64 + qj];
+    // the scheduler must not sink any of the loads above below the stream (or hoist stream pieces above them): a load issued
+    // after an LDS-DMA transfer returns after it
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- 2. the head of this wave's K / V stream -> LDS (rows wave*8U + u*8 + g, the rows of its first streaming step)
+    const int g = lane / LPK, c = lane % LPK;
+    const int Tk = p.Tk;
+    const int64_t head = (int64_t)Tk * 64;
+    const T* Kh = reinterpret_cast<const T*>(p.kv) + ((int64_t)b * 2 * p.H + h) * head;
+    const T* Vh = Kh + (int64_t)p.H * head;
+    {
+        const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int off = min(wave * G * U + u * G + g, Tk - 1) * 128 + c * 16;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, (lds_ptr_x)&pre[wave][0][u][0], 16, off, 0, 0, 2);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int off = min(wave * G * U + u * G + g, Tk - 1) * 128 + c * 16;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, (lds_ptr_x)&pre[wave][1][u][0], 16, off, 0, 0, 2);
+        }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- 3. prologue: residual row (x + out-bias + slabs in order), LayerNorm -> xn (rounded through T), query GEMV.
+    // Workgroup barriers are RAW s_barriers behind an LDS-only wait: __syncthreads() carries a workgroup fence, and a fence
+    // makes the compiler drain vmcnt(0) -- i.e. wait for the whole LDS-DMA stream -- at the first barrier of the prologue.
+#define XBAR()                                                \
+    do {                                                      \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+        __builtin_amdgcn_s_barrier();                         \
+        asm volatile("" ::: "memory");                        \
+    } while (0)
+    {
+        float sum = 0.f;
+#pragma unroll
+        for (int s = 0; s < SG; ++s)
+            if (s < p.n_slabs) v += sl[s];
+        if (cc < d) {
+            if (h == 0) *reinterpret_cast<f32x4*>(p.x_out + (int64_t)b * d + cc) = v;
+            sum = (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        sum = wave_reduce_sum(sum);
+        if (lane == 0) s_red[wave] = sum;
+        XBAR();
+        const float mean = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) / (float)d;
+        float sq = 0.f;
+        if (cc < d) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dv = v[e] - mean;
+                sq += dv * dv;
+            }
+        }
+        sq = wave_reduce_sum(sq);
+        if (lane == 0) s_red[4 + wave] = sq;
+        XBAR();
+        const float rstd = rsqrtf(((s_red[4] + s_red[5]) + (s_red[6] + s_red[7])) / (float)d + p.eps);
+        if (cc < d) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = round_through<T>((v[e] - mean) * rstd * lnw[e] + lnb[e]);
+            *reinterpret_cast<f32x4*>(xn + cc) = o;
+        }
+    }
+    XBAR();
+    {
+        float a = 0.f;
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            if (qpart + 4 * u < nch) {
+                const float* xp = xn + (qpart + 4 * u) * EPL;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) a = fmaf(xp[e], wq[u].get(e), a);
+            }
+        }
+        a += __shfl_xor(a, 1, 64);
+        a += __shfl_xor(a, 2, 64);
+        if (qpart == 0) q_s[qj] = round_through<T>((a + bqv) * p.qk_scale);
+    }
+    XBAR();
+
+    // ---- 4. streaming cross-attention: step 0 from LDS, later steps from registers loaded one step ahead
+    const T* Kb = Kh + c * EPL;
+    const T* Vb = Vh + c * EPL;
+    float qf[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) qf[e] = q_s[c * EPL + e];
+    float m = NEG_BIG, l = 0.f, acc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+    auto key_group = [&](const Vec16<T> (&ka)[U], const Vec16<T> (&va)[U], int t0) {
+        float s[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float a = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) a = fmaf(qf[e], ka[u].get(e), a);
+#pragma unroll
+            for (int o = 1; o < LPK; o <<= 1) a += __shfl_xor(a, o, 64);
+            s[u] = (t0 + u * G + g < Tk) ? a : NEG_BIG;
+        }
+        float m_new = m;
+#pragma unroll
+        for (int u = 0; u < U; ++u) m_new = fmaxf(m_new, s[u]);
+        const float alpha = __expf(m - m_new);
+        l *= alpha;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[e] *= alpha;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float pr = (s[u] <= NEG_TEST) ? 0.f : __expf(s[u] - m_new);
+            l += pr;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc[e] = fmaf(pr, va[u].get(e), acc[e]);
+        }
+        m = m_new;
+    };
+    auto load_step = [&](Vec16<T> (&ka)[U], Vec16<T> (&va)[U], int t0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            ka[u].v = __builtin_nontemporal_load(reinterpret_cast<const VT*>(Kb + (int64_t)min(t0 + u * G + g, Tk - 1) * 64));
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            va[u].v = __builtin_nontemporal_load(reinterpret_cast<const VT*>(Vb + (int64_t)min(t0 + u * G + g, Tk - 1) * 64));
+    };
+    const int t_first = wave * G * U;
+    Vec16<T> kn[U], vn[U];
+    const bool more = t_first + STEP < Tk;  // wave-uniform
+    if (more) load_step(kn, vn, t_first + STEP);  // younger than the LDS-DMA: they return after it
+    // the 2U LDS-DMA transfers of this wave have landed once at most the 2U register loads above are outstanding
+    if (more) {
+        if constexpr (U == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if constexpr (U == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (t_first < Tk) {
+        Vec16<T> ka[U], va[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            ka[u].v = *reinterpret_cast<const VT*>(&pre[wave][0][u][lane * 16]);
+            va[u].v = *reinterpret_cast<const VT*>(&pre[wave][1][u][lane * 16]);
+        }
+        key_group(ka, va, t_first);
+    }
+    for (int t0 = t_first + STEP; t0 < Tk; t0 += STEP) {
+        Vec16<T> ka[U], va[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            ka[u] = kn[u];
+            va[u] = vn[u];
+        }
+        if (t0 + STEP < Tk) load_step(kn, vn, t0 + STEP);
+        key_group(ka, va, t0);
+    }
+#pragma unroll
+    for (int o = LPK; o < 64; o <<= 1) {
+        const float m_o = __shfl_xor(m, o, 64);
+        const float l_o = __shfl_xor(l, o, 64);
+        const float m_n = fmaxf(m, m_o);
+        const float a = __expf(m - m_n), bsc = __expf(m_o - m_n);
+        l = l * a + l_o * bsc;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[e] = acc[e] * a + __shfl_xor(acc[e], o, 64) * bsc;
+        m = m_n;
+    }
+    if (lane < LPK) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) s_acc[wave][c * EPL + e] = acc[e];
+        if (lane == 0) {
+            s_m[wave] = m;
+            s_l[wave] = l;
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const float mm = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float sc = __expf(s_m[w] - mm);
+            num += s_acc[w][tid] * sc;
+            den += s_l[w] * sc;
+        }
+        reinterpret_cast<T*>(p.out)[(int64_t)b * d + h * 64 + tid] = from_f32<T>(num / den);
+    }
+}
+
+#undef XBAR
+
 template <typename T>
 size_t self_block_lds(int d) {
     return (size_t)RG * (d * sizeof(T) + 16) + 4 * 12 * 64 * 16 + 3 * RG * 64 * 4 + RG * (64 * sizeof(T) + 16);
@@ -623,7 +875,18 @@ extern "C" int wipa_decode_cross_block(const wipa_cross_block_desc* d, wipa_stre
     p.slab_stride = d->slab_stride; p.n_slabs = d->n_slabs; p.B = d->B; p.d = d->d; p.H = d->H; p.Tk = d->Tk;
     p.eps = d->eps; p.qk_scale = d->qk_scale;
     const dim3 grid(d->H, d->B);
-    if (d->dtype == WIPA_BF16)
+    // WIPA_CROSS_PRE: 0 = the plain kernel, 4 / 6 = the LDS-staged kernel with U x 8 key rows per wave and step (A/B runs).
+    // Default: staged with U = 4 (32 KiB of LDS, bit-identical to the plain kernel: same row groups, same order) when the
+    // whole grid is resident at once, i.e. when nothing else would keep HBM busy under the prologue; larger grids overlap one
+    // workgroup's prologue with its neighbours' streams by themselves and are better off with six workgroups per CU.
+    // Measured r03, whisper-small, 12 x 64 workgroups: plain 54.5 us, U = 4 51.3 us (0.72 of the HBM peak), U = 6 52.5 us.
+    const char* pre_env = getenv("WIPA_CROSS_PRE");  // read per call (enqueue / capture time): tests flip it within a process
+    int pre = pre_env ? atoi(pre_env) : -1;
+    if (pre < 0) pre = (d->H * d->B <= 3 * 256) ? 4 : 0;
+    if (d->dtype == WIPA_BF16 && d->d <= 768 && d->d % 8 == 0 && d->Tk >= 8 && d->n_slabs >= 1 && d->n_slabs <= 4 && !d->bias_o && (pre == 4 || pre == 6)) {
+        if (pre == 4) hipLaunchKernelGGL(decode_cross_block_pre_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(decode_cross_block_pre_kernel<6>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    } else if (d->dtype == WIPA_BF16)
         hipLaunchKernelGGL(decode_cross_block_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(decode_cross_block_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);

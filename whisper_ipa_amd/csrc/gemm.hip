@@ -45,6 +45,7 @@ struct GemmParams {
     int64_t slab_stride;
     int a_trans = 0, w_trans = 0;    // operand given K-major ([K][rows], lda_b / ldw_b = bytes per k-row): 128x128 f32 kernel only
     const float* w_scale = nullptr;  // fp8 (e4m3) weights: per-output-column dequantisation scale
+    const float* a_scale = nullptr;  // fp8 (e4m3) A operand: per-row dequantisation scale
     // LayerNorm prologue (weight-streaming kernel only): A = LayerNorm(ln_x) computed in the kernel
     const float* ln_x = nullptr;
     const float* ln_w = nullptr;
@@ -1047,6 +1048,131 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------
+// fp8 x fp8 on the block-scaled matrix instruction (BASELINE.json configs[4]: "fp8-weight inference (CDNA4 fp8 MFMA)").
+// Both operands are OCP e4m3fn codes with one power-of-two scale per row: A [M, K] bytes with a_scale[M] (activations
+// quantised by wipa_layernorm_fp8 / wipa_rowquant_fp8), W [N, K] bytes with w_scale[N] (Whisper.quantize_weights).  Same
+// tiling, LDS image and LDS-DMA staging as gemm_nt256_kernel -- the staging moves bytes -- but a 128-byte K-step is now 128
+// elements, i.e. ONE v_mfma_scale_f32_16x16x128_f8f6f4 per 16 x 16 output tile (scale operands 0: the unscaled form, which
+// runs at twice the bf16 rate on gfx950): a lane (row = lane & 15, k-group = lane >> 4) feeds the 32 bytes k = 32 (lane >> 4)
+// ... + 31 of its row, two ds_read_b128.  Half the staged bytes per FLOP of the bf16 kernel, which is what these tile GEMMs
+// are bound by.  The per-row scales are powers of two, so acc * a_scale[m] * w_scale[n] is exact; the rest of the epilogue
+// (bias, column scale, GELU, f32 residual, remaps) is the shared one.
+typedef int v8i32 __attribute__((ext_vector_type(8)));
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+
+template <typename OutT>
+__global__ __launch_bounds__(512) void gemm_fp8_256_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][W tile | A tile]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nblocks = p.tiles_m * p.tiles_n;
+    int id;
+    {
+        const int bid = blockIdx.x;
+        const int q = nblocks >> 3, r = nblocks & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int group_size = GROUP_M * p.tiles_n;
+    const int group = id / group_size;
+    const int first_m = group * GROUP_M;
+    const int gm = min(p.tiles_m - first_m, GROUP_M);
+    const int in_group = id - group * group_size;
+    const int tile_m = first_m + in_group % gm;
+    const int tile_n = in_group / gm;
+    const int m0 = tile_m * LBM, n0 = tile_n * LBN;
+
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (int64_t)n0 * p.ldw_b), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)m0 * p.lda_b), 0, 0x7fffffff, 0x00020000);
+    int oW[4], oA[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 64 * i + 8 * wave + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        oW[i] = (min(n0 + row, p.N - 1) - n0) * (int)p.ldw_b + c * 16;
+        oA[i] = (min(m0 + row, p.M - 1) - m0) * (int)p.lda_b + c * 16;
+    }
+    auto stage = [&](int kt, int buf) {
+        const int kb = kt * ROWB;
+        char* base = smem + buf * (2 * LTILE) + wave * (8 * ROWB);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)(base + i * 64 * ROWB), 16, oW[i], kb, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(base + LTILE + i * 64 * ROWB), 16, oA[i], kb, 0, 0);
+        }
+    };
+    f32x4 acc[4][8];  // [n tile i][m tile j]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15;
+    const int fsw = (lane >> 1) & 7;
+    const int fq = lane >> 4;
+    const int nk = p.K / ROWB;  // one byte per element
+    const int c0 = ((2 * fq) ^ fsw) << 4, c1 = ((2 * fq + 1) ^ fsw) << 4;
+    auto frag = [&](const char* row) {
+        const v4i32 lo = *reinterpret_cast<const v4i32*>(row + c0);
+        const v4i32 hi = *reinterpret_cast<const v4i32*>(row + c1);
+        return v8i32{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        const char* wb = smem + (kt & 1) * (2 * LTILE) + (wn * 64 + frow) * ROWB;
+        const char* ab = smem + (kt & 1) * (2 * LTILE) + LTILE + (wm * 128 + frow) * ROWB;
+        v8i32 fw[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fw[i] = frag(wb + i * 16 * ROWB);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const v8i32 fx = frag(ab + j * 16 * ROWB);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fw[i], fx, acc[i][j], 0, 0, 0, 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // dequantisation: acc[i][j][e] is C[m = m0 + wm*128 + 16 j + frow][n = n0 + wn*64 + 16 i + 4 fq + e]
+    {
+        f32x4 ws[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + 16 * i + 4 * fq;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ws[i][e] = p.w_scale[min(n + e, p.N - 1)];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float as = p.a_scale[min(m0 + wm * 128 + 16 * j + frow, p.M - 1)];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] *= ws[i] * as;
+        }
+    }
+    const bool vec = p.vec_ok != 0;
+    int64_t coff_dev = p.c_offset;
+    if (p.c_offset_dev) coff_dev += *p.c_offset_dev;
+    if (p.stage_ok) {
+        epilogue_staged<OutT, 8>(p, acc, smem + wave * 4096, m0 + wm * 128, n0 + wn * 64, coff_dev, lane);
+        return;
+    }
+    EpiCol cols[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cols[i] = epi_col(p, n0 + wn * 64 + 16 * i + 4 * fq);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const EpiRow row = epi_row(p, m0 + wm * 128 + 16 * j + frow, coff_dev);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) epilogue4<OutT>(p, acc[i][j], row, cols[i], vec);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // 256 x 256 tile, bf16, phase-interleaved (WIPA_GEMM_TILE=2568 selects it for A/B runs).  Same LDS image as gemm_nt256_kernel
 // (two buffers of [W tile | A tile], 128-byte rows, swizzled 16-byte chunks, filled by LDS-DMA) and the same wave grid
 // (2 x 4, 128 x 64 per wave), but the K loop never drains the DMA queue:
@@ -1482,6 +1608,15 @@ int launch256(GemmParams p, hipStream_t s) {
     return WIPA_OK;
 }
 
+template <typename OutT>
+int launch_fp8_256(GemmParams p, hipStream_t s) {
+    p.tiles_m = (p.M + LBM - 1) / LBM;
+    p.tiles_n = (p.N + LBN - 1) / LBN;
+    hipLaunchKernelGGL((gemm_fp8_256_kernel<OutT>), dim3(p.tiles_m * p.tiles_n), dim3(512), LSMEM, s, p);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
 constexpr int SMEM_BYTES = 4 * TILE_BYTES;  // 64 KiB
 
 // Raise the dynamic-LDS limit of every instantiation once, outside any stream capture.
@@ -1540,6 +1675,12 @@ int init_attrs() {
             const hipError_t e = hipFuncSetAttribute(wide[i], hipFuncAttributeMaxDynamicSharedMemorySize, i < 12 ? X384<4>::SMEM : X384<2>::SMEM);
             if (e != hipSuccess) err = e;
         }
+        const void* f8k[2] = {reinterpret_cast<const void*>(&gemm_fp8_256_kernel<__bf16>),
+                              reinterpret_cast<const void*>(&gemm_fp8_256_kernel<float>)};
+        for (const void* f : f8k) {
+            const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LSMEM);
+            if (e != hipSuccess) err = e;
+        }
         const void* lnk[9] = {reinterpret_cast<const void*>(&gemm_skinny_ln_kernel<__bf16, __bf16, 1>),
                               reinterpret_cast<const void*>(&gemm_skinny_ln_kernel<__bf16, __bf16, 2>),
                               reinterpret_cast<const void*>(&gemm_skinny_ln_kernel<__bf16, __bf16, 4>),
@@ -1593,11 +1734,46 @@ extern "C" int wipa_gemm_dispatch_counts(int64_t* out, int n, int reset) {
     return WIPA_OK;
 }
 
+// fp8 activations x fp8 weights (wipa_gemm_desc.in_dtype = WIPA_FP8_E4M3): the block-scaled MFMA tile kernel
+static int gemm_fp8(const wipa_gemm_desc* d, wipa_stream_t stream) {
+    WIPA_REQUIRE(d->A && d->a_scale && d->w_scale && (d->w_dtype == 0 || d->w_dtype == WIPA_FP8_E4M3),
+                 "wipa_gemm: fp8 operands need a_scale (per row of A) and w_scale (per row of W)");
+    WIPA_REQUIRE(d->K % 128 == 0 && d->lda % 16 == 0 && d->ldw % 16 == 0 && ((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->W % 16) == 0,
+                 "wipa_gemm: fp8 operands: K=%d must be a multiple of 128 and rows 16-byte aligned", d->K);
+    WIPA_REQUIRE(!d->ln_x && !d->a_trans && !d->w_trans && d->k_slices <= 1, "wipa_gemm: fp8 operands: no LayerNorm prologue, K-major operands or k_slices");
+    WIPA_REQUIRE(d->lda < (1 << 22) && d->ldw < (1 << 22), "wipa_gemm: fp8 operands: row pitch too large for 32-bit tile offsets");
+    GemmParams p;
+    p.A = (const char*)d->A; p.W = (const char*)d->W; p.C = (char*)d->C;
+    p.bias = d->bias; p.residual = (const char*)d->residual; p.pos = d->pos; p.c_offset_dev = d->c_offset_dev;
+    p.lda_b = d->lda; p.ldw_b = d->ldw; p.w_scale = d->w_scale; p.a_scale = d->a_scale;
+    p.ldc = d->ldc; p.ldpos = d->ldpos; p.M = d->M; p.N = d->N; p.K = d->K;
+    p.rg_in = d->rg_in > 0 ? d->rg_in : d->M;
+    p.rg_valid = d->rg_in > 0 ? d->rg_valid : d->M;
+    p.rg_stride = d->rg_in > 0 ? d->rg_stride : 0;
+    p.cg_in = d->cg_in > 0 ? d->cg_in : d->N;
+    p.cg_stride = d->cg_in > 0 ? d->cg_stride : 0;
+    p.c_offset = d->c_offset; p.zero_invalid = d->zero_invalid_rows; p.bias_along_m = d->bias_along_m; p.act = d->act;
+    p.col_scale_n = d->col_scale_n; p.col_scale = d->col_scale;
+    p.k_slices = 1; p.slab_stride = 0;
+    const int64_t osz = (int64_t)wipa_dtype_size(d->out_dtype);
+    p.vec_ok = (p.ldc % 4 == 0) && (p.rg_stride % 4 == 0) && (p.cg_stride % 4 == 0) && (p.cg_in % 4 == 0) && (p.c_offset % 4 == 0) &&
+               (((uintptr_t)d->C) % 16 == 0) && (!d->residual || ((uintptr_t)d->residual) % 16 == 0);
+    const int64_t epc = 16 / osz;
+    p.stage_ok = (p.ldc % epc == 0) && (p.rg_stride % epc == 0) && (p.cg_stride % epc == 0) && (p.cg_in % epc == 0) && (p.c_offset % epc == 0) &&
+                 (p.col_scale_n % epc == 0) && !d->c_offset_dev && (((uintptr_t)d->C) % 16 == 0) &&
+                 (!d->residual || ((uintptr_t)d->residual) % 16 == 0);
+    const int rc = init_attrs();
+    if (rc != WIPA_OK) return rc;
+    count_dispatch(WIPA_GEMM_TILE_FP8);
+    return d->out_dtype == WIPA_BF16 ? launch_fp8_256<__bf16>(p, (hipStream_t)stream) : launch_fp8_256<float>(p, (hipStream_t)stream);
+}
+
 extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
     WIPA_REQUIRE(d && (d->A || d->ln_x) && d->W && d->C, "wipa_gemm: null operand");
     WIPA_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "wipa_gemm: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
-    WIPA_REQUIRE(d->in_dtype == WIPA_F32 || d->in_dtype == WIPA_BF16, "wipa_gemm: bad in_dtype %d", d->in_dtype);
+    WIPA_REQUIRE(d->in_dtype == WIPA_F32 || d->in_dtype == WIPA_BF16 || d->in_dtype == WIPA_FP8_E4M3, "wipa_gemm: bad in_dtype %d", d->in_dtype);
     WIPA_REQUIRE(d->out_dtype == WIPA_F32 || d->out_dtype == WIPA_BF16, "wipa_gemm: bad out_dtype %d", d->out_dtype);
+    if (d->in_dtype == WIPA_FP8_E4M3) return gemm_fp8(d, stream);
     const int64_t esz = (int64_t)wipa_dtype_size(d->in_dtype);
     if (d->w_dtype == WIPA_FP8_E4M3) {
         // fp8 weights: weight-streaming kernel only (decode rows); larger M runs on weights dequantised to bf16 at load time

@@ -74,6 +74,8 @@ int cfg_check(const wipa_model_cfg* c) {
     WIPA_REQUIRE(c->n_audio_state % 64 == 0 && c->n_text_state % 64 == 0, "state must be a multiple of 64");
     WIPA_REQUIRE(c->dec_w_dtype == 0 || (c->dec_w_dtype == WIPA_FP8_E4M3 && c->dtype == WIPA_BF16),
                  "cfg.dec_w_dtype %d: fp8 (e4m3) decoder weights need a bf16 model", c->dec_w_dtype);
+    WIPA_REQUIRE(c->enc_act_fp8 == 0 || (c->enc_act_fp8 == 1 && c->dtype == WIPA_BF16 && c->n_audio_state % 128 == 0),
+                 "cfg.enc_act_fp8 %d: fp8 encoder activations need a bf16 model whose width is a multiple of 128", c->enc_act_fp8);
     return WIPA_OK;
 }
 
@@ -156,6 +158,19 @@ int gemm(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_
     return wipa_gemm(&g, s);
 }
 
+// fp8 x fp8 GEMM (cfg.enc_act_fp8): A codes [M, K] + a_scale[M], W codes [N, K] + w_scale[N]
+int gemm_f8(const void* A, int64_t lda, const float* a_scale, const void* W, int64_t ldw, const float* w_scale, void* C, int64_t ldc,
+            int M, int N, int K, int out_dt, const float* bias, int act, const void* residual, wipa_stream_t s,
+            wipa_gemm_desc* extra = nullptr) {
+    wipa_gemm_desc g;
+    if (extra) g = *extra; else memset(&g, 0, sizeof(g));
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc;
+    g.M = M; g.N = N; g.K = K; g.in_dtype = WIPA_FP8_E4M3; g.out_dtype = out_dt;
+    g.bias = bias; g.act = act; g.residual = residual;
+    g.a_scale = a_scale; g.w_scale = w_scale;
+    return wipa_gemm(&g, s);
+}
+
 // ------------------------------------------------------------------ encoder
 struct EncWs {
     size_t c1, x, ln, qk, v, ao, h, total;
@@ -224,21 +239,34 @@ extern "C" int wipa_encoder_forward(const wipa_model_cfg* cfg, const void* const
                      stream, &g));
     }
     if (dt == WIPA_BF16) WIPA_CHECK_HIP(hipMemsetAsync(vb, 0, (size_t)B * d * T_ENC_PAD * e, s));
+    // fp8 activations (cfg.enc_act_fp8, BASELINE.json configs[4]): the LayerNorm outputs and the GELU output are quantised per
+    // row to e4m3 and q|k, value, mlp1, mlp2 multiply fp8 x fp8 on the block-scaled fp8 MFMA.  Buffers are the bf16 path's:
+    // `ln` holds the codes [M, d] followed by their M row scales, the (idle) q|k buffer takes the codes of the GELU output
+    // [M, 4d] and the (idle) attention-output buffer their row scales.
+    const bool f8 = cfg->enc_act_fp8 != 0;
+    float* ln_scale = (float*)((char*)ln + (size_t)M * d);  // M*d bytes of codes, then M floats (M*d*2 bytes available)
+    const void* const* w8 = w + WIPA_ENC_GLOBAL + WIPA_ENC_PER_LAYER * cfg->n_audio_layer;
     for (int l = 0; l < cfg->n_audio_layer; ++l) {
         const void* const* lw = w + WIPA_ENC_GLOBAL + WIPA_ENC_PER_LAYER * l;
-        PROF(PROF_NORM, wipa_layernorm(x, WIPA_F32, d, ln, dt, d, (const float*)lw[0], (const float*)lw[1], M, d, 1e-5f, stream));
+        const void* const* l8 = w8 + WIPA_ENC_FP8_PER_LAYER * l;
+        if (f8) PROF(PROF_NORM, wipa_layernorm_fp8(x, d, ln, d, ln_scale, (const float*)lw[0], (const float*)lw[1], M, d, 1e-5f, stream));
+        else PROF(PROF_NORM, wipa_layernorm(x, WIPA_F32, d, ln, dt, d, (const float*)lw[0], (const float*)lw[1], M, d, 1e-5f, stream));
         {
             wipa_gemm_desc g;
             memset(&g, 0, sizeof(g));
             g.col_scale_n = 2 * d; g.col_scale = QK_SCALE;
-            PROF(PROF_GEMM, gemm(ln, d, lw[2], d, qk, 2 * d, M, 2 * d, d, dt, dt, (const float*)lw[3], 0, nullptr, stream, &g));
+            if (f8) PROF(PROF_GEMM, gemm_f8(ln, d, ln_scale, l8[0], d, (const float*)l8[1], qk, 2 * d, M, 2 * d, d, dt, (const float*)lw[3], 0,
+                                            nullptr, stream, &g));
+            else PROF(PROF_GEMM, gemm(ln, d, lw[2], d, qk, 2 * d, M, 2 * d, d, dt, dt, (const float*)lw[3], 0, nullptr, stream, &g));
         }
         if (dt == WIPA_BF16) {
             // V^T per clip: swap the operand roles so the GEMM writes [d][t] directly
             wipa_gemm_desc g;
             memset(&g, 0, sizeof(g));
             g.bias_along_m = 1; g.cg_in = T; g.cg_stride = (int64_t)d * T_ENC_PAD;
-            PROF(PROF_GEMM, gemm(lw[4], d, ln, d, vb, T_ENC_PAD, d, M, d, dt, dt, (const float*)lw[5], 0, nullptr, stream, &g));
+            if (f8) PROF(PROF_GEMM, gemm_f8(l8[2], d, (const float*)l8[3], ln, d, ln_scale, vb, T_ENC_PAD, d, M, d, dt, (const float*)lw[5], 0,
+                                            nullptr, stream, &g));
+            else PROF(PROF_GEMM, gemm(lw[4], d, ln, d, vb, T_ENC_PAD, d, M, d, dt, dt, (const float*)lw[5], 0, nullptr, stream, &g));
             PROF(PROF_ATTN, wipa_flash_attn_enc_bf16(qk, 2 * d, vb, T_ENC_PAD, ao, d, B, H, T, stream));
         } else {
             PROF(PROF_GEMM, gemm(ln, d, lw[4], d, vb, d, M, d, d, dt, dt, (const float*)lw[5], 0, nullptr, stream));
@@ -246,9 +274,20 @@ extern "C" int wipa_encoder_forward(const wipa_model_cfg* cfg, const void* const
                                             B, H, T, t_f32_split, stream));
         }
         PROF(PROF_GEMM, gemm(ao, d, lw[6], d, x, d, M, d, d, dt, WIPA_F32, (const float*)lw[7], 0, x, stream));
-        PROF(PROF_NORM, wipa_layernorm(x, WIPA_F32, d, ln, dt, d, (const float*)lw[8], (const float*)lw[9], M, d, 1e-5f, stream));
-        PROF(PROF_GEMM, gemm(ln, d, lw[10], d, hb, 4 * d, M, 4 * d, d, dt, dt, (const float*)lw[11], 1, nullptr, stream));
-        PROF(PROF_GEMM, gemm(hb, 4 * d, lw[12], 4 * d, x, d, M, d, 4 * d, dt, WIPA_F32, (const float*)lw[13], 0, x, stream));
+        if (f8) {
+            PROF(PROF_NORM, wipa_layernorm_fp8(x, d, ln, d, ln_scale, (const float*)lw[8], (const float*)lw[9], M, d, 1e-5f, stream));
+            PROF(PROF_GEMM, gemm_f8(ln, d, ln_scale, l8[4], d, (const float*)l8[5], hb, 4 * d, M, 4 * d, d, dt, (const float*)lw[11], 1, nullptr,
+                                    stream));
+            void* h8 = qk;                 // [M, 4d] codes in the q|k buffer (M * 2d * 2 bytes)
+            float* h_scale = (float*)ao;   // M floats in the attention-output buffer
+            PROF(PROF_NORM, wipa_rowquant_fp8(hb, dt, 4 * d, h8, 4 * d, h_scale, M, 4 * d, stream));
+            PROF(PROF_GEMM, gemm_f8(h8, 4 * d, h_scale, l8[6], 4 * d, (const float*)l8[7], x, d, M, d, 4 * d, WIPA_F32, (const float*)lw[13], 0,
+                                    x, stream));
+        } else {
+            PROF(PROF_NORM, wipa_layernorm(x, WIPA_F32, d, ln, dt, d, (const float*)lw[8], (const float*)lw[9], M, d, 1e-5f, stream));
+            PROF(PROF_GEMM, gemm(ln, d, lw[10], d, hb, 4 * d, M, 4 * d, d, dt, dt, (const float*)lw[11], 1, nullptr, stream));
+            PROF(PROF_GEMM, gemm(hb, 4 * d, lw[12], 4 * d, x, d, M, d, 4 * d, dt, WIPA_F32, (const float*)lw[13], 0, x, stream));
+        }
     }
     PROF(PROF_NORM, wipa_layernorm(x, WIPA_F32, d, out, dt, d, (const float*)w[5], (const float*)w[6], M, d, 1e-5f, stream));
     return WIPA_OK;

@@ -42,6 +42,48 @@ def gemm(A: torch.Tensor, W: torch.Tensor, C_out: torch.Tensor, *, M: int, N: in
     return C_out
 
 
+def gemm_fp8(A: torch.Tensor, a_scale: torch.Tensor, W: torch.Tensor, w_scale: torch.Tensor, C_out: torch.Tensor, *,
+             bias: Optional[torch.Tensor] = None, act: int = 0, residual: Optional[torch.Tensor] = None, col_scale_n: int = 0,
+             col_scale: float = 1.0, bias_along_m: bool = False) -> torch.Tensor:
+    """C = epilogue((A * a_scale[:, None]) @ (W * w_scale[:, None])^T) with A [M, K], W [N, K] uint8 OCP e4m3fn codes: the
+    fp8 x fp8 tile GEMM on v_mfma_scale_f32_16x16x128_f8f6f4 (wipa_gemm_desc.in_dtype = WIPA_FP8_E4M3)."""
+    L = _lib.lib()
+    assert A.dtype == torch.uint8 and W.dtype == torch.uint8 and A.shape[1] == W.shape[1]
+    d = _lib.GemmDesc()
+    d.A, d.W, d.C = ptr(A), ptr(W), ptr(C_out)
+    d.bias, d.residual = ptr(bias), ptr(residual)
+    d.a_scale, d.w_scale = ptr(a_scale), ptr(w_scale)
+    d.lda, d.ldw, d.ldc = A.stride(0), W.stride(0), C_out.stride(0)
+    d.M, d.N, d.K = A.shape[0], W.shape[0], A.shape[1]
+    d.in_dtype, d.out_dtype = _lib.WIPA_FP8_E4M3, dt_code(C_out.dtype)
+    d.act, d.col_scale_n, d.col_scale, d.bias_along_m = act, col_scale_n, col_scale, int(bias_along_m)
+    with on_stream() as s:
+        _lib.check(L.wipa_gemm(C.byref(d), sptr(s)), "wipa_gemm")
+    return C_out
+
+
+def layernorm_fp8(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-5):
+    """rows of f32 x -> (e4m3fn codes uint8 [rows, D], power-of-two scale f32 [rows]) of LayerNorm(x): wipa_layernorm_fp8"""
+    rows, D = x.shape
+    with on_stream() as s:
+        y = torch.empty(rows, D, dtype=torch.uint8, device=x.device)
+        sc = torch.empty(rows, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().wipa_layernorm_fp8(ptr(x), x.stride(0), ptr(y), D, ptr(sc), ptr(w), ptr(b), rows, D, eps, sptr(s)),
+                   "wipa_layernorm_fp8")
+    return y, sc
+
+
+def rowquant_fp8(x: torch.Tensor):
+    """bf16 / f32 x [rows, D] -> (e4m3fn codes uint8 [rows, D], power-of-two scale f32 [rows]): wipa_rowquant_fp8"""
+    rows, D = x.shape
+    with on_stream() as s:
+        y = torch.empty(rows, D, dtype=torch.uint8, device=x.device)
+        sc = torch.empty(rows, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().wipa_rowquant_fp8(ptr(x), dt_code(x.dtype), x.stride(0), ptr(y), D, ptr(sc), rows, D, sptr(s)),
+                   "wipa_rowquant_fp8")
+    return y, sc
+
+
 def gemm_dispatch_counts(reset: bool = False) -> dict:
     """wipa_gemm_dispatch_counts: {kernel family: calls since the last reset} (a test / measurement aid)."""
     n = len(_lib.GEMM_DISPATCH)

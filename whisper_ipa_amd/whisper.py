@@ -136,6 +136,7 @@ class Whisper:
         _lib.lib()  # fail now if the extension is missing
         self._params: Dict[str, torch.Tensor] = {}
         self._fp8: Dict[str, tuple] = {}  # name -> (codes uint8 [N,K], scale f32 [N]) for the decode-step matrices
+        self._fp8_enc: Dict[str, tuple] = {}  # ... and for the encoder's q|k, value, mlp1, mlp2 when activations are fp8 too
         self._frozen = set()
         self._packed = None
         self._packed_tf = None
@@ -172,6 +173,7 @@ class Whisper:
         dt_code(dtype)
         self.dtype = dtype
         self._fp8 = {}  # fp8 codes belong to the bf16 configuration they were made for (quantize_weights again if wanted)
+        self._fp8_enc = {}
         with on_stream():
             for k, v in list(self._params.items()):
                 if _is_matrix(k, v):
@@ -192,6 +194,7 @@ class Whisper:
                     want = self.dtype if _is_matrix(n, t) else torch.float32
                     self._params[n] = t.to(device=self.device, dtype=want).contiguous()
         self._fp8 = {}  # new weights: any fp8 codes are stale (call quantize_weights again)
+        self._fp8_enc = {}
         self._invalidate()
         return self
 
@@ -200,8 +203,19 @@ class Whisper:
     def weights_format(self) -> str:
         return "fp8_e4m3" if self._fp8 else str(self.dtype).replace("torch.", "")
 
-    def quantize_weights(self, fmt: str = "fp8_e4m3"):
-        """Quantise EVERY matrix of the model (Linear / Conv1d weights, token embedding) to OCP fp8 e4m3fn with one
+    @property
+    def activations_format(self) -> str:
+        """"fp8_e4m3" when the encoder's q|k, value, mlp1 and mlp2 projections run fp8 x fp8 (quantize_weights(activations="fp8"))"""
+        return "fp8_e4m3" if self._fp8_enc else str(self.dtype).replace("torch.", "")
+
+    def quantize_weights(self, fmt: str = "fp8_e4m3", activations: str = "bf16"):
+        """``activations="fp8"`` additionally runs the ENCODER's q|k, value, mlp1 and mlp2 projections (11/12 of its GEMM FLOPs)
+        with e4m3 activations on the block-scaled fp8 MFMA: LayerNorm outputs and the GELU output are quantised per row
+        (power-of-two scales), the weights are the e4m3 codes (wipa_model_cfg.enc_act_fp8).  This is NOT the same model as
+        "bf16 activations on quantised weights": expect feature differences of a few percent (tests/test_gpu_model.py states
+        the measured bound).  Default "bf16".
+
+        Quantise EVERY matrix of the model (Linear / Conv1d weights, token embedding) to OCP fp8 e4m3fn with one
         power-of-two scale per output row (quantize_fp8_e4m3).  Biases, LayerNorm and positional tables stay f32.
         The matrices the decode step streams once per step stay in fp8 (1 byte per weight) and are read by the fp8
         weight-streaming GEMM; all matrices are ALSO kept as their exact bf16 dequantisation for the MFMA-bound tile GEMMs of
@@ -210,8 +224,18 @@ class Whisper:
             raise _lib.WipaError(f"quantize_weights: unknown format {fmt!r} (fp8_e4m3)")
         if self.dtype != torch.bfloat16:
             raise _lib.WipaError("quantize_weights: fp8 weights run with bf16 activations: call set_dtype(torch.bfloat16) first")
+        if activations not in ("bf16", "fp8"):
+            raise _lib.WipaError(f"quantize_weights: activations must be 'bf16' or 'fp8', got {activations!r}")
+        if activations == "fp8" and self.dims.n_audio_state % 128 != 0:
+            raise _lib.WipaError("quantize_weights: fp8 activations need an encoder width that is a multiple of 128")
         step = set(_decode_step_matrices(self.dims))
-        fp8 = {}
+        enc_f8 = set()
+        if activations == "fp8":
+            for i in range(self.dims.n_audio_layer):
+                pfx = f"encoder.blocks.{i}"
+                enc_f8 |= {f"{pfx}.attn.query.weight", f"{pfx}.attn.key.weight", f"{pfx}.attn.value.weight", f"{pfx}.mlp1.weight",
+                           f"{pfx}.mlp2.weight"}
+        fp8, fp8_enc = {}, {}
         with on_stream():
             for n, t in list(self._params.items()):
                 if not _is_matrix(n, t):
@@ -220,8 +244,11 @@ class Whisper:
                 self._params[n] = dequantize_fp8_e4m3(codes, scale).to(torch.bfloat16).reshape(t.shape).contiguous()
                 if n in step:
                     fp8[n] = (codes, scale)
+                if n in enc_f8:
+                    fp8_enc[n] = (codes, scale)
         self._invalidate()
         self._fp8 = fp8
+        self._fp8_enc = fp8_enc
         return self
 
     def parameters(self) -> Dict:
@@ -256,7 +283,7 @@ class Whisper:
         return _lib.ModelCfg(d.n_mels, d.n_audio_ctx, d.n_audio_state, d.n_audio_head, d.n_audio_layer, d.n_vocab,
                              d.n_text_ctx, d.n_text_state, d.n_text_head, d.n_text_layer, dt_code(self.dtype),
                              int(self.f32_split and self.dtype == torch.float32), _lib.WIPA_FP8_E4M3 if fp8 else 0,
-                             getattr(self, "_generation", 0))
+                             getattr(self, "_generation", 0), int(bool(self._fp8_enc)))
 
     def packed(self, teacher_forced: bool = False):
         """(cfg, encoder table, decoder table); fused matrices are rebuilt after any update.  With fp8 weights the decoder
@@ -320,6 +347,15 @@ class Whisper:
                         mat(P[f"{p}.mlp1.weight"]), vec(P[f"{p}.mlp1.bias"]),
                         mat(P[f"{p}.mlp2.weight"]), vec(P[f"{p}.mlp2.bias"])]
             assert len(enc) == _lib.ENC_GLOBAL + _lib.ENC_PER_LAYER * d.n_audio_layer
+            if self._fp8_enc:  # fp8 encoder tail: codes + per-row scales of q|k, value, mlp1, mlp2 (WIPA_ENC_FP8_PER_LAYER)
+                E = self._fp8_enc
+                for i in range(d.n_audio_layer):
+                    p = f"encoder.blocks.{i}"
+                    for names in ((f"{p}.attn.query.weight", f"{p}.attn.key.weight"), (f"{p}.attn.value.weight",), (f"{p}.mlp1.weight",),
+                                  (f"{p}.mlp2.weight",)):
+                        enc.append(torch.cat([E[n][0] for n in names], 0).to(self.device).contiguous())
+                        enc.append(torch.cat([E[n][1] for n in names], 0).to(device=self.device, dtype=f32).contiguous())
+                assert len(enc) == _lib.ENC_GLOBAL + (_lib.ENC_PER_LAYER + _lib.ENC_FP8_PER_LAYER) * d.n_audio_layer
             assert len(dec) == _lib.DEC_GLOBAL + _lib.DEC_PER_LAYER * d.n_text_layer
             if fp8:
                 # the decode-step matrices as e4m3 codes (rows concatenated like their bf16 counterparts) + per-row scales
