@@ -433,6 +433,12 @@ def roofline_mfma(model, audio, pmc_file: str = "r02_pmc_encoder_gemm.json"):
            "flash_attention": {"ms_per_pass": round(attn_ms, 3), "achieved": round(attn_flops / (attn_ms * 1e-3) / 1e12, 1),
                                "frac": round(attn_flops / (attn_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)},
            "layernorm_ms_per_pass": round(norm_ms, 3), "mfma_busy_pmc": None}
+    if model.activations_format == "fp8_e4m3":
+        # 11/12 of the encoder's layer GEMM FLOPs (q|k, value, mlp1, mlp2) run fp8 x fp8; the out projection, the convolutions
+        # and the cross-K/V projection stay bf16.  Quoted against BOTH dense peaks.
+        f8 = B * 2.0 * d.n_audio_layer * Ta * 11 * de * de
+        out["fp8_mfma"] = {"fp8_share_of_flops": round(f8 / flops, 4), "peak_fp8": 5000.0, "frac_of_fp8_peak": round(achieved / 5000.0, 4),
+                           "note": "whole GEMM set (fp8 and bf16 launches together) / its summed launch time; frac above is against the bf16 peak"}
     try:  # SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE per GEMM shape, separate rocprofv3 --pmc passes (profiles/)
         out["mfma_busy_pmc"] = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
     except Exception:
@@ -856,6 +862,9 @@ def main():
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: BASELINE.json configs[4] sizing runs (e4m3 weights with per-row scales, bf16 activations); the "
                          "benchmark metric is quoted on bf16 weights")
+    ap.add_argument("--activations", default="bf16", choices=["bf16", "fp8"],
+                    help="with --weights fp8: fp8 also runs the encoder's q|k, value, mlp1, mlp2 projections fp8 x fp8 on the "
+                         "block-scaled fp8 MFMA (LayerNorm / GELU outputs quantised per row) -- configs[4] '(CDNA4 fp8 MFMA)'")
     ap.add_argument("--f32", default="exact", choices=["exact", "split"],
                     help="float32 runs: exact f32 MFMA products (default, as the reference computes) or the split-bf16 opt-in")
     ap.add_argument("--train-batch", type=int, default=32)
@@ -885,9 +894,11 @@ def main():
     model = Whisper(dims, dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32, f32_split=(args.f32 == "split"))
     model.load_weights(W)
     del W
+    if args.activations == "fp8" and args.weights != "fp8":
+        sys.exit("bench.py: --activations fp8 needs --weights fp8")
     if args.weights == "fp8":
-        model.quantize_weights("fp8_e4m3")
-        log("weights quantised to fp8 e4m3")
+        model.quantize_weights("fp8_e4m3", activations=args.activations)
+        log(f"weights quantised to fp8 e4m3 (encoder activations: {args.activations})")
     audio_dev = torch.from_numpy(synthetic_audio(rank * B, B)).cuda()
     audio_chunks = [c.contiguous() for c in audio_dev.chunk(args.streams)]
     setup = decode_setup()
@@ -945,7 +956,7 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": f"synthetic (seeded noise clips, random-init whisper-{args.model} weights)",
-            "config": {"weights": model.weights_format,
+            "config": {"weights": model.weights_format, "encoder_activations": model.activations_format,
                        "workload": f"whisper-{args.model} {args.dtype}{' (fp8 e4m3 weights)' if args.weights == 'fp8' else ''} batched inference, batch={B}x30s synthetic clips per GPU, "
                                    f"log-mel + encoder + cross-KV + {NEW_TOKENS} greedy KV-cached decode steps",
                        "clips_per_gpu": B, "new_tokens": NEW_TOKENS, "streams_per_gpu": args.streams, "passes_in_flight": args.pipeline, "decode_group": args.decode_group,

@@ -847,7 +847,7 @@ def test_gemm_fp8_mfma_with_row_scales_and_epilogues(ops, M, N, K, act, resid, o
     assert err < (2e-5 if out_dtype == torch.float32 else 6e-3), err
 
 
-@pytest.mark.parametrize("rows,D", [(37, 768), (1000, 1280), (5, 384), (64, 5120)])
+@pytest.mark.parametrize("rows,D", [(37, 768), (1000, 1280), (5, 384), (64, 5120), (9, 6144), (11, 3080)])
 def test_layernorm_fp8_and_rowquant_fp8(ops, rows, D):
     """the row quantisers: codes + power-of-two scales equal the host quantiser's (Whisper.quantize_weights' rule) on the
     same values -- the LayerNorm variant up to one e4m3 ulp where its f32 rounding of LN(x) sits on a rounding boundary."""
