@@ -271,6 +271,8 @@ def roofline_cross_attn(model, B: int, iters: int = 48):
     H, Ta = d.n_text_head, d.n_audio_ctx
     st = model._dec_states[0]
     lay = st.layout
+    if model.cross_absorbed:
+        return roofline_cross_absorbed(model, B, st, iters)
     e = 2 if model.dtype == torch.bfloat16 else 4
     per_layer = B * 2 * H * Ta * 64
     kv_all = st.blob[lay.cross_kv: lay.cross_kv + d.n_text_layer * per_layer * e].view(model.dtype).view(
@@ -388,6 +390,81 @@ def roofline_cross_attn(model, B: int, iters: int = 48):
     return out
 
 
+def roofline_cross_absorbed(model, B: int, st, iters: int = 48):
+    """Dominant HBM-bound kernel of the default decode step since round 3: cross_absorbed_kernel, the ONE pass over the encoder
+    output xa that serves scores and values of a layer (csrc/cross_absorbed.hip).  Algorithmic bytes per launch = B * 1500 * d *
+    sizeof(bf16) (every element of xa once) + the absorbed queries and the split partials.  SURVEY.md section 8(d) counted
+    55.3 MB per clip and step for the cached K and V of the 12 layers; with the projections absorbed the bytes a step MUST read
+    are half of that, which is the point -- the line also gives the rate in cached-K/V terms (`kv_equivalent`).  Timed with
+    events around graph-replayed launches that rotate over several xa buffers (several passes in flight share the Infinity
+    Cache; one buffer alone, 147 MB, would stay resident in it)."""
+    import ctypes as C
+
+    from whisper_ipa_amd import _lib
+    from whisper_ipa_amd.runtime import on_stream, ptr, sptr, stream
+
+    L = _lib.lib()
+    d = model.dims
+    H, Ta, dd = d.n_text_head, d.n_audio_ctx, d.n_text_state
+    pk = model.packed()
+    n_buf = max(2, min(5, int(600e6 // (B * Ta * dd * 2)) + 1))
+    with on_stream() as s:
+        xas = [torch.randn(B, Ta, dd, device=model.device).to(torch.bfloat16) for _ in range(n_buf)]
+        q = (torch.randn(B, dd, device=model.device) * 0.3).to(torch.bfloat16)
+        out = torch.empty_like(q)
+        nbytes = L.wipa_cross_absorbed_scratch_bytes(B, dd, Ta)
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=model.device)
+        base = _lib.DEC_GLOBAL + _lib.DEC_PER_LAYER * d.n_text_layer
+        lw = pk["dec"][_lib.DEC_GLOBAL: _lib.DEC_GLOBAL + _lib.DEC_PER_LAYER]
+        wkT, wkv, bkv = pk["dec"][base], lw[10], lw[11]
+
+        def full(i):
+            _lib.check(L.wipa_cross_absorbed_attention(ptr(q), dd, ptr(wkT), ptr(xas[i % n_buf]), ptr(wkv[dd:]), ptr(bkv[dd:]), ptr(out), dd,
+                                                       ptr(scratch), nbytes, B, H, dd, Ta, 64 ** -0.25, sptr(s)), "wipa_cross_absorbed_attention")
+
+        def stream_only(i):
+            _lib.check(L.wipa_cross_absorbed_stream(ptr(xas[i % n_buf]), ptr(scratch), nbytes, B, H, dd, Ta, sptr(s)), "wipa_cross_absorbed_stream")
+
+        times = {}
+        for name, fn in (("stream", stream_only), ("layer_call", full)):
+            for i in range(n_buf):
+                full(i)
+            s.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=s):
+                for i in range(iters):
+                    fn(i)
+            graph.replay()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record(s)
+            graph.replay()
+            ev1.record(s)
+            ev1.synchronize()
+            times[name] = ev0.elapsed_time(ev1) / iters
+    S = L.wipa_cross_absorbed_splits(B, Ta)
+    xa_bytes = B * Ta * dd * 2
+    bytes_alg = xa_bytes + B * 16 * dd * 2 + B * S * 16 * (2 + dd) * 4  # xa once + absorbed queries in + split partials out
+    ms = times["stream"]
+    achieved = bytes_alg / (ms * 1e-3) / 1e9
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_cross_absorbed.json")))
+        if pm.get("algorithmic_bytes_per_launch") == bytes_alg:
+            traffic = pm["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    kv_bytes = B * 2 * H * Ta * 64 * 2
+    return {"kernel": "cross_absorbed_kernel (decode-step cross-attention of one layer: one pass over the encoder output, key / value "
+                      "projections absorbed into the query and the output)", "bound": "hbm", "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "algorithmic_bytes_per_launch": bytes_alg, "avg_launch_ms": round(ms, 5), "xa_buffers_rotated": n_buf, "frame_splits": S,
+            "layer_call": {"what": "absorb-q + streaming + merge / value projection (3 launches: what replaces the cached-K/V cross "
+                                   "block's streaming loop)", "avg_ms": round(times["layer_call"], 5)},
+            "kv_equivalent": {"what": "the cached K / V bytes this launch stands for (SURVEY.md 8d: 55.3 MB per clip and step over 12 "
+                                      "layers) over the same time", "bytes": kv_bytes,
+                              "GB/s": round(kv_bytes / (ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(kv_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+
+
 def roofline_mfma(model, audio, pmc_file: str = "r02_pmc_encoder_gemm.json"):
     """The MFMA-bound kernel set: every GEMM / conv-as-GEMM of one encoder pass plus the cross-K/V projection.
     Algorithmic FLOPs per clip are SURVEY.md App. B's (whisper-small: 261.2 + 42.5 GFLOP); the time is the sum of HIP-event
@@ -403,7 +480,7 @@ def roofline_mfma(model, audio, pmc_file: str = "r02_pmc_encoder_gemm.json"):
     # 2*M*N*K of: conv1 (K = 3 n_mels, 3000 frames), conv2 (K = 3 d, 1500 frames), per layer q,k,v,out (4 d^2) + MLP (8 d^2),
     # and the decoder's cross key / value projections of the encoder output (2 d^2 per decoder layer)
     enc = 2.0 * (3000 * de * 3 * d.n_mels + Ta * de * 3 * de + d.n_audio_layer * Ta * 12 * de * de)
-    ckv = 2.0 * d.n_text_layer * Ta * 2 * dd * dd
+    ckv = 0.0 if model.cross_absorbed else 2.0 * d.n_text_layer * Ta * 2 * dd * dd  # absorbed projections: no cross-K/V GEMMs
     flops = B * (enc + ckv)
     L = _lib.lib()
     pk = model.packed()
@@ -426,7 +503,7 @@ def roofline_mfma(model, audio, pmc_file: str = "r02_pmc_encoder_gemm.json"):
     gemm_ms, n_gemm, attn_ms, norm_ms = best
     achieved = flops / (gemm_ms * 1e-3) / 1e12
     attn_flops = B * d.n_audio_layer * 4.0 * Ta * Ta * de
-    out = {"kernel": "gemm_nt384/gemm_nt256 (encoder GEMM + conv + cross-K/V projection set)", "bound": "mfma",
+    out = {"kernel": "gemm_nt384/gemm_nt256 (encoder GEMM + conv" + ("" if model.cross_absorbed else " + cross-K/V projection") + " set)", "bound": "mfma",
            "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "algorithmic_tflop_per_pass": round(flops / 1e12, 3),
            "gemm_ms_per_pass": round(gemm_ms, 3), "gemm_launches": n_gemm,
@@ -477,6 +554,8 @@ def decode_step_roofline(model, B: int, n_steps: int = 48):
     t_mean = p0 + 2 + n_steps / 2.0
     dd, Ld = d.n_text_state, d.n_text_layer
     cross = B * Ld * 2 * d.n_audio_ctx * dd * e
+    if model.cross_absorbed:  # one pass over the encoder output per layer instead of one over K and one over V
+        cross = B * Ld * d.n_audio_ctx * dd * e
     self_kv = B * Ld * 2 * t_mean * dd * e
     dec_params = d.n_vocab * dd + d.n_text_ctx * dd + Ld * (4 * dd * dd + 4 * dd * dd + 8 * dd * dd) + Ld * 11 * dd + 2 * dd
     weights = dec_params * e
@@ -486,7 +565,8 @@ def decode_step_roofline(model, B: int, n_steps: int = 48):
     achieved = total / (ms * 1e-3) / 1e9
     return {"what": "one decode step, hipGraph replay, one pass in flight", "bound": "hbm", "ms_per_step": round(ms, 4),
             "bytes_per_step": int(total), "cross_kv_bytes": int(cross), "self_kv_bytes": int(self_kv), "weight_bytes": int(weights),
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4)}
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "cross_attention": "absorbed projections: the encoder output streamed once per layer" if model.cross_absorbed else "cached K / V"}
 
 
 def cpu_baseline(n_clips: int = 1):
@@ -957,6 +1037,7 @@ def main():
             "dtype": args.dtype,
             "data": f"synthetic (seeded noise clips, random-init whisper-{args.model} weights)",
             "config": {"weights": model.weights_format, "encoder_activations": model.activations_format,
+                       "cross_attention": "absorbed" if model.cross_absorbed else "cached",
                        "workload": f"whisper-{args.model} {args.dtype}{' (fp8 e4m3 weights)' if args.weights == 'fp8' else ''} batched inference, batch={B}x30s synthetic clips per GPU, "
                                    f"log-mel + encoder + cross-KV + {NEW_TOKENS} greedy KV-cached decode steps",
                        "clips_per_gpu": B, "new_tokens": NEW_TOKENS, "streams_per_gpu": args.streams, "passes_in_flight": args.pipeline, "decode_group": args.decode_group,

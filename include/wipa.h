@@ -286,6 +286,27 @@ typedef struct wipa_cross_block_desc {
 } wipa_cross_block_desc;
 int wipa_decode_cross_block(const wipa_cross_block_desc* d, wipa_stream_t s);
 
+/* ------------------------------------------------------------------ K11 with ABSORBED key / value projections
+ * Decode-step cross-attention that streams the encoder output xa itself instead of cached K = xa Wk^T and V = xa Wv^T + bv
+ * (mlx_whisper MultiHeadAttention with xa, behind DecodingTask._main_loop, transcribe_single.py:55):
+ *     scores_h = (q_h Wk_h) xa^T,   out_h = (softmax(scores_h) xa) Wv_h^T + bv_h
+ * -- one pass over xa [Tk, d] per clip, layer and step instead of one over K and one over V (half the bytes), no K/V cache and no
+ * cross-K/V projection; the 12x larger contractions run on the matrix cores (csrc/cross_absorbed.hip).  bf16, H <= 16 heads of
+ * 64, d in {384, 512, 768, 1024}.
+ * q   [B rows, row stride q_row_stride] bf16: the cross query, already multiplied by 64^-0.25 (and with its bias);
+ * wkT [d, d] bf16 = Wk^T ([in][out]);  xa [B, Tk, d] bf16;  wv [d, d] bf16 ([out][in]), bv [d] f32;
+ * out [B rows, row stride out_row_stride] bf16;  k_scale = 64^-0.25 (the key side's share of the score scale);
+ * scratch: wipa_cross_absorbed_scratch_bytes(B, d, Tk) bytes, 16-byte aligned.  wipa_cross_absorbed_init(d) raises the
+ * kernel's LDS limit (call it once outside any stream capture). */
+int wipa_cross_absorbed_splits(int B, int Tk);
+size_t wipa_cross_absorbed_scratch_bytes(int B, int d, int Tk);
+int wipa_cross_absorbed_init(int d);
+int wipa_cross_absorbed_attention(const void* q, int64_t q_row_stride, const void* wkT, const void* xa, const void* wv, const float* bv,
+                                  void* out, int64_t out_row_stride, void* scratch, size_t scratch_bytes, int B, int H, int d, int Tk,
+                                  float k_scale, wipa_stream_t s);
+/* measurement aid: the streaming kernel of wipa_cross_absorbed_attention alone, on a scratch a full call has filled */
+int wipa_cross_absorbed_stream(const void* xa, void* scratch, size_t scratch_bytes, int B, int H, int d, int Tk, wipa_stream_t s);
+
 /* ------------------------------------------------------------------ K13 greedy step
  * GreedyDecoder.update + SuppressBlank + SuppressTokens of mlx_whisper.decoding
  * (transcribe_single.py:49-55).  p = *pos_dev is the position whose logits these are.
@@ -338,6 +359,12 @@ typedef struct wipa_model_cfg {
                           * e4m3 codes.  Attention, the out projection, the residual stream and everything downstream stay as
                           * they are.  0 = bf16 activations on the dequantised weights (the default; what the parity tests call
                           * "the bf16 model on quantised weights"). */
+    int32_t dec_cross_absorbed; /* bf16 models, <= 16 heads, d in {384, 512, 768, 1024}, dec_w_dtype = 0: 1 = the decode step's
+                                 * cross-attention streams the encoder output with absorbed key / value projections
+                                 * (wipa_cross_absorbed_attention): the state's cross_kv region then holds a copy of the features
+                                 * [B, n_audio_ctx, d], wipa_decoder_set_audio runs no projection, and the decoder table carries one
+                                 * more entry per layer after the regular blocks: Wk^T [d, d] (WIPA_DEC_ABSORBED_PER_LAYER).  0 =
+                                 * cached K / V (every other configuration). */
 } wipa_model_cfg;
 
 /* Encoder weight table (const void* [WIPA_ENC_GLOBAL + WIPA_ENC_PER_LAYER * n_layer]):
@@ -365,6 +392,9 @@ typedef struct wipa_model_cfg {
  *   token_embedding scale [V] f32, then per layer: qkv scale [3d], out [d], cross.query [d], cross.out [d], mlp1 [4d], mlp2 [d]
  * (value = code * scale[row]); entries 0 and per-layer 2, 4, 8, 12, 16, 18 then point to e4m3 codes. */
 #define WIPA_DEC_FP8_PER_LAYER 6
+/* absorbed cross-attention tables (cfg.dec_cross_absorbed = 1, never together with fp8 tables) append per layer:
+ *   0 cross.key.w transposed, [d_in, d_out] T */
+#define WIPA_DEC_ABSORBED_PER_LAYER 1
 
 /* AudioEncoder.__call__ / Whisper.embed_audio (train_whisper_ipa.py:223,
  * transcribe_single.py:54).  mel_padded [B,3002,n_mels] T -> out [B, n_audio_ctx, d] T. */

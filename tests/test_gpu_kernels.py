@@ -874,3 +874,128 @@ def test_layernorm_fp8_and_rowquant_fp8(ops, rows, D):
         got, want = dequantize_fp8_e4m3(lc.cpu(), ls.cpu()), dequantize_fp8_e4m3(rc, rs)
         assert (got != want).float().mean() < 2e-3                       # boundary cases only
         assert ((got - want).abs() <= 0.126 * want.abs() + 1e-30).all()  # ... and then by one ulp (2^-3 relative)
+
+
+@pytest.mark.parametrize("B,H,Tk", [(64, 12, 1500), (3, 12, 1500), (5, 6, 200), (17, 8, 95), (2, 16, 33)])
+def test_cross_attention_with_absorbed_projections(B, H, Tk):
+    """Round 3: decode-step cross-attention that streams the encoder output xa with the key / value projections absorbed into
+    the query and the output (csrc/cross_absorbed.hip): scores_h = (q_h Wk_h) xa^T, out_h = (P_h xa) Wv_h^T + bv_h.  Against the
+    float64 statement WITH explicit K = xa Wk^T and V = xa Wv^T + bv (what mlx_whisper caches), ragged frame counts, fewer than
+    16 heads (the padded rows of the 16-wide MFMA dimension), strided query / output rows (the prompt prefill's layout)."""
+    from whisper_ipa_amd import _lib
+    from whisper_ipa_amd.runtime import on_stream, ptr, sptr
+
+    L = _lib.lib()
+    d = H * 64
+    g = torch.Generator().manual_seed(B * 31 + H + Tk)
+    scale = 64 ** -0.25
+    q = (torch.randn(B, 2, d, generator=g) * 0.8 * scale).to(torch.bfloat16)     # rows with stride 2d: row (b, 1) is used
+    wk = (torch.randn(d, d, generator=g) * 0.06).to(torch.bfloat16)
+    wv = (torch.randn(d, d, generator=g) * 0.06).to(torch.bfloat16)
+    bv = torch.randn(d, generator=g) * 0.1
+    xa = torch.randn(B, Tk, d, generator=g).to(torch.bfloat16)
+    _lib.check(L.wipa_cross_absorbed_init(d))
+    with on_stream() as s:
+        qd, wkT, wvd, bvd, xad = q.cuda(), wk.T.contiguous().cuda(), wv.cuda(), bv.cuda(), xa.cuda()
+        out = torch.full((B, 3, d), 5.0, device="cuda", dtype=torch.bfloat16)
+        nbytes = L.wipa_cross_absorbed_scratch_bytes(B, d, Tk)
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        _lib.check(L.wipa_cross_absorbed_attention(ptr(qd[:, 1]), 2 * d, ptr(wkT), ptr(xad), ptr(wvd), ptr(bvd), ptr(out[:, 2]), 3 * d,
+                                                   ptr(scratch), nbytes, B, H, d, Tk, scale, sptr(s)), "wipa_cross_absorbed_attention")
+    torch.cuda.synchronize()
+    qq = q[:, 1].double().view(B, H, 64)
+    K = (xa.double() @ wk.double().T * scale).view(B, Tk, H, 64)
+    V = (xa.double() @ wv.double().T + bv.double()).view(B, Tk, H, 64)
+    sc = torch.einsum("bhd,bthd->bht", qq, K)
+    ref = torch.einsum("bht,bthd->bhd", torch.softmax(sc, -1), V).reshape(B, d)
+    got = out[:, 2].float().cpu().double()
+    assert (out[:, :2].float() == 5.0).all()  # rows of the other positions untouched
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err < 2.5e-2, err
+    assert float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()) < 8e-3
+
+
+@pytest.mark.parametrize("H,Tk", [(12, 1500), (6, 700)])
+def test_cross_attention_absorbed_when_scores_climb_past_the_fixed_reference(H, Tk):
+    """The streaming kernel takes each wave's softmax reference from the wave's FIRST 16 frames and never rescales; when later
+    scores climb more than 40 above it the wave re-derives its exact maximum and streams again (csrc/cross_absorbed.hip).  Here
+    the frames grow with their index along one direction of every head's absorbed query so that late scores exceed the early
+    ones by ~+120 for some clips and fall by as much for others (no restart, tiny probabilities): both against float64."""
+    from whisper_ipa_amd import _lib
+    from whisper_ipa_amd.runtime import on_stream, ptr, sptr
+
+    L = _lib.lib()
+    B, d = 6, H * 64
+    g = torch.Generator().manual_seed(H + Tk)
+    scale = 64 ** -0.25
+    q = (torch.randn(B, d, generator=g) * 0.8 * scale).to(torch.bfloat16)
+    wk = (torch.randn(d, d, generator=g) * 0.06).to(torch.bfloat16)
+    wv = (torch.randn(d, d, generator=g) * 0.06).to(torch.bfloat16)
+    bv = torch.randn(d, generator=g) * 0.1
+    xa = torch.randn(B, Tk, d, generator=g)
+    # direction u_b = sum_h q_h Wk_h (the absorbed query summed over heads): adding ramp(t) * u_b / |u_b|^2 moves every head's score
+    qk = torch.einsum("bhj,hjc->bc", q.float().view(B, H, 64), wk.float().view(H, 64, d)) * scale
+    ramp = torch.linspace(0, 1, Tk).view(1, Tk, 1) * torch.tensor([120.0, -120.0, 60.0, 0.0, 200.0, 45.0]).view(B, 1, 1)
+    xa = (xa + ramp * H * qk.view(B, 1, d) / qk.pow(2).sum(-1).view(B, 1, 1)).to(torch.bfloat16)
+    _lib.check(L.wipa_cross_absorbed_init(d))
+    with on_stream() as s:
+        qd, wkT, wvd, bvd, xad = q.cuda(), wk.T.contiguous().cuda(), wv.cuda(), bv.cuda(), xa.cuda()
+        out = torch.empty(B, d, device="cuda", dtype=torch.bfloat16)
+        nbytes = L.wipa_cross_absorbed_scratch_bytes(B, d, Tk)
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        for _ in range(2):
+            _lib.check(L.wipa_cross_absorbed_attention(ptr(qd), d, ptr(wkT), ptr(xad), ptr(wvd), ptr(bvd), ptr(out), d, ptr(scratch), nbytes,
+                                                       B, H, d, Tk, scale, sptr(s)), "wipa_cross_absorbed_attention")
+    torch.cuda.synchronize()
+    # reference from the bf16-rounded absorbed queries the kernel itself uses (the ramp amplifies their rounding: a score of 200
+    # moves by ~0.4 when q' moves by one bf16 ulp, which is a property of the input, not of the kernel)
+    qp = (torch.einsum("bhj,hjc->bhc", q.double().view(B, H, 64), wk.double().view(H, 64, d)) * scale).to(torch.bfloat16).double()
+    sc = torch.einsum("bhc,btc->bht", qp, xa.double())
+    assert float((sc.amax(-1) - sc[..., :16].amax(-1)).max()) > 60  # the restart case is exercised
+    px = torch.einsum("bht,btc->bhc", torch.softmax(sc, -1), xa.double())
+    ref = (torch.einsum("bhc,hjc->bhj", px, wv.double().view(H, 64, d)) + bv.double().view(H, 64)).reshape(B, d)
+    got = out.float().cpu().double()
+    assert torch.isfinite(got).all()
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err < 2.5e-2, err
+
+
+def test_cross_attention_absorbed_is_deterministic_with_four_streams_in_flight():
+    """Regression test of two timing hazards found in round 3 (both invisible with one pass in flight): a destination
+    register of ds_read_b64_tr_b16 copied before its data had arrived (the wait sat in a later asm statement), and the merge
+    kernel's single-thread weight section.  The same call on four HIP streams at once, repeated: every output and every
+    partial result must equal the single-stream ones bit for bit."""
+    from whisper_ipa_amd import _lib
+    from whisper_ipa_amd.runtime import ptr
+
+    L = _lib.lib()
+    B, H, Tk = 64, 12, 1500
+    d = H * 64
+    _lib.check(L.wipa_cross_absorbed_init(d))
+    g = torch.Generator(device="cuda").manual_seed(0)
+    xa = torch.randn(B, Tk, d, device="cuda", generator=g).bfloat16()
+    q = (torch.randn(B, d, device="cuda", generator=g) * 0.3).bfloat16()
+    wkT = (torch.randn(d, d, device="cuda", generator=g) * 0.05).bfloat16()
+    wv = (torch.randn(d, d, device="cuda", generator=g) * 0.05).bfloat16()
+    bv = torch.randn(d, device="cuda", generator=g) * 0.1
+    nbytes = L.wipa_cross_absorbed_scratch_bytes(B, d, Tk)
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    outs = [torch.empty(B, d, device="cuda", dtype=torch.bfloat16) for _ in range(4)]
+    scr = [torch.zeros(nbytes, dtype=torch.uint8, device="cuda") for _ in range(4)]
+    torch.cuda.synchronize()
+
+    def call(i):
+        _lib.check(L.wipa_cross_absorbed_attention(ptr(q), d, ptr(wkT), ptr(xa), ptr(wv), ptr(bv), ptr(outs[i]), d, ptr(scr[i]), nbytes, B, H, d,
+                                                   Tk, 64 ** -0.25, streams[i].cuda_stream))
+
+    call(0)
+    torch.cuda.synchronize()
+    ref, ref_scr = outs[0].clone(), scr[0].clone()
+    for _ in range(6):
+        for _ in range(12):
+            for i in range(4):
+                call(i)
+        torch.cuda.synchronize()
+        for i in range(4):
+            assert torch.equal(outs[i], ref), (i, int((outs[i] != ref).sum()))
+            assert torch.equal(scr[i][: nbytes - 1024], ref_scr[: nbytes - 1024]), i

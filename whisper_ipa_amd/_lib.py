@@ -19,6 +19,7 @@ DEC_GLOBAL, DEC_PER_LAYER, DEC_FP8_PER_LAYER = 4, 20, 6
 GEMM_DISPATCH = ("tile128", "tile256", "tile384", "tile384n", "tile256p", "skinny", "skinny_fp8", "skinny_ln", "kmajor", "split_k",
                  "tile_fp8")
 ENC_FP8_PER_LAYER = 8
+DEC_ABSORBED_PER_LAYER = 1
 
 c_void_p, c_int, c_int64, c_size_t, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
 
@@ -79,7 +80,7 @@ class ModelCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n_mels", "n_audio_ctx", "n_audio_state", "n_audio_head", "n_audio_layer",
         "n_vocab", "n_text_ctx", "n_text_state", "n_text_head", "n_text_layer", "dtype", "f32_split", "dec_w_dtype", "weights_generation",
-        "enc_act_fp8")]
+        "enc_act_fp8", "dec_cross_absorbed")]
 
 
 class DecLayout(C.Structure):
@@ -120,6 +121,12 @@ SIGNATURES = {
     "wipa_decode_cross_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "wipa_decode_self_block": (c_int, [_P(SelfBlockDesc), c_void_p]),
     "wipa_decode_cross_block": (c_int, [_P(CrossBlockDesc), c_void_p]),
+    "wipa_cross_absorbed_splits": (c_int, [c_int, c_int]),
+    "wipa_cross_absorbed_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "wipa_cross_absorbed_init": (c_int, [c_int]),
+    "wipa_cross_absorbed_attention": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_size_t,
+                                              c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "wipa_cross_absorbed_stream": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_void_p]),
     "wipa_greedy_step": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int,
                                  c_int, c_void_p, c_void_p, c_void_p]),
     "wipa_add_i32": (c_int, [c_void_p, C.c_int32, c_void_p]),

@@ -1,0 +1,781 @@
+// Decode-step cross-attention with the key / value projections ABSORBED (round 3).
+//
+// mlx_whisper's MultiHeadAttention (behind DecodingTask._main_loop, scripts/transcribe_single.py:55) projects the encoder
+// output xa [1500, d] of a clip to K_l = xa Wk_l^T and V_l = xa Wv_l^T + bv_l once per decoder layer l and caches them; every
+// decode step then streams K_l and V_l: 2 x 1500 x d values per clip, layer and step -- 55.3 MB per clip and step for
+// whisper-small, the dominant HBM stream of the whole transcription.  But both are linear images of the
+// SAME xa:
+//
+//     scores_h = q_h K_h^T = (q_h Wk_h) xa^T            Wk_h = rows h*64 .. h*64+63 of Wk   [64, d]
+//     out_h    = P_h V_h   = (P_h xa) Wv_h^T + bv_h     (sum_t P_h[t] = 1)
+//
+// so a step can read xa ONCE per layer for the scores and for the values: half the bytes, no K/V cache (3.5 GB -> 0.15 GB
+// per 64 clips), no cross-K/V projection GEMMs (42.5 GFLOP per clip), and xa is the same for all layers.  The price is
+// arithmetic -- the contraction runs over d = 768 channels instead of 64 per head, 12x the FLOPs -- which is why it only works
+// on the matrix cores, with the 12 heads of a clip as one 16-wide MFMA dimension:
+//
+//   wipa_cross_absorb_q      Qp[b][h][:] = scale * q_h[b] Wk_h              [B, 16, d] bf16 (heads 12..15 stay zero)
+//   wipa_cross_absorbed_attn one workgroup per (clip, frame split): 32-frame tiles of xa stream through LDS by LDS-DMA
+//                            (2 x 48 KiB, two tiles in flight); per tile S^T[32 frames, 16 heads] = tile Qp^T (channels split
+//                            over the 4 waves, partial sums exchanged through LDS in a fixed order), online softmax per
+//                            head, O'[16 heads, d] += P tile with the SAME tile read column-wise by ds_read_b64_tr_b16 --
+//                            the P accumulator tile is the A operand as it stands (k order 4g+j | 16+4g+j, which the
+//                            transposed reads follow); partial (m, l, O') per split
+//   wipa_cross_merge_proj    merges the splits (fixed order), out_h = (O'_h / l_h) Wv_h^T + bv_h -> [B, d] bf16
+//
+// Rounding points differ from the cached-K/V path (K and V are never rounded to bf16 here; Qp and O' are): the results
+// are equal up to bf16 noise, and closer to the f32 arithmetic.  bf16 models with <= 16 heads and d in {384, 512, 768, 1024}.
+#include <cstdlib>
+
+#include "wipa_common.h"
+
+namespace {
+
+constexpr float NEG_BIG = -1.0e30f;
+constexpr int FT = 32;  // frames per tile
+typedef __attribute__((address_space(3))) void* lds_ptr_a;
+typedef int v2i32 __attribute__((ext_vector_type(2)));
+
+struct AbsParams {
+    const __bf16* qp;     // [B][16][D]
+    const __bf16* xa;     // [B][Tk][D]
+    float* part_m;        // [B][S][16]
+    float* part_l;        // [B][S][16]
+    float* part_o;        // [B][S][16][D]
+    int Tk, n_splits, tiles_per_split;
+    int dbg;  // measurement aid (WIPA_ABS_DBG): 1 stream without arithmetic, 2 arithmetic without stream, 3 scores only, 4 P x tile only
+};
+
+// chunk swizzle of the LDS tile image: 16-byte chunk c of frame row r sits at chunk c ^ ((r & 7) << 1).  The four rows of a
+// transposed-read block (and the two blocks of a 32-lane half, 4 rows apart) then hit disjoint banks.
+__device__ __forceinline__ int swz(int row) { return (row & 7) << 1; }
+
+// NW waves split the channels (scores: k-steps; O': column tiles).  NBUF tile buffers: with three, two tiles are in flight
+// while one is being spent and a tile costs two workgroup barriers; with two (d = 1024: 64 KiB tiles) a third barrier guards
+// the buffer that is re-staged.
+template <int D>
+struct AbsCfg {
+#ifndef WIPA_ABS_NW
+#define WIPA_ABS_NW 4
+#endif
+#ifndef WIPA_ABS_NBUF
+#define WIPA_ABS_NBUF 3
+#endif
+    static constexpr int NW = (WIPA_ABS_NW == 8 && D % 256 == 0) ? 8 : 4;
+    static constexpr int ROWB = D * 2;
+    static constexpr int TILE = FT * ROWB;
+    static constexpr int SX = NW * 2 * 64 * 4 * (int)sizeof(float);
+    static constexpr int NBUF = (WIPA_ABS_NBUF == 3 && 3 * TILE + SX <= 160 * 1024) ? 3 : 2;
+#ifdef WIPA_ABS_FULL_LDS
+    static constexpr int SMEM = 160 * 1024;  // experiment: the whole CU's LDS, no co-resident workgroup
+#else
+    static constexpr int SMEM = NBUF * TILE + SX;
+#endif
+};
+
+template <int D>
+__global__ __launch_bounds__(512, 1) void cross_absorbed_kernel(AbsParams p) {
+    typedef AbsCfg<D> X;
+    constexpr int NW = X::NW, ROWB = X::ROWB, TILE = X::TILE, NBUF = X::NBUF;
+    constexpr int NDMA = TILE / 1024 / NW;    // LDS-DMA transfers per wave and tile (1 KiB each)
+    constexpr int KS = D / NW / 32;           // k-steps (32 channels) of the score product per wave
+    constexpr int CT = D / NW / 16;           // 16-channel column tiles of O' per wave
+    static_assert(D % (32 * NW) == 0 && TILE % (1024 * NW) == 0, "width");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];  // [NBUF tiles][FT rows][ROWB] | sx [NW][2][64][4] f32
+    float* sx = reinterpret_cast<float*>(smem + NBUF * TILE);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int split = blockIdx.x, b = blockIdx.y;
+    const int tile0 = split * p.tiles_per_split;
+    const int n_tiles_total = (p.Tk + FT - 1) / FT;
+    const int nt = max(0, min(p.tiles_per_split, n_tiles_total - tile0));
+    const __bf16* xb = p.xa + (int64_t)b * p.Tk * D;
+
+    // Qp fragments of this wave's channels: B operand of the score product, lane (head = l15, k-group g)
+    bf16x8 qf[KS];
+    {
+        const __bf16* qr = p.qp + ((int64_t)b * 16 + l15) * D + wave * (D / NW) + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qr + 32 * ks);
+    }
+    // LDS-DMA: transfer i of this wave covers image bytes [1024 (NDMA wave + i), +1024); a lane's 16 bytes sit at image
+    // (row, chunk') and come from source chunk chunk' ^ swz(row) of that frame
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, 0x7fffffff, 0x00020000);
+    int drow[NDMA], dch[NDMA];
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+        const int off = 1024 * (NDMA * wave + i) + 16 * lane;
+        drow[i] = off / ROWB;
+        dch[i] = ((off % ROWB) >> 4) ^ swz(off / ROWB);
+    }
+    auto stage = [&](int t, int buf) {
+#if defined(WIPA_ABS_DEBUG) && WIPA_ABS_DEBUG == 2
+        if (t > 1) return;  // timing experiment: the arithmetic alone on whatever the buffers hold
+#endif
+        const int f0 = (tile0 + t) * FT;
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            const int voff = min(f0 + drow[i], p.Tk - 1) * ROWB + dch[i] * 16;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_ptr_a)(smem + buf * TILE + 1024 * (NDMA * wave + i)), 16, voff, 0, 0, 0);
+        }
+    };
+    auto wait_dma = [&](bool one_behind) {  // this wave's transfers of the current tile have landed (one younger tile may fly on)
+        if (one_behind) {
+            if constexpr (NDMA == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if constexpr (NDMA == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if constexpr (NDMA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if constexpr (NDMA == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if constexpr (NDMA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if constexpr (NDMA == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
+    f32x4 acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = NEG_BIG, l_run = 0.f;  // of head l15 (replicated over the four lane groups)
+
+    if (nt > 0) stage(0, 0);
+    if (nt > 1) stage(1, 1);
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_a)smem;
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t % NBUF;
+        wait_dma(t + 1 < nt);
+        __builtin_amdgcn_s_barrier();  // every wave's share of tile t has landed; every wave is done with tile t - 1
+        asm volatile("" ::: "memory");
+        if constexpr (NBUF == 3) {
+            if (t + 2 < nt) stage(t + 2, (t + 2) % 3);  // into the buffer tile t - 1 has just left
+        }
+#if defined(WIPA_ABS_DEBUG) && WIPA_ABS_DEBUG == 1
+        continue;  // timing experiment: the stream alone (DMA + one barrier per tile), no arithmetic
+#endif
+        const char* tb = smem + buf * TILE;
+        // ---- partial scores over this wave's channels: S^T[frame 16 ft + 4g + r][head l15]
+        f32x4 s[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft) {
+            const int row = 16 * ft + l15;
+            const char* rp = tb + row * ROWB;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int ch = (4 * (KS * wave + ks) + g) ^ swz(row);
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(rp + 16 * ch);
+                s[ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], s[ft], 0, 0, 0);
+            }
+        }
+        *reinterpret_cast<f32x4*>(sx + ((wave * 2 + 0) * 64 + lane) * 4) = s[0];
+        *reinterpret_cast<f32x4*>(sx + ((wave * 2 + 1) * 64 + lane) * 4) = s[1];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft) {
+            f32x4 tot = *reinterpret_cast<const f32x4*>(sx + ((0 * 2 + ft) * 64 + lane) * 4);
+#pragma unroll
+            for (int w = 1; w < NW; ++w) tot += *reinterpret_cast<const f32x4*>(sx + ((w * 2 + ft) * 64 + lane) * 4);  // fixed order
+            s[ft] = tot;
+        }
+        // ---- online softmax of head l15 over the tile's 32 frames (8 in this lane, the rest in lanes l15 + 16 k)
+        const int f0 = (tile0 + t) * FT;
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (f0 + 16 * ft + 4 * g + r >= p.Tk) s[ft][r] = NEG_BIG;
+                mx = fmaxf(mx, s[ft][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);
+        float pr[8], ls = 0.f;
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = (s[ft][r] <= -1.0e29f) ? 0.f : __expf(s[ft][r] - m_new);
+                pr[4 * ft + r] = e;
+                ls += e;
+            }
+        ls += __shfl_xor(ls, 16, 64);
+        ls += __shfl_xor(ls, 32, 64);
+        l_run = l_run * alpha + ls;
+        m_run = m_new;
+        // the accumulators hold heads 4g + r in their rows: fetch those heads' rescale factors from the lanes that own them
+        float al[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) al[r] = __shfl(alpha, 4 * g + r, 64);
+        bf16x8 pf;  // A operand of P x tile: row = head l15, k-slot (g, j) = frame (j < 4 ? 4g + j : 16 + 4g + j - 4)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (__bf16)pr[j];
+        // ---- O'[head][channel] += P x tile: the tile read column-wise (transposed LDS reads), 16 channels per column tile
+        {
+            const int q = l15 >> 2, pp = l15 & 3;
+            const int r1 = 4 * g + q, r2 = 16 + 4 * g + q;
+            const unsigned a1 = lds_base + buf * TILE + r1 * ROWB + 8 * (pp & 1);
+            const unsigned a2 = lds_base + buf * TILE + r2 * ROWB + 8 * (pp & 1);
+            const int cbase = (D / NW / 8) * wave + (pp >> 1);  // logical 16-byte chunk of column tile 0: (2 wave D/NW + 8 pp) / 16
+            typedef int v4i32x __attribute__((ext_vector_type(4)));
+            // Transposed reads and the wait that completes them live in ONE asm statement: the compiler believes an asm's
+            // outputs are written when the statement ends, so with the wait in a later statement it was free to copy a
+            // destination register before the LDS data had arrived -- harmless at idle-LDS latencies, wrong as soon as a
+            // co-resident workgroup of another stream slowed the LDS down (found as run-to-run id differences with four
+            // passes in flight).  Three column tiles (six reads) per statement.
+            static_assert(CT % 3 == 0 || CT % 2 == 0, "column tiles per wave");
+            constexpr int GB = (CT % 3 == 0) ? 3 : 2;
+#pragma unroll
+            for (int c0 = 0; c0 < CT; c0 += GB) {
+                v2i32 lo[3], hi[3];
+                unsigned ad[6];
+#pragma unroll
+                for (int c = 0; c < GB; ++c) {
+                    const int lc = cbase + 2 * (c0 + c);
+                    ad[2 * c] = a1 + 16 * (lc ^ swz(r1));
+                    ad[2 * c + 1] = a2 + 16 * (lc ^ swz(r2));
+                }
+                if constexpr (GB == 3) {
+                    asm volatile(
+                        "ds_read_b64_tr_b16 %0, %6\n\tds_read_b64_tr_b16 %1, %7\n\tds_read_b64_tr_b16 %2, %8\n\t"
+                        "ds_read_b64_tr_b16 %3, %9\n\tds_read_b64_tr_b16 %4, %10\n\tds_read_b64_tr_b16 %5, %11\n\t"
+                        "s_waitcnt lgkmcnt(0)"
+                        : "=&v"(lo[0]), "=&v"(hi[0]), "=&v"(lo[1]), "=&v"(hi[1]), "=&v"(lo[2]), "=&v"(hi[2])
+                        : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5])
+                        : "memory");
+                } else {
+                    asm volatile(
+                        "ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %5\n\tds_read_b64_tr_b16 %2, %6\n\t"
+                        "ds_read_b64_tr_b16 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                        : "=&v"(lo[0]), "=&v"(hi[0]), "=&v"(lo[1]), "=&v"(hi[1])
+                        : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3])
+                        : "memory");
+                }
+#pragma unroll
+                for (int c = 0; c < GB; ++c) {
+                    const bf16x8 xf = __builtin_bit_cast(bf16x8, v4i32x{lo[c][0], lo[c][1], hi[c][0], hi[c][1]});
+                    f32x4 o = acc[c0 + c];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] *= al[r];
+                    acc[c0 + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, xf, o, 0, 0, 0);
+                }
+            }
+        }
+        if constexpr (NBUF == 2) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // all waves are done with tile t: its buffer may be re-staged
+            asm volatile("" ::: "memory");
+            if (t + 2 < nt) stage(t + 2, buf);
+        }
+    }
+    // ---- partial results of this split
+    const int64_t ps = (int64_t)b * p.n_splits + split;
+    if (wave == 0 && g == 0) {
+        p.part_m[ps * 16 + l15] = m_run;
+        p.part_l[ps * 16 + l15] = l_run;
+    }
+    float* po = p.part_o + ps * 16 * D;
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) po[(int64_t)(4 * g + r) * D + wave * (D / NW) + 16 * c + l15] = acc[c][r];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Second form of the streaming kernel: INDEPENDENT WAVES.  The kernel above splits a tile's channels over the waves, which
+// costs two workgroup barriers, an exchange of partial scores through LDS and a redundant softmax per 32 frames -- a serial
+// chain of ~1.8 us per tile on one wave per SIMD, as long as the tile's DMA itself, and the two do not overlap well (measured:
+// stream alone 26.7 us, arithmetic alone 21.7 us, together 31-41 us per launch).  Here every wave is a flash-decoding worker
+// of its own: it stages its OWN 16-frame groups (two private 24 KiB slots, LDS-DMA, its own vmcnt waits -- no barrier in the
+// loop), computes the scores of its 16 frames over all 768 channels (24 MFMAs, the absorbed queries of all k-steps held in
+// registers), the softmax of 16 frames per head, and O'[16 heads x 768] += P x group on v_mfma_f32_16x16x16_bf16 with the
+// group read column-wise by ONE transposed read per column tile (a lane's four probabilities ARE the A fragment).  Three waves
+// per workgroup (6 x 24 KiB = 144 KiB of LDS); their (m, l, O') are merged through LDS once, at the end.
+typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+
+template <int D>
+struct AbsCfg2 {
+    static constexpr int NWV = 3;
+    static constexpr int GF = 16;                   // frames per group
+    static constexpr int ROWB = D * 2;
+    static constexpr int SLOT = GF * ROWB;          // 24 KiB for d = 768
+    static constexpr int SMEM_LOOP = NWV * 2 * SLOT;
+    static constexpr int SMEM_MERGE = NWV * 16 * D * 4 + NWV * 32 * 4;
+    static constexpr int SMEM = SMEM_LOOP > SMEM_MERGE ? SMEM_LOOP : SMEM_MERGE;
+};
+
+// eight transposed reads (column tiles 8 blk .. 8 blk + 7: per-lane addresses A[0..7] + one immediate) and their wait in ONE
+// asm statement (see the note on the first kernel: the outputs are only valid once the wait has run)
+#define WIPA_TR8(X, A, IMM)                                                                                                          \
+    asm volatile("ds_read_b64_tr_b16 %0, %8 offset:" #IMM "\n\tds_read_b64_tr_b16 %1, %9 offset:" #IMM                              \
+                 "\n\tds_read_b64_tr_b16 %2, %10 offset:" #IMM "\n\tds_read_b64_tr_b16 %3, %11 offset:" #IMM                          \
+                 "\n\tds_read_b64_tr_b16 %4, %12 offset:" #IMM "\n\tds_read_b64_tr_b16 %5, %13 offset:" #IMM                          \
+                 "\n\tds_read_b64_tr_b16 %6, %14 offset:" #IMM "\n\tds_read_b64_tr_b16 %7, %15 offset:" #IMM "\n\ts_waitcnt lgkmcnt(0)" \
+                 : "=&v"(X[0]), "=&v"(X[1]), "=&v"(X[2]), "=&v"(X[3]), "=&v"(X[4]), "=&v"(X[5]), "=&v"(X[6]), "=&v"(X[7])           \
+                 : "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(A[4]), "v"(A[5]), "v"(A[6]), "v"(A[7])                           \
+                 : "memory")
+
+template <int D>
+__global__ __launch_bounds__(192, 1) void cross_absorbed_v2_kernel(AbsParams p) {
+    typedef AbsCfg2<D> X;
+    constexpr int NWV = X::NWV, GF = X::GF, ROWB = X::ROWB, SLOT = X::SLOT;
+    constexpr int NDMA = SLOT / 1024;  // LDS-DMA transfers per group (24 for d = 768)
+    constexpr int KS = D / 32;         // k-steps of the score product
+    constexpr int CT = D / 16;         // column tiles of O'
+    static_assert(SLOT % 1024 == 0 && NDMA <= 32 && CT % 8 == 0 && KS % 4 == 0 && CT / 8 <= 6 && D % 128 == 0, "width");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int split = blockIdx.x, b = blockIdx.y;
+    const int groups_total = (p.Tk + GF - 1) / GF;
+    const int gps = 2 * p.tiles_per_split;  // 16-frame groups per split (tiles_per_split counts 32-frame tiles)
+    const int g0 = split * gps;
+    const int ng = max(0, min(gps, groups_total - g0));            // groups of this split
+    const int my_n = ng > wave ? (ng - wave + NWV - 1) / NWV : 0;  // this wave takes groups wave, wave + 3, ...
+    const __bf16* xb = p.xa + (int64_t)b * p.Tk * D;
+    char* my = smem + wave * (2 * SLOT);
+
+    bf16x8 qf[KS];  // absorbed queries, all k-steps: B operand of the scores, lane (head l15, k-group g)
+    {
+        const __bf16* qr = p.qp + ((int64_t)b * 16 + l15) * D + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qr + 32 * ks);
+    }
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, 0x7fffffff, 0x00020000);
+    // LDS-DMA: transfer i covers image bytes [1024 i, +1024) of a slot; a lane's 16 bytes sit at image (row, chunk') and come
+    // from source chunk chunk' ^ swz(row).  The (row, chunk') of (i, lane) is recomputed per transfer from a laundered lane id:
+    // 24 precomputed offsets per lane would cost 24 registers this kernel does not have.
+    int lane_v = lane;
+    auto stage = [&](int i_local, int slot) {
+        const int f0 = (g0 + wave + NWV * i_local) * GF;
+        asm volatile("" : "+v"(lane_v));
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            const int off = 1024 * i + 16 * lane_v;
+            const int row = off / ROWB;
+            const int ch = ((off - row * ROWB) >> 4) ^ swz(row);
+            const int voff = min(f0 + row, p.Tk - 1) * ROWB + ch * 16;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_ptr_a)(my + slot * SLOT + 1024 * i), 16, voff, 0, 0, 0);
+        }
+    };
+    const unsigned lds_my = (unsigned)(uintptr_t)(lds_ptr_a)my;
+    // per-lane LDS addresses (slot 0).  Scores: row l15, k-step ks -> 256 (ks >> 2) + 64 ((ks & 3) ^ t) + 16 (g ^ (sw & 3)): four
+    // bases + an immediate.  Transposed reads: rows 4g + q, column tile 8 blk + cc -> 256 blk + 32 (cc ^ k) + 16 (pp >> 1) + 8 (pp & 1):
+    // eight bases + an immediate.
+    const char* sb[4];
+    {
+        const int sw = swz(l15), t = (sw >> 2) & 3;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sb[u] = my + l15 * ROWB + 64 * (u ^ t) + 16 * (g ^ (sw & 3));
+    }
+    unsigned ta[8];
+    {
+        const int q = l15 >> 2, pp = l15 & 3, r1 = 4 * g + q, k = r1 & 7;
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) ta[cc] = lds_my + r1 * ROWB + 32 * (cc ^ k) + 16 * (pp >> 1) + 8 * (pp & 1);
+    }
+    auto wait_slot = [&](bool more_in_flight) {
+        if (more_in_flight) {
+            if constexpr (NDMA == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else if constexpr (NDMA == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if constexpr (NDMA == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
+    // scores S^T[frame 4g + r][head l15] of one group over all channels (four interleaved accumulation chains), frames past the
+    // end masked; mx = the head's maximum over the group's 16 frames
+    auto scores = [&](int slot, int i_local, float& mx) -> f32x4 {
+        f32x4 s4[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        const int so = slot * SLOT;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(sb[ks & 3] + so + 256 * (ks >> 2));
+            s4[ks & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], s4[ks & 3], 0, 0, 0);
+        }
+        f32x4 s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        const int f0 = (g0 + wave + NWV * i_local) * GF;
+        mx = NEG_BIG;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (f0 + 4 * g + r >= p.Tk) s[r] = NEG_BIG;
+            mx = fmaxf(mx, s[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        return s;
+    };
+    // Softmax against a FIXED per-head reference m_ref (the maximum over the wave's first group) instead of a running maximum:
+    // p = exp(s - m_ref) may exceed 1 -- bf16 and f32 carry the range -- and O' is never rescaled.  The 192 accumulators live in
+    // the accumulation registers; any conditional multiply of them makes the compiler copy all of them to vector registers at
+    // the top of every iteration and spill the queries.  If a later group's maximum climbs more than DRIFT above the reference
+    // (e^40 x 1500 frames x |xa| stays far inside f32), the wave starts over: one scores-only sweep finds its exact maximum,
+    // then the stream is redone against that.  Same input -> same path -> same bits.
+    constexpr float DRIFT = 40.f;
+    f32x4 acc[CT];
+    float m_ref = NEG_BIG, l_run = 0.f;
+    bool exact = false;
+    for (;;) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        l_run = 0.f;
+        bool drifted = false;
+        if (my_n > 0) stage(0, 0);
+        if (my_n > 1) stage(1, 1);
+        for (int i = 0; i < my_n; ++i) {
+            const int slot = i & 1;
+            if (p.dbg != 2) wait_slot(i + 1 < my_n);
+            if (p.dbg == 1) {
+                if (i + 2 < my_n) stage(i + 2, slot);
+                continue;
+            }
+            float mx;
+            f32x4 s;
+            if (p.dbg == 4) { s = f32x4{0.f, 0.f, 0.f, 0.f}; mx = 0.f; }
+            else s = scores(slot, i, mx);
+            if (i == 0 && !exact) m_ref = mx;
+            if (__builtin_amdgcn_ballot_w64(mx > m_ref + DRIFT) != 0) {
+                drifted = true;
+                break;
+            }
+            float ls = 0.f;
+            bf16x4v pf;  // A operand of P x group (16x16x16): row = head l15, k = frames 4g .. 4g + 3 -- the lane's own values
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = (s[r] <= -1.0e29f) ? 0.f : __expf(s[r] - m_ref);
+                pf[r] = (__bf16)e;
+                ls += e;
+            }
+            ls += __shfl_xor(ls, 16, 64);
+            ls += __shfl_xor(ls, 32, 64);
+            l_run += ls;
+            // ---- O'[head][channel] += P x group: ONE transposed read per column tile (rows = frames 4g + q, 16 channels)
+            if (p.dbg != 3) {
+                unsigned tas[8];
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) tas[cc] = ta[cc] + slot * SLOT;
+#define WIPA_PV_BLK(BLK, IMM)                                                                                                       \
+    if constexpr (CT / 8 > BLK) {                                                                                                   \
+        v2i32 x[8];                                                                                                                 \
+        WIPA_TR8(x, tas, IMM);                                                                                                      \
+        _Pragma("unroll") for (int cc = 0; cc < 8; ++cc) acc[8 * BLK + cc] =                                                       \
+            __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pf, __builtin_bit_cast(bf16x4v, x[cc]), acc[8 * BLK + cc], 0, 0, 0);         \
+    }
+                WIPA_PV_BLK(0, 0)
+                WIPA_PV_BLK(1, 256)
+                WIPA_PV_BLK(2, 512)
+                WIPA_PV_BLK(3, 768)
+                WIPA_PV_BLK(4, 1024)
+                WIPA_PV_BLK(5, 1280)
+#undef WIPA_PV_BLK
+            }
+            // every read of this slot has completed (score fragments are spent, the transposed reads were waited for): re-stage
+            asm volatile("" ::: "memory");
+            if (i + 2 < my_n && p.dbg != 2) stage(i + 2, slot);
+        }
+        if (!drifted) break;
+        // rare: exact maximum of this wave's frames, scores only
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float mt = NEG_BIG;
+        stage(0, 0);
+        if (my_n > 1) stage(1, 1);
+        for (int i = 0; i < my_n; ++i) {
+            const int slot = i & 1;
+            wait_slot(i + 1 < my_n);
+            float mx;
+            (void)scores(slot, i, mx);
+            mt = fmaxf(mt, mx);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (i + 2 < my_n) stage(i + 2, slot);
+        }
+        m_ref = mt;
+        exact = true;
+    }
+    const float m_run = m_ref;
+    // ---- merge the three waves' (m, l, O') through LDS: one partial per workgroup
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float* so = reinterpret_cast<float*>(smem);                   // [NWV][16 heads][D]
+    float* sm = so + NWV * 16 * D;                                // [NWV][16] m, then [NWV][16] l
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) so[(wave * 16 + 4 * g + r) * D + 16 * c + l15] = acc[c][r];
+    if (g == 0) {
+        sm[wave * 16 + l15] = m_run;
+        sm[NWV * 16 + wave * 16 + l15] = l_run;
+    }
+    __syncthreads();
+    const int64_t ps = (int64_t)b * p.n_splits + split;
+    float* po = p.part_o + ps * 16 * D;
+    for (int e = tid; e < 16 * D; e += NWV * 64) {
+        const int hd = e / D;
+        float M = NEG_BIG;
+#pragma unroll
+        for (int v = 0; v < NWV; ++v) M = fmaxf(M, sm[v * 16 + hd]);
+        float o = 0.f;
+#pragma unroll
+        for (int v = 0; v < NWV; ++v) o += __expf(sm[v * 16 + hd] - M) * so[v * 16 * D + e];  // fixed order
+        po[e] = o;
+    }
+    if (tid < 16) {
+        float M = NEG_BIG, Lsum = 0.f;
+#pragma unroll
+        for (int v = 0; v < NWV; ++v) M = fmaxf(M, sm[v * 16 + tid]);
+#pragma unroll
+        for (int v = 0; v < NWV; ++v) Lsum += __expf(sm[v * 16 + tid] - M) * sm[NWV * 16 + v * 16 + tid];
+        p.part_m[ps * 16 + tid] = M;
+        p.part_l[ps * 16 + tid] = Lsum;
+    }
+}
+#undef WIPA_TR8
+
+// Qp[b][h][c] = scale * sum_j q[b][h*64 + j] WkT[c][h*64 + j]     (WkT = Wk^T, [d_in][d_out]: 16-byte loads along j)
+// one WAVE per (head 0..15, 16 clips, channel quarter): 192 short independent chains instead of 48 workgroups; heads >= H are
+// the zero rows of the 16-wide MFMA dimension
+template <int D>
+__global__ __launch_bounds__(64) void cross_absorb_q_kernel(const __bf16* __restrict__ q, int64_t q_rs, const __bf16* __restrict__ wkT,
+                                                            __bf16* __restrict__ qp, int B, int H, float scale) {
+    constexpr int CT = D / 4 / 16;
+    const int lane = threadIdx.x & 63, wave = blockIdx.z;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x, b0 = blockIdx.y * 16;
+    if (h >= H) {
+        for (int e = lane; e < 16 * (D / 4); e += 64) {
+            const int bb = b0 + e / (D / 4);
+            if (bb < B) qp[((int64_t)bb * 16 + h) * D + wave * (D / 4) + e % (D / 4)] = (__bf16)0.f;
+        }
+        return;
+    }
+    const int bq = min(b0 + l15, B - 1);
+    bf16x8 qa[2];  // A operand: row = clip l15, k = j
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qa[ks] = *reinterpret_cast<const bf16x8*>(q + (int64_t)bq * q_rs + h * 64 + 32 * ks + 8 * g);
+    bf16x8 wb[CT][2];
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            wb[i][ks] = *reinterpret_cast<const bf16x8*>(wkT + (int64_t)(wave * (D / 4) + 16 * i + l15) * D + h * 64 + 32 * ks + 8 * g);
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+        const int c0 = wave * (D / 4) + 16 * i;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[ks], wb[i][ks], acc, 0, 0, 0);
+        // acc[r] = Qp[clip b0 + 4g + r][channel c0 + l15]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int bb = b0 + 4 * g + r;
+            if (bb < B) qp[((int64_t)bb * 16 + h) * D + c0 + l15] = (__bf16)(acc[r] * scale);
+        }
+    }
+}
+
+// merge of the frame splits (fixed order) and the absorbed value projection: out[b][h*64 + j] = (O'_h / l_h) . Wv[h*64 + j] + bv.
+// One workgroup per (head, clip) -- H x B of them, like the cross block's query GEMV: the merged row goes to LDS (rounded through
+// bf16, the activation dtype), then 4 threads per output column walk the 64 weight rows of the head (98 KB, L2-resident).
+template <int D>
+__global__ __launch_bounds__(256) void cross_merge_proj_kernel(const float* __restrict__ part_m, const float* __restrict__ part_l,
+                                                               const float* __restrict__ part_o, int n_splits, const __bf16* __restrict__ wv,
+                                                               const float* __restrict__ bv, __bf16* __restrict__ out, int64_t o_rs, int B) {
+    __shared__ __attribute__((aligned(16))) float on[D];
+    const int tid = threadIdx.x;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int j = tid >> 2, part = tid & 3;
+    constexpr int NCH = D / 8;  // 16-byte chunks of a weight row
+    constexpr int UQ = (NCH + 3) / 4;
+    const __bf16* wr = wv + (int64_t)(h * 64 + j) * D;
+    bf16x8 wq[UQ];  // this thread's chunks part, part + 4, ... of row j: requested before anything else
+#pragma unroll
+    for (int u = 0; u < UQ; ++u) wq[u] = *reinterpret_cast<const bf16x8*>(wr + min(part + 4 * u, NCH - 1) * 8);
+    const float bj = bv[h * 64 + j];
+    // split weights exp(m_s - M) / L: every thread computes them for itself (8 cached floats) -- no shared array, no
+    // single-thread section
+    float ws[8];
+    {
+        float M = NEG_BIG;
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            if (s < n_splits) M = fmaxf(M, part_m[((int64_t)b * n_splits + s) * 16 + h]);
+        float Lsum = 0.f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            ws[s] = 0.f;
+            if (s < n_splits) {
+                ws[s] = __expf(part_m[((int64_t)b * n_splits + s) * 16 + h] - M);
+                Lsum += ws[s] * part_l[((int64_t)b * n_splits + s) * 16 + h];
+            }
+        }
+        const float inv = 1.0f / Lsum;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) ws[s] *= inv;
+    }
+    const int c = tid * 4;
+    if (c < D) {
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 8; ++s)  // fixed order
+            if (s < n_splits) v += ws[s] * *reinterpret_cast<const f32x4*>(part_o + (((int64_t)b * n_splits + s) * 16 + h) * D + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (float)(__bf16)v[e];
+        *reinterpret_cast<f32x4*>(on + c) = v;
+    }
+    __syncthreads();
+    float a = 0.f;
+#pragma unroll
+    for (int u = 0; u < UQ; ++u) {
+        if (part + 4 * u < NCH) {
+            const float* xp = on + (part + 4 * u) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a = fmaf(xp[e], (float)wq[u][e], a);
+        }
+    }
+    a += __shfl_xor(a, 1, 64);
+    a += __shfl_xor(a, 2, 64);
+    if (part == 0) out[(int64_t)b * o_rs + h * 64 + j] = (__bf16)(a + bj);
+}
+
+// WIPA_ABS_KERNEL=1 keeps the channel-split kernel (A/B runs); default: the independent-wave kernel
+template <int D>
+int launch_attn(const AbsParams& p_in, int B, hipStream_t s) {
+    const char* e = getenv("WIPA_ABS_KERNEL");
+    const char* dbg = getenv("WIPA_ABS_DBG");
+    AbsParams p = p_in;
+    p.dbg = dbg ? atoi(dbg) : 0;
+    if ((e && atoi(e) == 1) || D > 768)  // d = 1024: 64 column tiles are all 256 accumulation registers -- the channel-split form
+        hipLaunchKernelGGL((cross_absorbed_kernel<D>), dim3(p.n_splits, B), dim3(64 * AbsCfg<D>::NW), AbsCfg<D>::SMEM, s, p);
+    else if constexpr (D <= 768)
+        hipLaunchKernelGGL((cross_absorbed_v2_kernel<D>), dim3(p.n_splits, B), dim3(64 * AbsCfg2<D>::NWV), AbsCfg2<D>::SMEM, s, p);
+    return WIPA_OK;
+}
+
+}  // namespace
+
+// Frame splits per clip: FOUR, whatever the batch -- a clip's result must not depend on the batch it rides in (the partition
+// of the frames fixes the order of the softmax merges), and a workgroup streams the same 375 frames at the same per-CU rate
+// whether 1 or 256 clips are decoded; 64 clips x 4 splits are exactly one round on the 256 CUs (the kernel holds a CU: 104 KiB
+// of LDS).  Short inputs: at least two 32-frame tiles per split.
+extern "C" int wipa_cross_absorbed_splits(int B, int Tk) {
+    (void)B;
+    const int tiles = (Tk + FT - 1) / FT;
+    int s = 4;
+    if (s > tiles / 2) s = tiles / 2;
+    return s < 1 ? 1 : s;
+}
+
+extern "C" size_t wipa_cross_absorbed_scratch_bytes(int B, int d, int Tk) {
+    const size_t S = (size_t)wipa_cross_absorbed_splits(B, Tk);
+    return (size_t)B * 16 * d * 2 + (size_t)B * S * 16 * (2 + (size_t)d) * 4 + 1024;
+}
+
+extern "C" int wipa_cross_absorbed_init(int d) {
+    // raise the dynamic-LDS limit outside any stream capture
+    AbsParams p = {};
+    (void)p;
+    hipError_t e = hipSuccess;
+#define ABS_ATTR(D)                                                                                                                        \
+    {                                                                                                                                      \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_absorbed_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                AbsCfg<D>::SMEM);                                                                                          \
+        if (e == hipSuccess && D <= 768)                                                                                                   \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_absorbed_v2_kernel<(D <= 768 ? D : 768)>),                        \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, AbsCfg2<(D <= 768 ? D : 768)>::SMEM);                      \
+    }
+    if (d == 384) ABS_ATTR(384)
+    else if (d == 512) ABS_ATTR(512)
+    else if (d == 768) ABS_ATTR(768)
+    else if (d == 1024) ABS_ATTR(1024)
+    else return WIPA_ERR_ARG;
+#undef ABS_ATTR
+    WIPA_CHECK_HIP(e);
+    return WIPA_OK;
+}
+
+// the streaming kernel alone on a scratch whose Qp a wipa_cross_absorbed_attention call has filled (measurement aid: bench.py
+// times the dominant kernel of the decode step by itself)
+extern "C" int wipa_cross_absorbed_stream(const void* xa, void* scratch, size_t scratch_bytes, int B, int H, int d, int Tk,
+                                          wipa_stream_t stream) {
+    WIPA_REQUIRE(xa && scratch && B > 0 && H >= 1 && H <= 16 && d == H * 64 && (d == 384 || d == 512 || d == 768 || d == 1024) && Tk >= 1,
+                 "wipa_cross_absorbed_stream: bad arguments");
+    WIPA_REQUIRE(scratch_bytes >= wipa_cross_absorbed_scratch_bytes(B, d, Tk), "wipa_cross_absorbed_stream: scratch too small");
+    const int rc0 = wipa_cross_absorbed_init(d);
+    if (rc0 != WIPA_OK) return rc0;
+    const int S = wipa_cross_absorbed_splits(B, Tk);
+    char* sc = (char*)scratch;
+    AbsParams p;
+    p.qp = (const __bf16*)sc; p.xa = (const __bf16*)xa;
+    p.part_m = (float*)(sc + (size_t)B * 16 * d * 2);
+    p.part_l = p.part_m + (size_t)B * S * 16;
+    p.part_o = p.part_l + (size_t)B * S * 16;
+    p.Tk = Tk; p.n_splits = S;
+    const int tiles = (Tk + FT - 1) / FT;
+    p.tiles_per_split = (tiles + S - 1) / S;
+    int rc;
+    if (d == 384) rc = launch_attn<384>(p, B, (hipStream_t)stream);
+    else if (d == 512) rc = launch_attn<512>(p, B, (hipStream_t)stream);
+    else if (d == 768) rc = launch_attn<768>(p, B, (hipStream_t)stream);
+    else rc = launch_attn<1024>(p, B, (hipStream_t)stream);
+    if (rc != WIPA_OK) return rc;
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+extern "C" int wipa_cross_absorbed_attention(const void* q, int64_t q_row_stride, const void* wkT, const void* xa, const void* wv,
+                                             const float* bv, void* out, int64_t out_row_stride, void* scratch, size_t scratch_bytes,
+                                             int B, int H, int d, int Tk, float k_scale, wipa_stream_t stream) {
+    WIPA_REQUIRE(q && wkT && xa && wv && bv && out && scratch, "wipa_cross_absorbed_attention: null pointer");
+    WIPA_REQUIRE(B > 0 && B <= 65535 && H >= 1 && H <= 16 && d == H * 64 && (d == 384 || d == 512 || d == 768 || d == 1024) && Tk >= 1,
+                 "wipa_cross_absorbed_attention: bf16, <= 16 heads of 64, d in {384, 512, 768, 1024} (got H=%d d=%d)", H, d);
+    WIPA_REQUIRE(q_row_stride % 8 == 0 && out_row_stride >= d && ((uintptr_t)q % 16) == 0 && ((uintptr_t)xa % 16) == 0 &&
+                     ((uintptr_t)wkT % 16) == 0 && ((uintptr_t)wv % 16) == 0 && ((uintptr_t)scratch % 16) == 0,
+                 "wipa_cross_absorbed_attention: operands must be 16-byte aligned");
+    WIPA_REQUIRE((int64_t)Tk * d * 2 < ((int64_t)1 << 31), "wipa_cross_absorbed_attention: clip too long for 32-bit tile offsets");
+    WIPA_REQUIRE(scratch_bytes >= wipa_cross_absorbed_scratch_bytes(B, d, Tk), "wipa_cross_absorbed_attention: scratch too small");
+    hipStream_t s = (hipStream_t)stream;
+    {
+        static bool attr_done[4] = {false, false, false, false};
+        const int wi = d == 384 ? 0 : d == 512 ? 1 : d == 768 ? 2 : 3;
+        if (!attr_done[wi]) {
+            const int rc0 = wipa_cross_absorbed_init(d);
+            if (rc0 != WIPA_OK) return rc0;
+            attr_done[wi] = true;
+        }
+    }
+    const int S = wipa_cross_absorbed_splits(B, Tk);
+    char* sc = (char*)scratch;
+    __bf16* qp = (__bf16*)sc;
+    float* part_m = (float*)(sc + (size_t)B * 16 * d * 2);
+    float* part_l = part_m + (size_t)B * S * 16;
+    float* part_o = part_l + (size_t)B * S * 16;
+    AbsParams p;
+    p.qp = qp; p.xa = (const __bf16*)xa; p.part_m = part_m; p.part_l = part_l; p.part_o = part_o;
+    p.Tk = Tk; p.n_splits = S;
+    const int tiles = (Tk + FT - 1) / FT;
+    p.tiles_per_split = (tiles + S - 1) / S;
+    const dim3 gq(16, (B + 15) / 16, 4), gm(H, B);
+    int rc = WIPA_OK;
+    const char* st_env = getenv("WIPA_ABS_STAGES");  // debugging: bit 0 absorb-q, bit 1 stream, bit 2 merge (default all)
+    const int stages = st_env ? atoi(st_env) : 7;
+#define ABS_RUN(D)                                                                                                                         \
+    do {                                                                                                                                   \
+        if (stages & 1)                                                                                                                    \
+            hipLaunchKernelGGL((cross_absorb_q_kernel<D>), gq, dim3(64), 0, s, (const __bf16*)q, q_row_stride, (const __bf16*)wkT, qp, B, H, k_scale); \
+        if (stages & 2) rc = launch_attn<D>(p, B, s);                                                                                      \
+        if (rc == WIPA_OK && (stages & 4))                                                                                                 \
+            hipLaunchKernelGGL((cross_merge_proj_kernel<D>), gm, dim3(256), 0, s, part_m, part_l, part_o, S, (const __bf16*)wv, bv,        \
+                               (__bf16*)out, out_row_stride, B);                                                                           \
+    } while (0)
+    if (d == 384) ABS_RUN(384);
+    else if (d == 512) ABS_RUN(512);
+    else if (d == 768) ABS_RUN(768);
+    else ABS_RUN(1024);
+#undef ABS_RUN
+    if (rc != WIPA_OK) return rc;
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}

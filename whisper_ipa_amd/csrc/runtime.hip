@@ -74,6 +74,11 @@ int cfg_check(const wipa_model_cfg* c) {
     WIPA_REQUIRE(c->n_audio_state % 64 == 0 && c->n_text_state % 64 == 0, "state must be a multiple of 64");
     WIPA_REQUIRE(c->dec_w_dtype == 0 || (c->dec_w_dtype == WIPA_FP8_E4M3 && c->dtype == WIPA_BF16),
                  "cfg.dec_w_dtype %d: fp8 (e4m3) decoder weights need a bf16 model", c->dec_w_dtype);
+    WIPA_REQUIRE(c->dec_cross_absorbed == 0 ||
+                     (c->dec_cross_absorbed == 1 && c->dtype == WIPA_BF16 && c->dec_w_dtype == 0 && c->n_text_head <= 16 &&
+                      (c->n_text_state == 384 || c->n_text_state == 512 || c->n_text_state == 768 || c->n_text_state == 1024)),
+                 "cfg.dec_cross_absorbed %d: absorbed cross-attention needs a bf16 model without fp8 decoder tables, <= 16 heads, d in "
+                 "{384, 512, 768, 1024}", c->dec_cross_absorbed);
     WIPA_REQUIRE(c->enc_act_fp8 == 0 || (c->enc_act_fp8 == 1 && c->dtype == WIPA_BF16 && c->n_audio_state % 128 == 0),
                  "cfg.enc_act_fp8 %d: fp8 encoder activations need a bf16 model whose width is a multiple of 128", c->enc_act_fp8);
     return WIPA_OK;
@@ -298,7 +303,7 @@ namespace {
 
 constexpr int MAX_SLABS = 4;
 struct DecScratch {
-    size_t x, x2, ln, q, ao, h, slabs, posd, total;
+    size_t x, x2, ln, q, ao, h, slabs, posd, absorbed, total;
 };
 // split-K factor of a decode-step residual GEMM: keep >= 3 fragment steps per wave (4 waves)
 inline int k_slices_for(int K, int dtype) {
@@ -322,6 +327,8 @@ DecScratch dec_scratch(const wipa_model_cfg* c, int B) {
     // split-K slabs of the unfused residual GEMMs, or one slab per head from the fused self block
     s.slabs = o; o += align256(std::max((size_t)MAX_SLABS * R, (size_t)c->n_text_head * B) * d * 4);
     s.posd = o; o += 256;
+    s.absorbed = o;  // Qp + split partials of the absorbed cross-attention (cfg.dec_cross_absorbed)
+    if (c->dec_cross_absorbed) o += align256(wipa_cross_absorbed_scratch_bytes(B, (int)d, c->n_audio_ctx));
     s.total = o;
     return s;
 }
@@ -338,7 +345,9 @@ wipa_dec_layout dec_layout(const wipa_model_cfg* c, int B) {
     L.sum_logprobs = o; o += align256((size_t)B * 4);
     L.ld_logits = round_up(c->n_vocab, 8);
     L.logits = o; o += align256((size_t)B * L.ld_logits * 4);
-    L.cross_kv = o; o += align256((size_t)c->n_text_layer * B * 2 * H * c->n_audio_ctx * 64 * e);
+    // cached cross K / V of every layer -- or, with absorbed projections, ONE copy of the encoder output [B, n_audio_ctx, d]
+    L.cross_kv = o; o += align256(c->dec_cross_absorbed ? (size_t)B * c->n_audio_ctx * d * e
+                                                        : (size_t)c->n_text_layer * B * 2 * H * c->n_audio_ctx * 64 * e);
     L.self_kv = o; o += align256((size_t)c->n_text_layer * 3 * B * c->n_text_ctx * d * e);
     L.scratch = o; o += dec_scratch(c, B).total;
     L.total_bytes = o;
@@ -370,7 +379,8 @@ int enqueue_step(const wipa_model_cfg* cfg, const void* const* w, char* st, cons
     char* sc = st + L.scratch;
     float* x = (float*)(sc + S.x);
     float* x_other = (float*)(sc + S.x2);
-    const bool cross_fused = decode_mode(cfg, B) == 2;
+    const bool absorbed = cfg->dec_cross_absorbed != 0;
+    const bool cross_fused = !absorbed && decode_mode(cfg, B) == 2;
     void* ln = sc + S.ln;
     void* q = sc + S.q;
     void* ao = sc + S.ao;
@@ -448,7 +458,15 @@ int enqueue_step(const wipa_model_cfg* cfg, const void* const* w, char* st, cons
                 g.col_scale_n = d; g.col_scale = QK_SCALE;
                 RT_CALL(gemm(ln, d, lw[8], d, q, d, B, d, d, dt, dt, (const float*)lw[9], 0, nullptr, stream, &g));
             }
-            RT_CALL(wipa_decode_cross_attn(q, ckv, ao, B, H, Ta, dt, stream));
+            if (absorbed) {
+                // scores and values from ONE pass over the encoder output: Wk absorbed into the query, Wv into the output
+                const void* wkT = w[WIPA_DEC_GLOBAL + WIPA_DEC_PER_LAYER * cfg->n_text_layer + WIPA_DEC_ABSORBED_PER_LAYER * l];
+                RT_CALL(wipa_cross_absorbed_attention(q, d, wkT, st + L.cross_kv, (const char*)lw[10] + (size_t)d * d * e,
+                                                      (const float*)lw[11] + d, ao, d, sc + S.absorbed, S.total - S.absorbed, B, H, d, Ta,
+                                                      QK_SCALE, stream));
+            } else {
+                RT_CALL(wipa_decode_cross_attn(q, ckv, ao, B, H, Ta, dt, stream));
+            }
         }
         RT_CALL(residual_gemm(ao, d, lw[12], lw[13]));
         RT_CALL(ln_step(lw[14], lw[15]));
@@ -548,7 +566,7 @@ int decode_mode(const wipa_model_cfg* cfg, int B) {
     if (m == 0 || cfg->dec_w_dtype != 0 || cfg->n_text_state > 1280 || cfg->n_text_head > 20 || B > 65535) return 0;
     return m == 1 ? 1 : 2;
 }
-bool use_fused_step(const wipa_model_cfg* cfg, int B) { return decode_mode(cfg, B) == 1; }
+bool use_fused_step(const wipa_model_cfg* cfg, int B) { return !cfg->dec_cross_absorbed && decode_mode(cfg, B) == 1; }
 
 int enqueue_decode_step(const wipa_model_cfg* cfg, const void* const* w, char* st, const wipa_dec_layout& L, int B, int n_init,
                         int eot, const float* mask_first, const float* mask_always, wipa_stream_t stream) {
@@ -636,7 +654,17 @@ int enqueue_prefill(const wipa_model_cfg* cfg, const void* const* w, char* st, c
             g.col_scale_n = d; g.col_scale = QK_SCALE;
             RT_CALL(gemm(ln, d, lw[8], d, q, d, M, d, d, dt, dt, (const float*)lw[9], 0, nullptr, stream, &g));
         }
-        RT_CALL(wipa_decode_cross_attn_multi(q, ckv, ao, B, H, Ta, P, dt, stream));
+        if (cfg->dec_cross_absorbed) {
+            // one absorbed pass per prompt position: rows (b, t) of q / ao with row stride P * d
+            const void* wkT = w[WIPA_DEC_GLOBAL + WIPA_DEC_PER_LAYER * cfg->n_text_layer + WIPA_DEC_ABSORBED_PER_LAYER * l];
+            for (int t = 0; t < P; ++t)
+                RT_CALL(wipa_cross_absorbed_attention((const char*)q + (size_t)t * d * e, (int64_t)P * d, wkT, st + L.cross_kv,
+                                                      (const char*)lw[10] + (size_t)d * d * e, (const float*)lw[11] + d,
+                                                      (char*)ao + (size_t)t * d * e, (int64_t)P * d, sc + S.absorbed, S.total - S.absorbed, B,
+                                                      H, d, Ta, QK_SCALE, stream));
+        } else {
+            RT_CALL(wipa_decode_cross_attn_multi(q, ckv, ao, B, H, Ta, P, dt, stream));
+        }
         RT_CALL(residual_gemm(ao, d, lw[12], lw[13]));
         RT_CALL(ln_step(lw[14], lw[15]));
         {
@@ -682,9 +710,10 @@ bool graphs_allowed() {
     return !counters_attached();
 }
 // every kernel attribute the step needs, set outside any capture
-int init_before_capture() {
+int init_before_capture(const wipa_model_cfg* cfg) {
     RT_CALL(wipa_decode_fused_init());
     RT_CALL(wipa_gemm_init());
+    if (cfg && cfg->dec_cross_absorbed) RT_CALL(wipa_cross_absorbed_init(cfg->n_text_state));
     return WIPA_OK;
 }
 
@@ -744,6 +773,11 @@ extern "C" int wipa_decoder_set_audio(const wipa_model_cfg* cfg, const void* con
     const size_t e = wipa_dtype_size(dt);
     const int d = cfg->n_text_state, H = cfg->n_text_head, Ta = cfg->n_audio_ctx;
     WIPA_REQUIRE(cfg->n_audio_state == d, "encoder/decoder widths differ");
+    if (cfg->dec_cross_absorbed) {
+        // no key / value projection and no cache: the decode steps stream the encoder output itself (csrc/cross_absorbed.hip)
+        WIPA_CHECK_HIP(hipMemcpyAsync((char*)state + L.cross_kv, features, (size_t)B * Ta * d * e, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        return WIPA_OK;
+    }
     for (int l = 0; l < cfg->n_text_layer; ++l) {
         const void* const* lw = w + WIPA_DEC_GLOBAL + WIPA_DEC_PER_LAYER * l;
         char* ckv = (char*)state + L.cross_kv + (size_t)l * B * 2 * H * Ta * 64 * e;
@@ -791,7 +825,7 @@ extern "C" int wipa_decoder_run(const wipa_model_cfg* cfg, const void* const* w,
     const wipa_dec_layout L = dec_layout(cfg, B);
     char* st = (char*)state;
     hipStream_t s = (hipStream_t)stream;
-    RT_CALL(init_before_capture());
+    RT_CALL(init_before_capture(cfg));
     if (!use_graph || !graphs_allowed()) {
         for (int i = 0; i < n_steps; ++i)
             RT_CALL(enqueue_decode_step(cfg, w, st, L, B, n_init, eot, mask_first, mask_always, stream));
@@ -799,7 +833,7 @@ extern "C" int wipa_decoder_run(const wipa_model_cfg* cfg, const void* const* w,
     }
     WIPA_REQUIRE(s != nullptr, "wipa_decoder_run: graph capture needs a non-default stream");
     hipGraphExec_t exec = nullptr;
-    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * decode_mode(cfg, B) + 16 * cfg->dec_w_dtype, cfg->weights_generation, 0);
+    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * decode_mode(cfg, B) + 16 * cfg->dec_w_dtype + 64 * cfg->dec_cross_absorbed, cfg->weights_generation, 0);
     {
         std::lock_guard<std::mutex> lk(g_graph_mu);
         auto it = g_graphs.find(key);
@@ -838,10 +872,10 @@ extern "C" int wipa_decoder_prefill(const wipa_model_cfg* cfg, const void* const
         return enqueue_prefill(cfg, w, st, L, B, n_init, eot, mask_first, mask_always, stream);
     };
     hipStream_t s = (hipStream_t)stream;
-    RT_CALL(init_before_capture());
+    RT_CALL(init_before_capture(cfg));
     if (!use_graph || s == nullptr || !graphs_allowed()) return enqueue();
     hipGraphExec_t exec = nullptr;
-    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * decode_mode(cfg, B) + 16 * cfg->dec_w_dtype, cfg->weights_generation, 1);
+    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * decode_mode(cfg, B) + 16 * cfg->dec_w_dtype + 64 * cfg->dec_cross_absorbed, cfg->weights_generation, 1);
     {
         std::lock_guard<std::mutex> lk(g_graph_mu);
         auto it = g_graphs.find(key);

@@ -117,15 +117,24 @@ class _Part:
 
 class Whisper:
     def __init__(self, dims: ModelDimensions, dtype: torch.dtype = torch.float32, f32_split: bool = False,
-                 sinusoid_rounding: str = "f32"):
+                 sinusoid_rounding: str = "f32", cross_attention: str = "auto"):
         """``f32_split`` (float32 models only): let the large GEMMs and the encoder attention take every f32 product as
         split-bf16 MFMA terms (about twice as fast, ~5e-6 relative error per dot product).  Off by default: the reference
         computes in true float32 (train_whisper_ipa.py:505, transcribe_single.py:13).
         ``sinusoid_rounding``: "f32" (default) adds the encoder's sinusoid table as computed in float32, which is what the
         published algorithm does; "fp16" rounds the table to fp16 first -- SURVEY.md App. C.3: mlx_whisper builds
         ``_positional_embedding`` in the load dtype (fp16) and ``set_dtype(float32)`` does not touch the private attribute
-        [UPSTREAM-UNVERIFIED], so a reference run may carry the rounded table (features move by ~1e-3).  The choice is
+        [UPSTREAM-UNVERIFIED], so a reference run may carry the rounded table (features move by ~1e-3).
+        ``cross_attention``: how a decode step reads the audio.  "cached": K = xa Wk^T and V = xa Wv^T + bv are projected once
+        per decoder layer and streamed every step, as mlx_whisper caches them.  "absorbed": Wk is absorbed into the query and
+        Wv into the output, and every layer streams the encoder output xa itself -- half the bytes per step, no K/V cache, no
+        projection GEMMs (csrc/cross_absorbed.hip); bf16 models with <= 16 heads and d in {384, 512, 768, 1024}, no fp8 tables.
+        "auto" (default): absorbed where it applies (WIPA_CROSS_ABSORB=0 turns that off).  Same mathematics, other bf16
+        rounding points.  The choice is
         explicit here and in the CPU checker, and both settings are pinned by golden fixtures (tests/golden/wide_model.npz)."""
+        if cross_attention not in ("auto", "absorbed", "cached"):
+            raise _lib.WipaError(f"cross_attention must be 'auto', 'absorbed' or 'cached', got {cross_attention!r}")
+        self.cross_attention = cross_attention
         if sinusoid_rounding not in ("f32", "fp16"):
             raise _lib.WipaError(f"sinusoid_rounding must be 'f32' or 'fp16', got {sinusoid_rounding!r}")
         self.sinusoid_rounding = sinusoid_rounding
@@ -277,13 +286,29 @@ class Whisper:
         self._packed = None
         self._packed_tf = None
 
+    @property
+    def cross_absorbed(self) -> bool:
+        """whether decode steps use the absorbed-projection cross-attention (see ``cross_attention`` in __init__)"""
+        import os
+
+        d = self.dims
+        eligible = (self.dtype == torch.bfloat16 and not self._fp8 and d.n_text_head <= 16 and d.n_text_state in (384, 512, 768, 1024)
+                    and d.n_text_state == d.n_audio_state)
+        if self.cross_attention == "absorbed":
+            if not eligible:
+                raise _lib.WipaError("cross_attention='absorbed' needs a bf16 model without fp8 tables, <= 16 heads, d in {384, 512, 768, 1024}")
+            return True
+        if self.cross_attention == "cached":
+            return False
+        return eligible and os.environ.get("WIPA_CROSS_ABSORB", "1") != "0"
+
     # ---- packing -------------------------------------------------------------------
     def _cfg(self, fp8: bool = False) -> _lib.ModelCfg:
         d = self.dims
         return _lib.ModelCfg(d.n_mels, d.n_audio_ctx, d.n_audio_state, d.n_audio_head, d.n_audio_layer, d.n_vocab,
                              d.n_text_ctx, d.n_text_state, d.n_text_head, d.n_text_layer, dt_code(self.dtype),
                              int(self.f32_split and self.dtype == torch.float32), _lib.WIPA_FP8_E4M3 if fp8 else 0,
-                             getattr(self, "_generation", 0), int(bool(self._fp8_enc)))
+                             getattr(self, "_generation", 0), int(bool(self._fp8_enc)), int(self.cross_absorbed and not fp8))
 
     def packed(self, teacher_forced: bool = False):
         """(cfg, encoder table, decoder table); fused matrices are rebuilt after any update.  With fp8 weights the decoder
@@ -357,6 +382,9 @@ class Whisper:
                         enc.append(torch.cat([E[n][1] for n in names], 0).to(device=self.device, dtype=f32).contiguous())
                 assert len(enc) == _lib.ENC_GLOBAL + (_lib.ENC_PER_LAYER + _lib.ENC_FP8_PER_LAYER) * d.n_audio_layer
             assert len(dec) == _lib.DEC_GLOBAL + _lib.DEC_PER_LAYER * d.n_text_layer
+            if self.cross_absorbed and not fp8:  # absorbed cross-attention tail: Wk^T per layer (WIPA_DEC_ABSORBED_PER_LAYER)
+                for i in range(d.n_text_layer):
+                    dec.append(mat(P[f"decoder.blocks.{i}.cross_attn.key.weight"]).t().contiguous())
             if fp8:
                 # the decode-step matrices as e4m3 codes (rows concatenated like their bf16 counterparts) + per-row scales
                 F = self._fp8
