@@ -42,8 +42,7 @@ struct AbsParams {
     float* part_m;        // [B][S][16]
     float* part_l;        // [B][S][16]
     float* part_o;        // [B][S][16][D]
-    int Tk, n_splits, tiles_per_split;
-    int dbg;  // measurement aid (WIPA_ABS_DBG): 1 stream without arithmetic, 2 arithmetic without stream, 3 scores only, 4 P x tile only
+    int Tk, n_splits, tiles_per_split, H;
 };
 
 // chunk swizzle of the LDS tile image: 16-byte chunk c of frame row r sits at chunk c ^ ((r & 7) << 1).  The four rows of a
@@ -302,7 +301,8 @@ struct AbsCfg2 {
     static constexpr int ROWB = D * 2;
     static constexpr int SLOT = GF * ROWB;          // 24 KiB for d = 768
     static constexpr int SMEM_LOOP = NWV * 2 * SLOT;
-    static constexpr int SMEM_MERGE = NWV * 16 * D * 4 + NWV * 32 * 4;
+    static constexpr int MROW = D + 4;              // padded row of the final merge image
+    static constexpr int SMEM_MERGE = NWV * 16 * MROW * 4 + NWV * 32 * 4;
     static constexpr int SMEM = SMEM_LOOP > SMEM_MERGE ? SMEM_LOOP : SMEM_MERGE;
 };
 
@@ -428,15 +428,9 @@ __global__ __launch_bounds__(192, 1) void cross_absorbed_v2_kernel(AbsParams p) 
         if (my_n > 1) stage(1, 1);
         for (int i = 0; i < my_n; ++i) {
             const int slot = i & 1;
-            if (p.dbg != 2) wait_slot(i + 1 < my_n);
-            if (p.dbg == 1) {
-                if (i + 2 < my_n) stage(i + 2, slot);
-                continue;
-            }
+            wait_slot(i + 1 < my_n);
             float mx;
-            f32x4 s;
-            if (p.dbg == 4) { s = f32x4{0.f, 0.f, 0.f, 0.f}; mx = 0.f; }
-            else s = scores(slot, i, mx);
+            const f32x4 s = scores(slot, i, mx);
             if (i == 0 && !exact) m_ref = mx;
             if (__builtin_amdgcn_ballot_w64(mx > m_ref + DRIFT) != 0) {
                 drifted = true;
@@ -454,7 +448,7 @@ __global__ __launch_bounds__(192, 1) void cross_absorbed_v2_kernel(AbsParams p) 
             ls += __shfl_xor(ls, 32, 64);
             l_run += ls;
             // ---- O'[head][channel] += P x group: ONE transposed read per column tile (rows = frames 4g + q, 16 channels)
-            if (p.dbg != 3) {
+            {
                 unsigned tas[8];
 #pragma unroll
                 for (int cc = 0; cc < 8; ++cc) tas[cc] = ta[cc] + slot * SLOT;
@@ -475,7 +469,7 @@ __global__ __launch_bounds__(192, 1) void cross_absorbed_v2_kernel(AbsParams p) 
             }
             // every read of this slot has completed (score fragments are spent, the transposed reads were waited for): re-stage
             asm volatile("" ::: "memory");
-            if (i + 2 < my_n && p.dbg != 2) stage(i + 2, slot);
+            if (i + 2 < my_n) stage(i + 2, slot);
         }
         if (!drifted) break;
         // rare: exact maximum of this wave's frames, scores only
@@ -499,12 +493,15 @@ __global__ __launch_bounds__(192, 1) void cross_absorbed_v2_kernel(AbsParams p) 
     // ---- merge the three waves' (m, l, O') through LDS: one partial per workgroup
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    float* so = reinterpret_cast<float*>(smem);                   // [NWV][16 heads][D]
-    float* sm = so + NWV * 16 * D;                                // [NWV][16] m, then [NWV][16] l
+    // rows padded by 4 floats: the four lane groups of a wave write rows 4 apart, (D + 4) * 16 bytes = 64 mod 256 spreads them over
+    // the banks; one float4 column per thread and one head per sweep in the sum (NWV * 64 = D / 4 threads)
+    constexpr int RS = X::MROW;
+    float* so = reinterpret_cast<float*>(smem);                   // [NWV][16 heads][RS]
+    float* sm = so + NWV * 16 * RS;                               // [NWV][16] m, then [NWV][16] l
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) so[(wave * 16 + 4 * g + r) * D + 16 * c + l15] = acc[c][r];
+        for (int r = 0; r < 4; ++r) so[(wave * 16 + 4 * g + r) * RS + 16 * c + l15] = acc[c][r];
     if (g == 0) {
         sm[wave * 16 + l15] = m_run;
         sm[NWV * 16 + wave * 16 + l15] = l_run;
@@ -512,15 +509,21 @@ __global__ __launch_bounds__(192, 1) void cross_absorbed_v2_kernel(AbsParams p) 
     __syncthreads();
     const int64_t ps = (int64_t)b * p.n_splits + split;
     float* po = p.part_o + ps * 16 * D;
-    for (int e = tid; e < 16 * D; e += NWV * 64) {
-        const int hd = e / D;
-        float M = NEG_BIG;
+    static_assert(NWV * 64 >= D / 4, "one float4 column per thread");
+    for (int hd = 0; hd < p.H; ++hd) {  // rows of the padded heads are never read by the merge
+        float mv[NWV], M = NEG_BIG;
 #pragma unroll
-        for (int v = 0; v < NWV; ++v) M = fmaxf(M, sm[v * 16 + hd]);
-        float o = 0.f;
+        for (int v = 0; v < NWV; ++v) {
+            mv[v] = sm[v * 16 + hd];
+            M = fmaxf(M, mv[v]);
+        }
+        if (4 * tid < D) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int v = 0; v < NWV; ++v) o += __expf(sm[v * 16 + hd] - M) * so[v * 16 * D + e];  // fixed order
-        po[e] = o;
+            for (int v = 0; v < NWV; ++v)  // fixed order
+                o += __expf(mv[v] - M) * *reinterpret_cast<const f32x4*>(so + (v * 16 + hd) * RS + 4 * tid);
+            *reinterpret_cast<f32x4*>(po + hd * D + 4 * tid) = o;
+        }
     }
     if (tid < 16) {
         float M = NEG_BIG, Lsum = 0.f;
@@ -577,76 +580,121 @@ __global__ __launch_bounds__(64) void cross_absorb_q_kernel(const __bf16* __rest
 }
 
 // merge of the frame splits (fixed order) and the absorbed value projection: out[b][h*64 + j] = (O'_h / l_h) . Wv[h*64 + j] + bv.
-// One workgroup per (head, clip) -- H x B of them, like the cross block's query GEMV: the merged row goes to LDS (rounded through
-// bf16, the activation dtype), then 4 threads per output column walk the 64 weight rows of the head (98 KB, L2-resident).
+// One workgroup per (head, 4 clips): the clips are rows of the MFMA tile, the head's 64 outputs four column tiles, and the waves
+// each take a 96-channel slice of the reduction dimension: a lane merges exactly the 8-channel pieces of its clip that its A
+// fragments need (4 splits x 2 float4 per k-step, rounded through bf16, the activation dtype), the weight fragments come straight
+// from L2, and the slice sums meet in LDS in a fixed order.  Measured alternatives at 64 clips: one workgroup per (head, clip)
+// reading the head's 98 KB of weights each -- 75 MB of L2 reads, 8.7 us; one per (head, 16 clips) -- 48 workgroups pull the
+// 9.4 MB of partials through 48 CUs, 11.7 us.
 template <int D>
-__global__ __launch_bounds__(256) void cross_merge_proj_kernel(const float* __restrict__ part_m, const float* __restrict__ part_l,
-                                                               const float* __restrict__ part_o, int n_splits, const __bf16* __restrict__ wv,
-                                                               const float* __restrict__ bv, __bf16* __restrict__ out, int64_t o_rs, int B) {
-    __shared__ __attribute__((aligned(16))) float on[D];
-    const int tid = threadIdx.x;
-    const int h = blockIdx.x, b = blockIdx.y;
-    const int j = tid >> 2, part = tid & 3;
-    constexpr int NCH = D / 8;  // 16-byte chunks of a weight row
-    constexpr int UQ = (NCH + 3) / 4;
-    const __bf16* wr = wv + (int64_t)(h * 64 + j) * D;
-    bf16x8 wq[UQ];  // this thread's chunks part, part + 4, ... of row j: requested before anything else
+struct MergeCfg {
+    static constexpr int KQ = (D % 96 == 0) ? 96 : (D == 512 ? 64 : 128);  // channels per wave
+    static constexpr int NWM = D / KQ;                                       // waves: 4 (d = 384), 8 (512, 768, 1024)
+    static constexpr int KS = KQ / 32;
+    static constexpr int CL = 4;  // clips per workgroup
+};
+
+template <int D>
+__global__ __launch_bounds__(64 * MergeCfg<D>::NWM) void cross_merge_proj_kernel(
+    const float* __restrict__ part_m, const float* __restrict__ part_l, const float* __restrict__ part_o, int n_splits,
+    const __bf16* __restrict__ wv, const float* __restrict__ bv, __bf16* __restrict__ out, int64_t o_rs, int B) {
+    constexpr int KQ = MergeCfg<D>::KQ, KS = MergeCfg<D>::KS, NWM = MergeCfg<D>::NWM;
+    static_assert(KQ % 32 == 0 && NWM * KQ == D, "width");
+    constexpr int CL = MergeCfg<D>::CL;
+    __shared__ __attribute__((aligned(16))) float red[NWM][CL][64 + 4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x, b0 = blockIdx.y * CL;
+    // this lane's clip (A rows): only CL of the tile's 16 rows are distinct clips -- the others repeat them (same addresses, one
+    // fetch) and their results are dropped; rows past B are clamped the same way
+    const int bc = min(b0 + (l15 & (CL - 1)), B - 1);
+    // every load of the kernel is requested before the first use (the partials were just written by other XCDs: each miss is a
+    // trip to memory): weight fragments -- column tile nt, k-step ks -> Wv[h*64 + 16 nt + l15][w KQ + 32 ks + 8 g ..] ...
+    bf16x8 wq[4][KS];
 #pragma unroll
-    for (int u = 0; u < UQ; ++u) wq[u] = *reinterpret_cast<const bf16x8*>(wr + min(part + 4 * u, NCH - 1) * 8);
-    const float bj = bv[h * 64 + j];
-    // split weights exp(m_s - M) / L: every thread computes them for itself (8 cached floats) -- no shared array, no
-    // single-thread section
-    float ws[8];
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            wq[nt][ks] = *reinterpret_cast<const bf16x8*>(wv + (int64_t)(h * 64 + 16 * nt + l15) * D + w * KQ + 32 * ks + 8 * g);
+    // ... the split statistics of this lane's clip ...
+    float pm[4], pl[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int sc = min(s, n_splits - 1);
+        pm[s] = part_m[((int64_t)bc * n_splits + sc) * 16 + h];
+        pl[s] = part_l[((int64_t)bc * n_splits + sc) * 16 + h];
+    }
+    // ... and the 8-channel pieces of the partial rows its A fragments are made of
+    f32x4 po[KS][4][2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int sc = min(s, n_splits - 1);
+            const float* pr = part_o + (((int64_t)bc * n_splits + sc) * 16 + h) * D + w * KQ + 32 * ks + 8 * g;
+            po[ks][s][0] = *reinterpret_cast<const f32x4*>(pr);
+            po[ks][s][1] = *reinterpret_cast<const f32x4*>(pr + 4);
+        }
+    __builtin_amdgcn_sched_barrier(0);
+    // split weights exp(m_s - M) / L: every lane computes them for itself (no shared array, no single-thread section: see the
+    // determinism test)
+    float ws[4];
     {
         float M = NEG_BIG;
 #pragma unroll
-        for (int s = 0; s < 8; ++s)
-            if (s < n_splits) M = fmaxf(M, part_m[((int64_t)b * n_splits + s) * 16 + h]);
+        for (int s = 0; s < 4; ++s)
+            if (s < n_splits) M = fmaxf(M, pm[s]);
         float Lsum = 0.f;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            ws[s] = 0.f;
-            if (s < n_splits) {
-                ws[s] = __expf(part_m[((int64_t)b * n_splits + s) * 16 + h] - M);
-                Lsum += ws[s] * part_l[((int64_t)b * n_splits + s) * 16 + h];
-            }
+        for (int s = 0; s < 4; ++s) {
+            ws[s] = s < n_splits ? __expf(pm[s] - M) : 0.f;
+            Lsum += ws[s] * pl[s];
         }
         const float inv = 1.0f / Lsum;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) ws[s] *= inv;
+        for (int s = 0; s < 4; ++s) ws[s] *= inv;
     }
-    const int c = tid * 4;
-    if (c < D) {
-        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int s = 0; s < 8; ++s)  // fixed order
-            if (s < n_splits) v += ws[s] * *reinterpret_cast<const f32x4*>(part_o + (((int64_t)b * n_splits + s) * 16 + h) * D + c);
+    for (int ks = 0; ks < KS; ++ks) {
+        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (float)(__bf16)v[e];
-        *reinterpret_cast<f32x4*>(on + c) = v;
+        for (int s = 0; s < 4; ++s) {  // fixed order; splits past n_splits carry weight 0
+            lo += ws[s] * po[ks][s][0];
+            hi += ws[s] * po[ks][s][1];
+        }
+        bf16x8 a;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a[e] = (__bf16)lo[e];
+            a[4 + e] = (__bf16)hi[e];
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wq[nt][ks], acc[nt], 0, 0, 0);
+    }
+    // acc[nt][r] = this wave's share of the sum for tile row 4g + r (clip b0 + r in lane group 0), output 16 nt + l15
+    static_assert(CL == 4, "rows 0..3 of the tile are lane group 0");
+    if (g == 0) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[w][r][16 * nt + l15] = acc[nt][r];
     }
     __syncthreads();
-    float a = 0.f;
+    for (int e = tid; e < CL * 64; e += 64 * NWM) {
+        const int row = e >> 6, j = e & 63;
+        float o = 0.f;
 #pragma unroll
-    for (int u = 0; u < UQ; ++u) {
-        if (part + 4 * u < NCH) {
-            const float* xp = on + (part + 4 * u) * 8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) a = fmaf(xp[e], (float)wq[u][e], a);
-        }
+        for (int v = 0; v < NWM; ++v) o += red[v][row][j];  // fixed order
+        if (b0 + row < B) out[(int64_t)(b0 + row) * o_rs + h * 64 + j] = (__bf16)(o + bv[h * 64 + j]);
     }
-    a += __shfl_xor(a, 1, 64);
-    a += __shfl_xor(a, 2, 64);
-    if (part == 0) out[(int64_t)b * o_rs + h * 64 + j] = (__bf16)(a + bj);
 }
 
 // WIPA_ABS_KERNEL=1 keeps the channel-split kernel (A/B runs); default: the independent-wave kernel
 template <int D>
 int launch_attn(const AbsParams& p_in, int B, hipStream_t s) {
     const char* e = getenv("WIPA_ABS_KERNEL");
-    const char* dbg = getenv("WIPA_ABS_DBG");
-    AbsParams p = p_in;
-    p.dbg = dbg ? atoi(dbg) : 0;
+    const AbsParams& p = p_in;
     if ((e && atoi(e) == 1) || D > 768)  // d = 1024: 64 column tiles are all 256 accumulation registers -- the channel-split form
         hipLaunchKernelGGL((cross_absorbed_kernel<D>), dim3(p.n_splits, B), dim3(64 * AbsCfg<D>::NW), AbsCfg<D>::SMEM, s, p);
     else if constexpr (D <= 768)
@@ -707,12 +755,12 @@ extern "C" int wipa_cross_absorbed_stream(const void* xa, void* scratch, size_t 
     if (rc0 != WIPA_OK) return rc0;
     const int S = wipa_cross_absorbed_splits(B, Tk);
     char* sc = (char*)scratch;
-    AbsParams p;
+    AbsParams p = {};
     p.qp = (const __bf16*)sc; p.xa = (const __bf16*)xa;
     p.part_m = (float*)(sc + (size_t)B * 16 * d * 2);
     p.part_l = p.part_m + (size_t)B * S * 16;
     p.part_o = p.part_l + (size_t)B * S * 16;
-    p.Tk = Tk; p.n_splits = S;
+    p.Tk = Tk; p.n_splits = S; p.H = H;
     const int tiles = (Tk + FT - 1) / FT;
     p.tiles_per_split = (tiles + S - 1) / S;
     int rc;
@@ -752,12 +800,12 @@ extern "C" int wipa_cross_absorbed_attention(const void* q, int64_t q_row_stride
     float* part_m = (float*)(sc + (size_t)B * 16 * d * 2);
     float* part_l = part_m + (size_t)B * S * 16;
     float* part_o = part_l + (size_t)B * S * 16;
-    AbsParams p;
+    AbsParams p = {};
     p.qp = qp; p.xa = (const __bf16*)xa; p.part_m = part_m; p.part_l = part_l; p.part_o = part_o;
-    p.Tk = Tk; p.n_splits = S;
+    p.Tk = Tk; p.n_splits = S; p.H = H;
     const int tiles = (Tk + FT - 1) / FT;
     p.tiles_per_split = (tiles + S - 1) / S;
-    const dim3 gq(16, (B + 15) / 16, 4), gm(H, B);
+    const dim3 gq(16, (B + 15) / 16, 4), gm(H, (B + 3) / 4);
     int rc = WIPA_OK;
     const char* st_env = getenv("WIPA_ABS_STAGES");  // debugging: bit 0 absorb-q, bit 1 stream, bit 2 merge (default all)
     const int stages = st_env ? atoi(st_env) : 7;
@@ -767,7 +815,7 @@ extern "C" int wipa_cross_absorbed_attention(const void* q, int64_t q_row_stride
             hipLaunchKernelGGL((cross_absorb_q_kernel<D>), gq, dim3(64), 0, s, (const __bf16*)q, q_row_stride, (const __bf16*)wkT, qp, B, H, k_scale); \
         if (stages & 2) rc = launch_attn<D>(p, B, s);                                                                                      \
         if (rc == WIPA_OK && (stages & 4))                                                                                                 \
-            hipLaunchKernelGGL((cross_merge_proj_kernel<D>), gm, dim3(256), 0, s, part_m, part_l, part_o, S, (const __bf16*)wv, bv,        \
+            hipLaunchKernelGGL((cross_merge_proj_kernel<D>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o, S, (const __bf16*)wv, bv,        \
                                (__bf16*)out, out_row_stride, B);                                                                           \
     } while (0)
     if (d == 384) ABS_RUN(384);
