@@ -4,13 +4,22 @@
 //   reflect-pad 200 | periodic Hann(400) | 400-point real DFT, hop 160 | |.|^2 of frames
 //   0..2999 | mel filterbank (Slaney) | log10(max(.,1e-10)) | max(., clip_max - 8) | (.+4)/4
 //
-// MI355X mapping: the STFT is ONE f32-MFMA GEMM with overlapping A rows -- frame t of a
-// clip is the 400 consecutive samples at t*160 of the reflect-padded signal (lda = 160)
-// and the window is folded into the [402 x 416] DFT matrix (K padded 400 -> 416 with zero
-// columns).  f32 MFMA is an exact fma chain, so the spectrum has fp32-DFT accuracy.
-// Power + mel + log10 + per-clip max and the final clamp/scale are two small HBM-bound
-// passes.  The mel output is written straight into the conv1 halo layout [B,3002,n_mels].
+// MI355X mapping (round 3): ONE kernel from the audio samples to log10(mel) -- the spectrum never reaches HBM.
+//   * The DFT of a real frame is folded in half: with the window inside the matrix, re[f] = sum_{k=1..200} C[f][k] e[k] and
+//     im[f] = sum_{k=1..199} S[f][k] o[k], e[k] = x[k] + x[400-k], o[k] = x[k] - x[400-k] (e[200] = x[200]; w[0] = 0 drops
+//     k = 0).  Half the multiply-adds of the 402 x 400 matrix, still an exact f32 fma chain on v_mfma_f32_16x16x4_f32.
+//   * A workgroup owns 128 frames of one clip: its 20 720-sample span is reflect-padded straight into LDS, every wave builds
+//     the e / o values of its 32 frames ONCE as MFMA B fragments (200 registers) and keeps them; the 13 frequency tiles'
+//     matrix chunks (16 bins x 200 x cos|sin = 25.6 KB) stream through a double-buffered LDS image shared by the 4 waves.
+//   * Transposed product S^T[f][t]: its accumulator layout (lane = frame, 4 registers = 4 bins) IS the B-fragment layout of
+//     the next MFMA, so power = re^2 + im^2 feeds the mel projection (again f32 MFMA, mel^T[j][t] += W[j][f] P^T[f][t],
+//     only the mel tiles a frequency tile overlaps) without leaving registers.
+//   * log10 + per-clip max (atomic) in the epilogue; the clamp / scale pass writes the conv1 halo layout [B,3002,n_mels].
+// The previous form (f32 STFT GEMM with overlapping rows -> 320 MB spectrum -> VALU mel kernel: 1.4 ms per 64 clips) stays
+// selectable with WIPA_LOGMEL=gemm for A/B runs and serves n_mels > 128.
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "wipa_common.h"
@@ -25,27 +34,41 @@ constexpr int ROWS_PER_CLIP = 3003;                 // 3001 frames + 2 dead rows
 constexpr int PAD_CLIP = ROWS_PER_CLIP * WIPA_HOP;  // 480480 samples per padded clip
 constexpr int PAD_SLACK = 1024;                     // readable tail for the K padding of the last rows
 
+// fused kernel geometry
+constexpr int FT_TILES = 13;                        // frequency tiles of 16 bins (208 >= 201)
+constexpr int FK = 200;                             // folded reduction length
+constexpr int CHUNK_F = 2 * FK * 16;                // floats per frequency tile: [cos | sin][200 k][16 bins]
+constexpr int WG_FRAMES = 128;                      // frames per workgroup (4 waves x 2 frame tiles)
+constexpr int SPAN = (WG_FRAMES - 1) * WIPA_HOP + WIPA_N_FFT + 1;  // 20 721 padded samples a workgroup touches
+constexpr int SPAN_LDS = SPAN + SPAN / 32 + 2;      // one skew word per 32 samples: frame starts (160 t) spread over the banks
+
 struct TableLayout {
-    size_t dft, melw, lo, hi, total;
+    size_t dft, melw, lo, hi, chunks, melt, jrange, total;
 };
+int mel_tiles(int n_mels) { return (n_mels + 15) / 16; }
 TableLayout table_layout(int n_mels) {
     TableLayout t;
     t.dft = 0;
     t.melw = t.dft + sizeof(float) * DFT_N * DFT_K;
     t.lo = t.melw + sizeof(float) * (size_t)n_mels * N_BINS;
     t.hi = t.lo + sizeof(int) * (size_t)n_mels;
-    t.total = ((t.hi + sizeof(int) * (size_t)n_mels + 255) / 256) * 256;
+    t.chunks = ((t.hi + sizeof(int) * (size_t)n_mels + 255) / 256) * 256;  // [13]{[cos|sin][200][16], [JT][4 r][64 lanes]} f32
+    t.melt = t.chunks;                                                      // (mel fragments live inside the chunks)
+    t.jrange = t.chunks + sizeof(float) * (size_t)FT_TILES * (CHUNK_F + mel_tiles(n_mels) * 256);  // [13][2] int: mel tile range
+    t.total = ((t.jrange + sizeof(int) * 2 * FT_TILES + 255) / 256) * 256;
     return t;
 }
 
 struct WsLayout {
     size_t padded, spec, logmel, gmax, total;
 };
+bool use_fused(int n_mels);
 WsLayout ws_layout(int B, int n_mels) {
     WsLayout w;
+    const bool fused = use_fused(n_mels);  // the fused kernel needs neither the padded copy of the audio nor the spectrum
     w.padded = 0;
-    w.spec = w.padded + (((size_t)B * PAD_CLIP + PAD_SLACK) * sizeof(float) + 255) / 256 * 256;
-    w.logmel = w.spec + ((size_t)B * ROWS_PER_CLIP * SPEC_LD * sizeof(float) + 255) / 256 * 256;
+    w.spec = w.padded + (fused ? 0 : (((size_t)B * PAD_CLIP + PAD_SLACK) * sizeof(float) + 255) / 256 * 256);
+    w.logmel = w.spec + (fused ? 0 : ((size_t)B * ROWS_PER_CLIP * SPEC_LD * sizeof(float) + 255) / 256 * 256);
     w.gmax = w.logmel + ((size_t)B * WIPA_N_FRAMES * n_mels * sizeof(float) + 255) / 256 * 256;
     w.total = w.gmax + (((size_t)B * sizeof(unsigned)) + 255) / 256 * 256;
     return w;
@@ -132,6 +155,161 @@ __global__ __launch_bounds__(256) void mel_norm_kernel(const float* __restrict__
     out[(int64_t)b * per_out + idx] = from_f32<TO>(v);
 }
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int span_addr(int s) { return s + (s >> 5); }
+
+typedef __attribute__((address_space(3))) void* lm_lds_ptr;
+
+// audio [B][480000] -> logmel [B][3000][n_mels] (log10 of the mel energies, unclamped) + per-clip maximum
+template <int JT>
+__global__ __launch_bounds__(256, 1) void logmel_fused_kernel(const float* __restrict__ audio, const float* __restrict__ chunks,
+                                                              const int* __restrict__ jrange, int n_mels, float* __restrict__ logmel,
+                                                              unsigned* __restrict__ gmax) {
+    constexpr int CHUNK = CHUNK_F + JT * 256;   // floats per frequency tile: cos | sin | mel fragments
+    constexpr int NDMA = CHUNK * 4 / 1024;      // 1-KiB LDS-DMA transfers per chunk (25 + JT)
+    extern __shared__ __attribute__((aligned(1024))) float lds[];
+    float* cbuf = lds;                          // [2][CHUNK]
+    float* span = lds + 2 * CHUNK;              // [SPAN_LDS]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y, t0 = blockIdx.x * WG_FRAMES;
+    const float* clip = audio + (int64_t)b * WIPA_N_SAMPLES;
+    // matrix chunks go global -> LDS by LDS-DMA (lane-linear 1-KiB pieces: the image is the table as it lies in memory), the
+    // pieces dealt round-robin to the four waves; chunk 0 is requested before the span is built
+    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)chunks, 0, 0x7fffffff, 0x00020000);
+    auto stage = [&](int p) {
+        float* dst = cbuf + (p & 1) * CHUNK;
+        for (int i = wave; i < NDMA; i += 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rC, (lm_lds_ptr)(dst + i * 256), 16, p * (CHUNK * 4) + i * 1024 + lane * 16, 0, 0, 0);
+    };
+    stage(0);
+    // reflect-padded samples of frames t0 .. t0 + 127: padded index j = 160 t0 + s, source j - 200 mirrored at both ends
+    // (edge not repeated), zero past the padded clip.  Eight loads in flight per thread.
+    for (int s0 = 0; s0 < SPAN; s0 += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int sidx = s0 + 256 * u + tid;
+            const int j = t0 * WIPA_HOP + sidx;
+            int src = j - WIPA_N_FFT / 2;
+            if (src < 0) src = -src;
+            if (src >= WIPA_N_SAMPLES) src = 2 * (WIPA_N_SAMPLES - 1) - src;
+            const bool ok = sidx < SPAN && j < WIPA_N_SAMPLES + WIPA_N_FFT;
+            v[u] = clip[ok ? src : 0];
+            if (!ok) v[u] = 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int sidx = s0 + 256 * u + tid;
+            if (sidx < SPAN) span[span_addr(sidx)] = v[u];
+        }
+    }
+    __syncthreads();
+    // B fragments of this wave's two frame tiles: k-step ks, lane (frame l15, k = 4 ks + g + 1)
+    float ef[2][FK / 4], of[2][FK / 4];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int base = (32 * wave + 16 * tt + l15) * WIPA_HOP;
+#pragma unroll
+        for (int ks = 0; ks < FK / 4; ++ks) {
+            const int k = 4 * ks + g + 1;
+            const float a = span[span_addr(base + k)];
+            const float c = span[span_addr(base + WIPA_N_FFT - k)];
+            ef[tt][ks] = k < 200 ? a + c : a;   // k = 200 pairs with itself
+            of[tt][ks] = k < 200 ? a - c : 0.f;
+        }
+    }
+    f32x4_t macc[JT][2];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) macc[jt][0] = macc[jt][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < FT_TILES; ++p) {
+        // chunk p has landed for every wave; the other buffer (read in iteration p - 1) is free for chunk p + 1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (p + 1 < FT_TILES) stage(p + 1);
+        const float* cc = cbuf + (p & 1) * CHUNK;  // cos rows [k][16], sin rows, mel fragments
+        const int j_lo = jrange[2 * p], j_hi = jrange[2 * p + 1];
+        f32x4_t re[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+        f32x4_t im[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < FK / 4; ++ks) {
+            const float ac = cc[(4 * ks + g) * 16 + l15];
+            const float as = cc[FK * 16 + (4 * ks + g) * 16 + l15];
+            re[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac, ef[0][ks], re[0], 0, 0, 0);
+            im[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(as, of[0][ks], im[0], 0, 0, 0);
+            re[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac, ef[1][ks], re[1], 0, 0, 0);
+            im[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(as, of[1][ks], im[1], 0, 0, 0);
+        }
+        // power of bins 16 p + 4 g + r for frame l15: the B fragments of the mel projection (k-step r <-> bin 4 g + r)
+        f32x4_t pw[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pw[tt][r] = fmaf(re[tt][r], re[tt][r], im[tt][r] * im[tt][r]);
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            if (jt >= j_lo && jt < j_hi) {  // uniform
+                const float* wt = cc + CHUNK_F + jt * 256 + lane;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float wf = wt[r * 64];
+                    macc[jt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf, pw[0][r], macc[jt][0], 0, 0, 0);
+                    macc[jt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf, pw[1][r], macc[jt][1], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // macc[jt][tt][r] = mel energy of mel 16 jt + 4 g + r, frame t0 + 32 wave + 16 tt + l15
+    float mx = -INFINITY;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int t = t0 + 32 * wave + 16 * tt + l15;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            const int j = 16 * jt + 4 * g;
+            f32x4_t v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = log10f(fmaxf(macc[jt][tt][r], 1e-10f));
+                if (t < WIPA_N_FRAMES && j + r < n_mels) mx = fmaxf(mx, v[r]);
+            }
+            if (t < WIPA_N_FRAMES && j + 3 < n_mels)
+                *reinterpret_cast<f32x4_t*>(logmel + ((int64_t)b * WIPA_N_FRAMES + t) * n_mels + j) = v;
+            else if (t < WIPA_N_FRAMES) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (j + r < n_mels) logmel[((int64_t)b * WIPA_N_FRAMES + t) * n_mels + j + r] = v[r];
+            }
+        }
+    }
+    mx = wave_reduce_max(mx);
+    if (lane == 0) atomicMax(gmax + b, f32_key(mx));
+}
+
+constexpr size_t fused_lds(int JT) { return ((size_t)((SPAN_LDS + 3) & ~3) + 2 * (size_t)(CHUNK_F + JT * 256)) * sizeof(float); }
+
+template <int JT>
+int launch_fused(const float* audio, int batch, int n_mels, const char* tb, const TableLayout& L, float* logmel, unsigned* gmax,
+                 hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        WIPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&logmel_fused_kernel<JT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds(JT)));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((logmel_fused_kernel<JT>), dim3((WIPA_N_FRAMES + WG_FRAMES - 1) / WG_FRAMES, batch), dim3(256), fused_lds(JT), s,
+                       audio, (const float*)(tb + L.chunks), (const int*)(tb + L.jrange), n_mels, logmel, gmax);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+bool use_fused(int n_mels) {
+    static const bool gemm_form = [] { const char* e = getenv("WIPA_LOGMEL"); return e && strcmp(e, "gemm") == 0; }();
+    return !gemm_form && n_mels <= 128 && n_mels % 4 == 0;
+}
+
 }  // namespace
 
 extern "C" size_t wipa_logmel_tables_bytes(int n_mels) { return table_layout(n_mels).total; }
@@ -174,6 +352,46 @@ extern "C" int wipa_logmel_init(void* tables, int n_mels, wipa_stream_t stream) 
         lo[j] = first < last ? first : 0;
         hi[j] = first < last ? last : 0;
     }
+    // fused kernel: folded DFT chunks [13][cos|sin][kk = k - 1][bin in tile] with the window inside, bins >= 201 zero
+    const int JT = mel_tiles(n_mels);
+    const size_t chunk = CHUNK_F + (size_t)JT * 256;
+    float* ch = reinterpret_cast<float*>(host.data() + L.chunks);
+    for (int p = 0; p < FT_TILES; ++p)
+        for (int kk = 0; kk < FK; ++kk)
+            for (int fl = 0; fl < 16; ++fl) {
+                const int f = 16 * p + fl, k = kk + 1;
+                double c = 0.0, sn = 0.0;
+                if (f < N_BINS) {
+                    const double win = 0.5 - 0.5 * std::cos(two_pi * k / WIPA_N_FFT);
+                    const int ph = (int)(((int64_t)f * k) % WIPA_N_FFT);
+                    const double ang = two_pi * ph / WIPA_N_FFT;
+                    c = win * std::cos(ang);
+                    sn = k < 200 ? -win * std::sin(ang) : 0.0;
+                }
+                ch[(size_t)p * chunk + (size_t)kk * 16 + fl] = (float)c;
+                ch[(size_t)p * chunk + (size_t)FK * 16 + (size_t)kk * 16 + fl] = (float)sn;
+            }
+    // mel weights as A fragments: [p][jt][r][lane (g, l15)] = W[16 jt + l15][16 p + 4 g + r]; mel tiles a frequency tile meets
+    int* jr = reinterpret_cast<int*>(host.data() + L.jrange);
+    for (int p = 0; p < FT_TILES; ++p) {
+        int first = JT, last = 0;
+        for (int jt = 0; jt < JT; ++jt) {
+            bool any = false;
+            for (int r = 0; r < 4; ++r)
+                for (int ln = 0; ln < 64; ++ln) {
+                    const int j = 16 * jt + (ln & 15), f = 16 * p + 4 * (ln >> 4) + r;
+                    const float wgt = (j < n_mels && f < N_BINS) ? melw[(size_t)j * N_BINS + f] : 0.f;
+                    ch[(size_t)p * chunk + CHUNK_F + ((size_t)jt * 4 + r) * 64 + ln] = wgt;
+                    any = any || wgt != 0.f;
+                }
+            if (any) {
+                if (jt < first) first = jt;
+                last = jt + 1;
+            }
+        }
+        jr[2 * p] = first < last ? first : 0;
+        jr[2 * p + 1] = first < last ? last : 0;
+    }
     WIPA_CHECK_HIP(hipMemcpyAsync(tables, host.data(), L.total, hipMemcpyHostToDevice, (hipStream_t)stream));
     WIPA_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));  // host staging buffer dies here (init-time only)
     return WIPA_OK;
@@ -196,6 +414,23 @@ extern "C" int wipa_logmel(const float* audio, int batch, int n_mels, const void
     unsigned* gmax = (unsigned*)(ws + W.gmax);
     const char* tb = (const char*)tables;
 
+    const int per_clip = WIPA_N_FRAMES * n_mels;
+    const int per_out = (WIPA_N_FRAMES + 2) * n_mels;
+    if (use_fused(n_mels)) {
+        WIPA_CHECK_HIP(hipMemsetAsync(gmax, 0, batch * sizeof(unsigned), s));
+        int rc;
+        switch (mel_tiles(n_mels)) {
+            case 1: rc = launch_fused<1>(audio, batch, n_mels, tb, L, logmel, gmax, s); break;
+            case 2: rc = launch_fused<2>(audio, batch, n_mels, tb, L, logmel, gmax, s); break;
+            case 3: rc = launch_fused<3>(audio, batch, n_mels, tb, L, logmel, gmax, s); break;
+            case 4: rc = launch_fused<4>(audio, batch, n_mels, tb, L, logmel, gmax, s); break;
+            case 5: rc = launch_fused<5>(audio, batch, n_mels, tb, L, logmel, gmax, s); break;
+            case 6: rc = launch_fused<6>(audio, batch, n_mels, tb, L, logmel, gmax, s); break;
+            case 7: rc = launch_fused<7>(audio, batch, n_mels, tb, L, logmel, gmax, s); break;
+            default: rc = launch_fused<8>(audio, batch, n_mels, tb, L, logmel, gmax, s); break;
+        }
+        if (rc != WIPA_OK) return rc;
+    } else {
     const int64_t total = (int64_t)batch * PAD_CLIP + PAD_SLACK;
     hipLaunchKernelGGL(reflect_pad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, audio, padded,
                        (int64_t)batch * PAD_CLIP);
@@ -217,10 +452,9 @@ extern "C" int wipa_logmel(const float* audio, int batch, int n_mels, const void
     int rc = wipa_gemm(&g, stream);
     if (rc != WIPA_OK) return rc;
 
-    const int per_clip = WIPA_N_FRAMES * n_mels;
     hipLaunchKernelGGL(mel_log_kernel, dim3((per_clip + 255) / 256, batch), dim3(256), 0, s, spec,
                        (const float*)(tb + L.melw), (const int*)(tb + L.lo), (const int*)(tb + L.hi), n_mels, logmel, gmax);
-    const int per_out = (WIPA_N_FRAMES + 2) * n_mels;
+    }
     if (mel_dtype == WIPA_F32)
         hipLaunchKernelGGL((mel_norm_kernel<float>), dim3((per_out + 255) / 256, batch), dim3(256), 0, s, logmel, gmax,
                            n_mels, (float*)mel);
