@@ -396,8 +396,10 @@ def roofline_cross_absorbed(model, B: int, st, iters: int = 48):
     sizeof(bf16) (every element of xa once) + the absorbed queries and the split partials.  SURVEY.md section 8(d) counted
     55.3 MB per clip and step for the cached K and V of the 12 layers; with the projections absorbed the bytes a step MUST read
     are half of that, which is the point -- the line also gives the rate in cached-K/V terms (`kv_equivalent`).  Timed with
-    events around graph-replayed launches that rotate over several xa buffers (several passes in flight share the Infinity
-    Cache; one buffer alone, 147 MB, would stay resident in it)."""
+    events around graph-replayed launches in the decode loop's own order: the 12 layers of a step read the same encoder
+    output, then the step of another in-flight pass reads its own (4 outputs in turn: 590 MB against 256 MB of Infinity Cache,
+    so the first launch of every group is cold and the others largely cache-fed -- rotating a different output into every
+    launch gives 34.6 us instead of 30.6, one output alone 30.3; the kernel trace of the real run averages 30.3)."""
     import ctypes as C
 
     from whisper_ipa_amd import _lib
@@ -407,7 +409,9 @@ def roofline_cross_absorbed(model, B: int, st, iters: int = 48):
     d = model.dims
     H, Ta, dd = d.n_text_head, d.n_audio_ctx, d.n_text_state
     pk = model.packed()
-    n_buf = max(2, min(5, int(600e6 // (B * Ta * dd * 2)) + 1))
+    # launch order of the real decode loop: the n_layer launches of a step read the SAME encoder output (the first finds it cold,
+    # the others largely in the 256 MB Infinity Cache), then another in-flight pass's step runs on its own encoder output
+    n_buf, per_buf = N_PIPELINE, d.n_text_layer
     with on_stream() as s:
         xas = [torch.randn(B, Ta, dd, device=model.device).to(torch.bfloat16) for _ in range(n_buf)]
         q = (torch.randn(B, dd, device=model.device) * 0.3).to(torch.bfloat16)
@@ -419,11 +423,11 @@ def roofline_cross_absorbed(model, B: int, st, iters: int = 48):
         wkT, wkv, bkv = pk["dec"][base], lw[10], lw[11]
 
         def full(i):
-            _lib.check(L.wipa_cross_absorbed_attention(ptr(q), dd, ptr(wkT), ptr(xas[i % n_buf]), ptr(wkv[dd:]), ptr(bkv[dd:]), ptr(out), dd,
+            _lib.check(L.wipa_cross_absorbed_attention(ptr(q), dd, ptr(wkT), ptr(xas[(i // per_buf) % n_buf]), ptr(wkv[dd:]), ptr(bkv[dd:]), ptr(out), dd,
                                                        ptr(scratch), nbytes, B, H, dd, Ta, 64 ** -0.25, sptr(s)), "wipa_cross_absorbed_attention")
 
         def stream_only(i):
-            _lib.check(L.wipa_cross_absorbed_stream(ptr(xas[i % n_buf]), ptr(scratch), nbytes, B, H, dd, Ta, sptr(s)), "wipa_cross_absorbed_stream")
+            _lib.check(L.wipa_cross_absorbed_stream(ptr(xas[(i // per_buf) % n_buf]), ptr(scratch), nbytes, B, H, dd, Ta, sptr(s)), "wipa_cross_absorbed_stream")
 
         times = {}
         for name, fn in (("stream", stream_only), ("layer_call", full)):
@@ -443,7 +447,7 @@ def roofline_cross_absorbed(model, B: int, st, iters: int = 48):
             times[name] = ev0.elapsed_time(ev1) / iters
     S = L.wipa_cross_absorbed_splits(B, Ta)
     xa_bytes = B * Ta * dd * 2
-    bytes_alg = xa_bytes + B * 16 * dd * 2 + B * S * 16 * (2 + dd) * 4  # xa once + absorbed queries in + split partials out
+    bytes_alg = xa_bytes + B * 16 * dd * 2 + B * S * (H * dd + 32) * 4  # xa once + absorbed queries in + split partials (H head rows, m, l) out
     ms = times["stream"]
     achieved = bytes_alg / (ms * 1e-3) / 1e9
     traffic = None
@@ -454,10 +458,12 @@ def roofline_cross_absorbed(model, B: int, st, iters: int = 48):
     except Exception:
         pass
     kv_bytes = B * 2 * H * Ta * 64 * 2
-    return {"kernel": "cross_absorbed_kernel (decode-step cross-attention of one layer: one pass over the encoder output, key / value "
+    return {"kernel": "cross_absorbed_v2_kernel (decode-step cross-attention of one layer: one pass over the encoder output, key / value "
                       "projections absorbed into the query and the output)", "bound": "hbm", "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "algorithmic_bytes_per_launch": bytes_alg, "avg_launch_ms": round(ms, 5), "xa_buffers_rotated": n_buf, "frame_splits": S,
+            "algorithmic_bytes_per_launch": bytes_alg, "avg_launch_ms": round(ms, 5),
+            "launch_order": f"{per_buf} consecutive launches (the layers of one decode step) per encoder output, {n_buf} encoder outputs (passes in flight) in turn",
+            "frame_splits": S,
             "layer_call": {"what": "absorb-q + streaming + merge / value projection (3 launches: what replaces the cached-K/V cross "
                                    "block's streaming loop)", "avg_ms": round(times["layer_call"], 5)},
             "kv_equivalent": {"what": "the cached K / V bytes this launch stands for (SURVEY.md 8d: 55.3 MB per clip and step over 12 "

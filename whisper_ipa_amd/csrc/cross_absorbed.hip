@@ -346,19 +346,44 @@ __global__ __launch_bounds__(192, 1) void cross_absorbed_v2_kernel(AbsParams p) 
     }
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, 0x7fffffff, 0x00020000);
     // LDS-DMA: transfer i covers image bytes [1024 i, +1024) of a slot; a lane's 16 bytes sit at image (row, chunk') and come
-    // from source chunk chunk' ^ swz(row).  The (row, chunk') of (i, lane) is recomputed per transfer from a laundered lane id:
-    // 24 precomputed offsets per lane would cost 24 registers this kernel does not have.
+    // from source chunk chunk' ^ swz(row).  1024-byte transfers against ROWB-byte rows repeat every PER transfers = QR rows
+    // (3 : 2 for d = 768): transfer PER j + t puts the lane on row QR j + r_t, chunk c_t, so its source offset is
+    //   (f0 + QR j) ROWB  [scalar]  +  r_t ROWB + ((c_t ^ 2 r_t) << 4 ^ S_j << 4)   with S_j = ((QR j) & 7) << 1 a constant:
+    // one v_xad per transfer from two registers per t.  (Recomputing row and chunk per transfer -- 17 instructions, two of
+    // them quarter rate -- was ~1 us of issue time per 24 KiB group and wave, a quarter of the kernel.)  A group that hangs
+    // over the end of the clip (the last one) clamps its rows the slow way.
+    constexpr int G1K = (ROWB % 1024 == 0) ? 1024 : ((ROWB % 512 == 0) ? 512 : 256);  // gcd(1024, ROWB)
+    constexpr int PER = ROWB / G1K, QR = 1024 / G1K;
+    static_assert(NDMA % PER == 0 && PER <= 3 && (QR == 1 || QR == 2 || QR == 4), "transfer / row period");
+    int dma_a[PER], dma_b[PER];
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int off = 1024 * t + 16 * lane;
+        const int r = off / ROWB, c = (off - r * ROWB) >> 4;
+        dma_a[t] = (c ^ (r << 1)) << 4;
+        dma_b[t] = r * ROWB;
+    }
     int lane_v = lane;
     auto stage = [&](int i_local, int slot) {
         const int f0 = (g0 + wave + NWV * i_local) * GF;
-        asm volatile("" : "+v"(lane_v));
+        if (f0 + GF <= p.Tk) {
 #pragma unroll
-        for (int i = 0; i < NDMA; ++i) {
-            const int off = 1024 * i + 16 * lane_v;
-            const int row = off / ROWB;
-            const int ch = ((off - row * ROWB) >> 4) ^ swz(row);
-            const int voff = min(f0 + row, p.Tk - 1) * ROWB + ch * 16;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_ptr_a)(my + slot * SLOT + 1024 * i), 16, voff, 0, 0, 0);
+            for (int i = 0; i < NDMA; ++i) {
+                const int j = i / PER, t = i % PER;
+                const int sj = (((QR * j) & 7) << 1) << 4;
+                const int voff = (dma_a[t] ^ sj) + dma_b[t];
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_ptr_a)(my + slot * SLOT + 1024 * i), 16, voff, (f0 + QR * j) * ROWB, 0, 0);
+            }
+        } else {
+            asm volatile("" : "+v"(lane_v));
+#pragma unroll
+            for (int i = 0; i < NDMA; ++i) {
+                const int off = 1024 * i + 16 * lane_v;
+                const int row = off / ROWB;
+                const int ch = ((off - row * ROWB) >> 4) ^ swz(row);
+                const int voff = min(f0 + row, p.Tk - 1) * ROWB + ch * 16;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_ptr_a)(my + slot * SLOT + 1024 * i), 16, voff, 0, 0, 0);
+            }
         }
     };
     const unsigned lds_my = (unsigned)(uintptr_t)(lds_ptr_a)my;
