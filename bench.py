@@ -375,12 +375,15 @@ def roofline_cross_attn(model, B: int, iters: int = 48):
     # quoted when it was collected for exactly this launch shape.
     traffic = None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_cross_block.json" if fused else "r01_pmc_cross_attn.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_cross_block.json" if fused else "r01_pmc_cross_attn.json")))
         if pm.get("algorithmic_bytes_per_launch") == bytes_alg:
             traffic = pm["hbm_bytes_per_launch"]
     except Exception:
         pass
-    name = ("decode_cross_block_kernel (decode-step cross-attention incl. slab sum + LayerNorm + cross query)" if fused
+    staged = (H * B <= 768 and d.n_text_state <= 768 and model.dtype == torch.bfloat16
+              and os.environ.get("WIPA_CROSS_PRE", "4") in ("4", "6"))  # wipa_decode_cross_block's dispatch rule (decode_fused.hip)
+    name = (("decode_cross_block_pre_kernel" if staged else "decode_cross_block_kernel") +
+            " (decode-step cross-attention incl. slab sum + LayerNorm + cross query" + (", first K / V rows staged by LDS-DMA under the prologue)" if staged else ")") if fused
             else "decode_attn_kernel (decode-step cross-attention)")
     out = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1),
            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -391,7 +394,7 @@ def roofline_cross_attn(model, B: int, iters: int = 48):
 
 
 def roofline_cross_absorbed(model, B: int, st, iters: int = 48):
-    """Dominant HBM-bound kernel of the default decode step since round 3: cross_absorbed_kernel, the ONE pass over the encoder
+    """Dominant HBM-bound kernel of the decode step with --cross-attention absorbed: cross_absorbed_v2_kernel, the ONE pass over the encoder
     output xa that serves scores and values of a layer (csrc/cross_absorbed.hip).  Algorithmic bytes per launch = B * 1500 * d *
     sizeof(bf16) (every element of xa once) + the absorbed queries and the split partials.  SURVEY.md section 8(d) counted
     55.3 MB per clip and step for the cached K and V of the 12 layers; with the projections absorbed the bytes a step MUST read
@@ -471,7 +474,7 @@ def roofline_cross_absorbed(model, B: int, st, iters: int = 48):
                               "GB/s": round(kv_bytes / (ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(kv_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
 
 
-def roofline_mfma(model, audio, pmc_file: str = "r02_pmc_encoder_gemm.json"):
+def roofline_mfma(model, audio, pmc_file: str = "r03_pmc_encoder_gemm.json"):
     """The MFMA-bound kernel set: every GEMM / conv-as-GEMM of one encoder pass plus the cross-K/V projection.
     Algorithmic FLOPs per clip are SURVEY.md App. B's (whisper-small: 261.2 + 42.5 GFLOP); the time is the sum of HIP-event
     spans around each GEMM launch of a real pass on the library stream (wipa_profile_begin / wipa_profile_end)."""
@@ -569,10 +572,17 @@ def decode_step_roofline(model, B: int, n_steps: int = 48):
         weights = d.n_vocab * dd + Ld * 14 * dd * dd + (d.n_text_ctx * dd + Ld * 11 * dd + 2 * dd) * 4
     total = cross + self_kv + weights
     achieved = total / (ms * 1e-3) / 1e9
-    return {"what": "one decode step, hipGraph replay, one pass in flight", "bound": "hbm", "ms_per_step": round(ms, 4),
-            "bytes_per_step": int(total), "cross_kv_bytes": int(cross), "self_kv_bytes": int(self_kv), "weight_bytes": int(weights),
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "cross_attention": "absorbed projections: the encoder output streamed once per layer" if model.cross_absorbed else "cached K / V"}
+    out = {"what": "one decode step, hipGraph replay, one pass in flight", "bound": "hbm", "ms_per_step": round(ms, 4),
+           "bytes_per_step": int(total), "cross_kv_bytes": int(cross), "self_kv_bytes": int(self_kv), "weight_bytes": int(weights),
+           "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+           "cross_attention": "absorbed projections: the encoder output streamed once per layer" if model.cross_absorbed else "cached K / V"}
+    if model.cross_absorbed:
+        # the figure of the earlier rounds (SURVEY.md 8d bytes: cached K AND V of every layer) over the same time, so the rounds compare
+        kv_total = total + cross
+        out["cached_kv_accounting"] = {"bytes_per_step": int(kv_total), "achieved": round(kv_total / (ms * 1e-3) / 1e9, 1),
+                                       "frac": round(kv_total / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                       "note": "the step now reads half of these bytes; frac above counts what it actually reads"}
+    return out
 
 
 def cpu_baseline(n_clips: int = 1):
@@ -948,6 +958,9 @@ def main():
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: BASELINE.json configs[4] sizing runs (e4m3 weights with per-row scales, bf16 activations); the "
                          "benchmark metric is quoted on bf16 weights")
+    ap.add_argument("--cross-attention", default="auto", choices=["auto", "cached", "absorbed"],
+                    help="decode-step cross-attention: projected K / V caches (the default) or the encoder output with absorbed "
+                         "projections (Whisper(cross_attention=...); absorbed: bf16, <= 16 heads)")
     ap.add_argument("--activations", default="bf16", choices=["bf16", "fp8"],
                     help="with --weights fp8: fp8 also runs the encoder's q|k, value, mlp1, mlp2 projections fp8 x fp8 on the "
                          "block-scaled fp8 MFMA (LayerNorm / GELU outputs quantised per row) -- configs[4] '(CDNA4 fp8 MFMA)'")
@@ -977,7 +990,8 @@ def main():
     log(f"start: rank {rank}/{world}, host cores {host_cores()}")
     dims, W = synthetic_weights_small(0, args.model)
     log("weights generated")
-    model = Whisper(dims, dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32, f32_split=(args.f32 == "split"))
+    model = Whisper(dims, dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32, f32_split=(args.f32 == "split"),
+                    cross_attention=args.cross_attention)
     model.load_weights(W)
     del W
     if args.activations == "fp8" and args.weights != "fp8":

@@ -16,10 +16,10 @@ MICRO = R.ModelDimensions(80, 1500, 128, 2, 2, 51865, 448, 128, 2, 2)
 SMALL2 = R.ModelDimensions(80, 1500, 768, 12, 2, 51865, 448, 768, 12, 2)  # whisper-small width, 2+2 layers
 
 
-def _model(dims_o, W, dtype, f32_split=False):
+def _model(dims_o, W, dtype, f32_split=False, cross_attention="auto"):
     from whisper_ipa_amd.whisper import ModelDimensions, Whisper
 
-    m = Whisper(ModelDimensions(**dims_o.__dict__), dtype=dtype, f32_split=f32_split)
+    m = Whisper(ModelDimensions(**dims_o.__dict__), dtype=dtype, f32_split=f32_split, cross_attention=cross_attention)
     m.load_weights(W)
     return m
 
@@ -388,7 +388,8 @@ def test_other_model_widths_f32(name, dims):
     assert (res.tokens == ref.tokens).all(), (name, res.tokens.tolist(), ref.tokens.tolist(), ref.margins.min())
 
 
-def test_full_size_bench_workload_properties():
+@pytest.mark.parametrize("cross_attention", ["cached", "absorbed"])
+def test_full_size_bench_workload_properties(cross_attention):
     """BASELINE configs[1] at FULL size (whisper-small 12+12 layers, bf16, 64 clips x 30 s): properties that do
     not need the (too slow) CPU oracle at this size --
       * batch invariance: a clip's features and token ids do not depend on which batch it rides in
@@ -401,7 +402,7 @@ def test_full_size_bench_workload_properties():
     from whisper_ipa_amd.whisper import Whisper
 
     dims, W = bench.synthetic_weights_small(0)
-    m = Whisper(dims, dtype=torch.bfloat16)
+    m = Whisper(dims, dtype=torch.bfloat16, cross_attention=cross_attention)
     m.load_weights(W)
     del W
     init, always, first, eot = bench.decode_setup()
@@ -438,12 +439,13 @@ def test_full_size_bench_workload_properties():
     assert (grouped[:64, : 4 + 16] == t64).all()
 
 
-def test_small_width_bf16_close_and_tokens_match_where_margin_allows(small2):
+@pytest.mark.parametrize("cross_attention", ["cached", "absorbed"])
+def test_small_width_bf16_close_and_tokens_match_where_margin_allows(small2, cross_attention):
     """bf16 path (the bench configuration's arithmetic) against the f32 oracle: features within
     bf16 tolerance; greedy tokens must equal the oracle's except at a step whose oracle
     top-1 margin is within twice the bf16 logit error MEASURED at that (row, step) (tests/parity_util.py)."""
     W, mels, xa = small2
-    m = _model(SMALL2, W, torch.bfloat16)
+    m = _model(SMALL2, W, torch.bfloat16, cross_attention=cross_attention)
     feats = m.encoder(torch.from_numpy(mels).cuda())
     assert feats.dtype == torch.bfloat16
     rel = ((feats.float().cpu() - xa).abs().max() / xa.abs().max()).item()
@@ -453,8 +455,8 @@ def test_small_width_bf16_close_and_tokens_match_where_margin_allows(small2):
     init = list(sp.sot_sequence_including_notimestamps(0))
     with torch.no_grad():
         ref = R.greedy_decode(W, SMALL2, xa, init, always, first, sp.eot, sample_len=16, stop_on_eot=False, keep_logits=True)
-    err, rep = check_low_precision_decode(m, feats, ref, init, always, first, sp.eot, "small width bf16")
-    print(f"\nsmall width bf16: max logit error {rep['max_logit_err']:.4f} = {rep['rel_err']:.4f} of the logit std, token match {rep['token_match']:.3f}")
+    err, rep = check_low_precision_decode(m, feats, ref, init, always, first, sp.eot, f"small width bf16 ({cross_attention})")
+    print(f"\nsmall width bf16 ({cross_attention} cross-attention): max logit error {rep['max_logit_err']:.4f} = {rep['rel_err']:.4f} of the logit std, token match {rep['token_match']:.3f}")
 
 
 @pytest.mark.parametrize("name,dims,n_new", [

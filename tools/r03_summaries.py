@@ -86,36 +86,83 @@ if have("pmc_x1"):
     json.dump(out, open(os.path.join(DST, "r03_pmc_cross_absorbed.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
+# ---- the dominant kernel of the default step: fused cross block on the cached K / V
+if have("pmc_c1"):
+    x, n_launch = {}, []
+    for d in ("pmc_c1", "pmc_c2"):
+        for k, c in counters(d).items():
+            if "decode_cross_block" in k[0]:
+                for cn, (v, n) in c.items():
+                    x[cn] = v
+                    n_launch.append(n)
+    log = open(os.path.join(SRC, "pmc_c_timing.log")).read()
+    alg = int(re.search(r"algorithmic bytes per launch.*?:\s*(\d+)", log).group(1))
+    ev = float(re.search(r"wipa_decode_cross_block: ([0-9.]+) us", log).group(1))
+    d1, d2 = trace_us("pmc_c1", "decode_cross_block"), trace_us("pmc_c2", "decode_cross_block")
+    out = {"kernel": "decode_cross_block_pre_kernel<bf16, 4> (slab sum + residual + cross_attn_ln + cross query + streaming cross-attention; the first "
+                     "32 key and 32 value rows of every wave staged into LDS by LDS-DMA under the prologue), non-temporal K/V loads",
+           "shape": "whisper-small, B=64, H=12, Tk=1500, bf16, 2 slabs: 24 launches cycling 12 layer caches and 12 query matrices",
+           "command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 tools/pmc_cross_block.py ; same with --pmc WRITE_SIZE (separate passes)",
+           "FETCH_SIZE_KB_per_launch": round(x.get("FETCH_SIZE", 0), 2), "WRITE_SIZE_KB_per_launch": round(x.get("WRITE_SIZE", 0), 2),
+           "launches_counted": n_launch,
+           "correction": "gfx950: FETCH_SIZE counts a wide coalesced 16 B/lane stream at exactly 1/2 of its bytes (MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE is exact",
+           "hbm_bytes_per_launch": int(x.get("FETCH_SIZE", 0) * 1024 * 2 + x.get("WRITE_SIZE", 0) * 1024),
+           "algorithmic_bytes_per_launch": alg,
+           "note": "the doubling correction over-counts the part of the fetches that is not a wide coalesced stream (the 98 KB of query weights each of the 768 workgroups reads from L2 reach the fabric counter only on an L2 miss)",
+           "avg_us_under_counters": [round(sum(d1) / max(len(d1), 1), 2), round(sum(d2) / max(len(d2), 1), 2)],
+           "avg_us_event_timed_no_counters": ev}
+    out["ratio_traffic_over_algorithmic"] = round(out["hbm_bytes_per_launch"] / alg, 4)
+    json.dump(out, open(os.path.join(DST, "r03_pmc_cross_block.json"), "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
 # ---- encoder GEMM counters + per-shape times
 if have("pmc_g1"):
-    g1, g2, g3 = counters("pmc_g1"), counters("pmc_g2"), counters("pmc_g3") if have("pmc_g3") else {}
+    def by_launch(d):
+        """counters of the gemm_nt launches in dispatch order: [{counter: value}] (three launches per shape, five shapes)"""
+        rows = collections.defaultdict(dict)
+        names_ = {}
+        for f in glob.glob(os.path.join(SRC, d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if "gemm_nt" in r["Kernel_Name"]:
+                    rows[int(r["Dispatch_Id"])][r["Counter_Name"]] = rows[int(r["Dispatch_Id"])].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+                    names_[int(r["Dispatch_Id"])] = (r["Kernel_Name"], r["Grid_Size"])
+        order = sorted(rows)
+        return [rows[i] for i in order], [names_[i] for i in order]
+
+    sets = [by_launch(d) for d in ("pmc_g1", "pmc_g2", "pmc_g3") if have(d)]
     names = [("qk", "N=1536 K=768  bias+scale", 1536, 768), ("mlp1", "N=3072 K=768  bias+GELU", 3072, 768),
              ("out", "N=768  K=768  bias+f32 residual", 768, 768), ("mlp2", "N=768  K=3072 bias+f32 residual", 768, 3072),
              ("mlp2*", "N=768  K=3072 bf16 out, no residual", 768, 3072)]
-    # durations per launch in launch order (3 launches per shape)
+    # durations per launch in launch order (3 launches per shape), from the run without counters
     dur = []
     for f in glob.glob(os.path.join(SRC, "kt_g", "**", "*kernel_trace.csv"), recursive=True):
         rows = sorted((r for r in csv.DictReader(open(f)) if "gemm_nt" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
         dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
     gemm = {}
     with open(os.path.join(DST, "r03_pmc_encoder_gemm.txt"), "w") as f:
-        f.write("# rocprofv3 --pmc on tools/pmc_gemm.py (M = 96000 rows, the encoder GEMM shapes of whisper-small at B = 64), MI355X, round 3.\n"
+        f.write("# rocprofv3 --pmc on tools/pmc_gemm.py (M = 96000 rows, the encoder GEMM shapes of whisper-small at B = 64; three launches per\n"
+                "# shape, counters averaged over the 2nd and 3rd), MI355X, round 3.\n"
                 "# passes: {SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES},\n"
-                "# {GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16}, {LDS set, when available}; durations from a separate --kernel-trace run (no counters).\n"
-                "# MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs).\n")
-        keys = [k for k in g1 if "gemm_nt" in k[0]]
-        for i, k in enumerate(keys):
-            c = {cn: v for cn, (v, n) in g1[k].items()}
-            c.update({cn: v for cn, (v, n) in g2.get(k, {}).items()})
-            c.update({cn: v for cn, (v, n) in g3.get(k, {}).items()})
+                "# {GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16}, {SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD}; durations from a\n"
+                "# separate --kernel-trace run (no counters).  MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs).\n")
+        for i, (tag, label, N, K) in enumerate(names):
+            c = {}
+            kname = None
+            for launches, knames in sets:
+                if len(launches) < 3 * i + 3:
+                    continue
+                kname = knames[3 * i + 1]
+                for cn in launches[3 * i + 1]:
+                    c[cn] = (launches[3 * i + 1][cn] + launches[3 * i + 2].get(cn, launches[3 * i + 1][cn])) / 2
+            if not c:
+                continue
             util = c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (c["GRBM_GUI_ACTIVE"] / 8) if "GRBM_GUI_ACTIVE" in c else float("nan")
             parked = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
-            tag, label, N, K = names[i] if i < len(names) else (str(i), "", 0, 0)
             us = dur[3 * i + 1: 3 * i + 3] if len(dur) >= 3 * i + 3 else []
             avg = sum(us) / len(us) if us else float("nan")
             tf = 2 * 96000 * N * K / avg / 1e6 if us else float("nan")
             gemm[tag] = {"mfma_busy": round(util, 3), "waves_parked": round(parked, 3), "us": round(avg, 1), "TF/s": round(tf, 1)}
-            f.write(f"{short(k[0])} grid {k[1]}   [{tag} {label}]   {avg:.1f} us = {tf:.0f} TF/s\n")
+            f.write(f"{short(kname[0])} grid {kname[1]}   [{tag} {label}]   {avg:.1f} us = {tf:.0f} TF/s\n")
             for cn, v in sorted(c.items()):
                 f.write(f"   {cn:34s} {v:.4g}\n")
             f.write(f"   -> MFMA utilisation {util:.3f}, waves parked {parked:.3f}\n")
@@ -131,8 +178,11 @@ if have("kt_lm"):
             lm[short(r["Name"])] = {"calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 2)}
     fetch = sum(v for k, c in counters("pmc_lm1").items() for cn, (v, n) in c.items() if cn == "FETCH_SIZE" and ("logmel" in k[0] or "mel_norm" in k[0]))
     write = sum(v for k, c in counters("pmc_lm2").items() for cn, (v, n) in c.items() if cn == "WRITE_SIZE" and ("logmel" in k[0] or "mel_norm" in k[0]))
-    per_kernel = {short(k[0]): {cn: round(v, 1) for cn, (v, n) in c.items()} for d in ("pmc_lm1", "pmc_lm2") for k, c in counters(d).items()
-                  if "logmel" in k[0] or "mel_norm" in k[0]}
+    per_kernel = collections.defaultdict(dict)
+    for d in ("pmc_lm1", "pmc_lm2"):
+        for k, c in counters(d).items():
+            if "logmel" in k[0] or "mel_norm" in k[0]:
+                per_kernel[short(k[0])].update({cn: round(v, 1) for cn, (v, n) in c.items()})
     out = {"what": "log-mel front-end for 64 clips x 30 s, 80 mels, bf16 output in the conv1 halo layout (tools/logmel_bench.py 64 80)",
            "kernels": lm, "event_timed": open(os.path.join(SRC, "logmel_80.log")).read().strip().splitlines()[-1],
            "event_timed_128_mels": open(os.path.join(SRC, "logmel_128.log")).read().strip().splitlines()[-1],
@@ -144,7 +194,7 @@ if have("kt_lm"):
     json.dump(out, open(os.path.join(DST, "r03_logmel.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
-for n in ("bench_default.json", "bench_cached_kv.json", "train_exact.json", "train_split.json", "size_small_n224.json", "size_medium_b256.json",
+for n in ("bench_default.json", "bench_absorbed.json", "bench_absorbed_n224.json", "size_medium_b256_absorbed.json", "train_exact.json", "train_split.json", "size_small_n224.json", "size_medium_b256.json",
           "size_large_b128_bf16.json", "size_large_b128_fp8.json", "size_large_b128_fp8_act.json", "size_small_fp8.json", "size_small_p1.json"):
     if have(n) and os.path.getsize(os.path.join(SRC, n)) > 0:
         shutil.copy(os.path.join(SRC, n), os.path.join(DST, "r03_" + n))
