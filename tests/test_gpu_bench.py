@@ -41,7 +41,7 @@ def test_bench_single_rank_contract_and_rooflines():
     # convs + 5 GEMMs x 4 encoder layers; the 4 cross-K/V projections only run with a K/V cache (absorbed projections: none)
     assert out["config"]["cross_attention"] == "cached"  # the default: mlx_whisper's projected K / V caches
     assert out["roofline_mfma"]["gemm_launches"] == 2 + 5 * 4 + 4
-    assert "decode_cross_block_kernel" in out["roofline"]["kernel"]
+    assert "decode_cross_block" in out["roofline"]["kernel"]
     assert out["decode_step"]["bytes_per_step"] > out["decode_step"]["cross_kv_bytes"] > 0
     # the absorbed-projection cross-attention (opt-in): no cross-K/V GEMMs, the streaming kernel is the roofline kernel, half the
     # cross bytes per step, and the same greedy ids on this tiny model's 8 clips
