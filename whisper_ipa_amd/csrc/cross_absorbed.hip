@@ -294,9 +294,9 @@ __global__ __launch_bounds__(512, 1) void cross_absorbed_kernel(AbsParams p) {
 // per workgroup (6 x 24 KiB = 144 KiB of LDS); their (m, l, O') are merged through LDS once, at the end.
 typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
 
-template <int D>
+template <int D, int NW_>
 struct AbsCfg2 {
-    static constexpr int NWV = 3;
+    static constexpr int NWV = NW_;                 // independent waves per workgroup (3: 144 KiB of LDS; 2: 96 KiB, room for co-residents)
     static constexpr int GF = 16;                   // frames per group
     static constexpr int ROWB = D * 2;
     static constexpr int SLOT = GF * ROWB;          // 24 KiB for d = 768
@@ -317,9 +317,9 @@ struct AbsCfg2 {
                  : "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(A[4]), "v"(A[5]), "v"(A[6]), "v"(A[7])                           \
                  : "memory")
 
-template <int D>
-__global__ __launch_bounds__(192, 1) void cross_absorbed_v2_kernel(AbsParams p) {
-    typedef AbsCfg2<D> X;
+template <int D, int NW_>
+__global__ __launch_bounds__(64 * NW_, 1) void cross_absorbed_v2_kernel(AbsParams p) {
+    typedef AbsCfg2<D, NW_> X;
     constexpr int NWV = X::NWV, GF = X::GF, ROWB = X::ROWB, SLOT = X::SLOT;
     constexpr int NDMA = SLOT / 1024;  // LDS-DMA transfers per group (24 for d = 768)
     constexpr int KS = D / 32;         // k-steps of the score product
@@ -534,7 +534,6 @@ __global__ __launch_bounds__(192, 1) void cross_absorbed_v2_kernel(AbsParams p) 
     __syncthreads();
     const int64_t ps = (int64_t)b * p.n_splits + split;
     float* po = p.part_o + ps * 16 * D;
-    static_assert(NWV * 64 >= D / 4, "one float4 column per thread");
     for (int hd = 0; hd < p.H; ++hd) {  // rows of the padded heads are never read by the merge
         float mv[NWV], M = NEG_BIG;
 #pragma unroll
@@ -542,12 +541,12 @@ __global__ __launch_bounds__(192, 1) void cross_absorbed_v2_kernel(AbsParams p) 
             mv[v] = sm[v * 16 + hd];
             M = fmaxf(M, mv[v]);
         }
-        if (4 * tid < D) {
+        for (int c4 = tid; 4 * c4 < D; c4 += NWV * 64) {
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int v = 0; v < NWV; ++v)  // fixed order
-                o += __expf(mv[v] - M) * *reinterpret_cast<const f32x4*>(so + (v * 16 + hd) * RS + 4 * tid);
-            *reinterpret_cast<f32x4*>(po + hd * D + 4 * tid) = o;
+                o += __expf(mv[v] - M) * *reinterpret_cast<const f32x4*>(so + (v * 16 + hd) * RS + 4 * c4);
+            *reinterpret_cast<f32x4*>(po + hd * D + 4 * c4) = o;
         }
     }
     if (tid < 16) {
@@ -722,8 +721,11 @@ int launch_attn(const AbsParams& p_in, int B, hipStream_t s) {
     const AbsParams& p = p_in;
     if ((e && atoi(e) == 1) || D > 768)  // d = 1024: 64 column tiles are all 256 accumulation registers -- the channel-split form
         hipLaunchKernelGGL((cross_absorbed_kernel<D>), dim3(p.n_splits, B), dim3(64 * AbsCfg<D>::NW), AbsCfg<D>::SMEM, s, p);
-    else if constexpr (D <= 768)
-        hipLaunchKernelGGL((cross_absorbed_v2_kernel<D>), dim3(p.n_splits, B), dim3(64 * AbsCfg2<D>::NWV), AbsCfg2<D>::SMEM, s, p);
+    else if constexpr (D <= 768) {
+        static const int waves = [] { const char* w = getenv("WIPA_ABS_WAVES"); return w ? atoi(w) : 3; }();  // A/B: 2 leaves 64 KiB of LDS and two SIMDs to other kernels
+        if (waves == 2) hipLaunchKernelGGL((cross_absorbed_v2_kernel<D, 2>), dim3(p.n_splits, B), dim3(128), (AbsCfg2<D, 2>::SMEM), s, p);
+        else hipLaunchKernelGGL((cross_absorbed_v2_kernel<D, 3>), dim3(p.n_splits, B), dim3(192), (AbsCfg2<D, 3>::SMEM), s, p);
+    }
     return WIPA_OK;
 }
 
@@ -756,8 +758,13 @@ extern "C" int wipa_cross_absorbed_init(int d) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_absorbed_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize,      \
                                 AbsCfg<D>::SMEM);                                                                                          \
         if (e == hipSuccess && D <= 768)                                                                                                   \
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_absorbed_v2_kernel<(D <= 768 ? D : 768)>),                        \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, AbsCfg2<(D <= 768 ? D : 768)>::SMEM);                      \
+        {                                                                                                                                  \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_absorbed_v2_kernel<(D <= 768 ? D : 768), 3>),                     \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, AbsCfg2<(D <= 768 ? D : 768), 3>::SMEM);                   \
+            if (e == hipSuccess)                                                                                                           \
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_absorbed_v2_kernel<(D <= 768 ? D : 768), 2>),                 \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, AbsCfg2<(D <= 768 ? D : 768), 2>::SMEM);               \
+        }                                                                                                                                  \
     }
     if (d == 384) ABS_ATTR(384)
     else if (d == 512) ABS_ATTR(512)

@@ -131,8 +131,8 @@ class Whisper:
         projection GEMMs (csrc/cross_absorbed.hip); bf16 models with <= 16 heads and d in {384, 512, 768, 1024}, no fp8 tables.
         "auto" (default): cached, unless WIPA_CROSS_ABSORB=1 asks for absorbed where it applies.  Same mathematics, other bf16
         rounding points.  Measured on MI355X: absorbed wins when a pass is encoder-heavy or the batch is
-        large (whisper-small, 64 clips x 64 new tokens: 80.6 vs 82.7 ms; whisper-medium, 256 clips: 829 vs 872 ms) and loses
-        when the pass is decode-dominated (224 new tokens: 277.5 vs 243.6 ms -- its four extra launches per layer).  The choice is
+        large (whisper-small, 64 clips x 64 new tokens: 80.4 vs 82.5 ms; whisper-medium, 256 clips: 823 vs 867 ms) and loses
+        when the pass is decode-dominated (224 new tokens: 279.8 vs 244.4 ms -- its four extra launches per layer).  The choice is
         explicit here and in the CPU checker, and both settings are pinned by golden fixtures (tests/golden/wide_model.npz)."""
         if cross_attention not in ("auto", "absorbed", "cached"):
             raise _lib.WipaError(f"cross_attention must be 'auto', 'absorbed' or 'cached', got {cross_attention!r}")
