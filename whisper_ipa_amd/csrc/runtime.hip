@@ -698,8 +698,8 @@ int enqueue_prefill(const wipa_model_cfg* cfg, const void* const* w, char* st, c
 // step was the first GEMM of the process, as in a counter micro-target); (ii) while
 // counters are attached the same kernels are enqueued eagerly, which is also what a per-kernel counter run wants; (iii) any
 // other tool that intercepts queues can ask for the eager path with WIPA_DECODE_GRAPH=0.  WIPA_DECODE_GRAPH=force keeps
-// the graphs under counters (for a bounded run that chases the root cause; nothing in the tests or the bench uses it).  Kernel
-// tracing alone keeps the graphs.
+// the graphs under counters: the one bounded confirmation run of round 3 (tools/pmc_graph_confirm.py, profiles/r03_graph_replay_under_counters.txt)
+// captured and replayed a step with counters attached and got the eager ids.  Kernel tracing alone keeps the graphs.
 bool counters_attached() {
     const char* e = getenv("ROCPROF_COUNTER_COLLECTION");
     return e && *e && strcmp(e, "0") != 0 && strcasecmp(e, "false") != 0;
