@@ -174,14 +174,14 @@ if have("pmc_g1"):
 if have("kt_lm"):
     lm = {}
     for r in csv.DictReader(open(glob.glob(os.path.join(SRC, "kt_lm", "**", "*kernel_stats.csv"), recursive=True)[0])):
-        if any(s in r["Name"] for s in ("logmel", "mel_", "reflect", "gemm_nt", "fillBuffer")):
+        if any(s in r["Name"] for s in ("logmel", "mel_", "reflect", "gemm_nt", "fillBuffer")):  # fused kernel, clamp pass, memsets
             lm[short(r["Name"])] = {"calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 2)}
-    fetch = sum(v for k, c in counters("pmc_lm1").items() for cn, (v, n) in c.items() if cn == "FETCH_SIZE" and ("logmel" in k[0] or "mel_norm" in k[0]))
-    write = sum(v for k, c in counters("pmc_lm2").items() for cn, (v, n) in c.items() if cn == "WRITE_SIZE" and ("logmel" in k[0] or "mel_norm" in k[0]))
+    fetch = sum(v for k, c in counters("pmc_lm1").items() for cn, (v, n) in c.items() if cn == "FETCH_SIZE" and ("logmel" in k[0] or "mel_norm" in k[0] or "mel_clamp" in k[0]))
+    write = sum(v for k, c in counters("pmc_lm2").items() for cn, (v, n) in c.items() if cn == "WRITE_SIZE" and ("logmel" in k[0] or "mel_norm" in k[0] or "mel_clamp" in k[0]))
     per_kernel = collections.defaultdict(dict)
     for d in ("pmc_lm1", "pmc_lm2"):
         for k, c in counters(d).items():
-            if "logmel" in k[0] or "mel_norm" in k[0]:
+            if "logmel" in k[0] or "mel_norm" in k[0] or "mel_clamp" in k[0]:
                 per_kernel[short(k[0])].update({cn: round(v, 1) for cn, (v, n) in c.items()})
     out = {"what": "log-mel front-end for 64 clips x 30 s, 80 mels, bf16 output in the conv1 halo layout (tools/logmel_bench.py 64 80)",
            "kernels": lm, "event_timed": open(os.path.join(SRC, "logmel_80.log")).read().strip().splitlines()[-1],

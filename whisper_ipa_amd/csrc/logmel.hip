@@ -14,7 +14,9 @@
 //   * Transposed product S^T[f][t]: its accumulator layout (lane = frame, 4 registers = 4 bins) IS the B-fragment layout of
 //     the next MFMA, so power = re^2 + im^2 feeds the mel projection (again f32 MFMA, mel^T[j][t] += W[j][f] P^T[f][t],
 //     only the mel tiles a frequency tile overlaps) without leaving registers.
-//   * log10 + per-clip max (atomic) in the epilogue; the clamp / scale pass writes the conv1 halo layout [B,3002,n_mels].
+//   * log10, (x + 4) / 4 and the per-clip max (atomic) in the epilogue, written straight into the conv1 halo layout
+//     [B,3002,n_mels] in the output dtype; the clamp at clip_max - 8 commutes with that map and with the rounding, so a small
+//     in-place pass applies it afterwards (bit-identical to clamping first) and no f32 log-mel ever goes through HBM.
 // The previous form (f32 STFT GEMM with overlapping rows -> 320 MB spectrum -> VALU mel kernel: 1.4 ms per 64 clips) stays
 // selectable with WIPA_LOGMEL=gemm for A/B runs and serves n_mels > 128.
 #include <cmath>
@@ -69,7 +71,7 @@ WsLayout ws_layout(int B, int n_mels) {
     w.padded = 0;
     w.spec = w.padded + (fused ? 0 : (((size_t)B * PAD_CLIP + PAD_SLACK) * sizeof(float) + 255) / 256 * 256);
     w.logmel = w.spec + (fused ? 0 : ((size_t)B * ROWS_PER_CLIP * SPEC_LD * sizeof(float) + 255) / 256 * 256);
-    w.gmax = w.logmel + ((size_t)B * WIPA_N_FRAMES * n_mels * sizeof(float) + 255) / 256 * 256;
+    w.gmax = w.logmel + (fused ? 0 : ((size_t)B * WIPA_N_FRAMES * n_mels * sizeof(float) + 255) / 256 * 256);
     w.total = w.gmax + (((size_t)B * sizeof(unsigned)) + 255) / 256 * 256;
     return w;
 }
@@ -161,10 +163,22 @@ __device__ __forceinline__ int span_addr(int s) { return s + (s >> 5); }
 
 typedef __attribute__((address_space(3))) void* lm_lds_ptr;
 
-// audio [B][480000] -> logmel [B][3000][n_mels] (log10 of the mel energies, unclamped) + per-clip maximum
-template <int JT>
+__device__ __forceinline__ void store4(float* p, const f32x4_t& v) { *reinterpret_cast<f32x4_t*>(p) = v; }
+__device__ __forceinline__ void store4(__bf16* p, const f32x4_t& v) {
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    bf16x4_t o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = (__bf16)v[r];
+    *reinterpret_cast<bf16x4_t*>(p) = o;
+}
+
+// audio [B][480000] -> out [B][3002][n_mels] rows 1..3000 = (log10(mel) + 4) / 4, NOT yet clamped, already in the output dtype and
+// the conv1 halo layout, + the per-clip maximum of log10(mel).  The clamp max(x, clip_max - 8) commutes with the monotone map
+// x -> (x + 4) / 4 and with the rounding to the output dtype, so mel_clamp_kernel can apply it in place afterwards and the result
+// is bit-identical to clamping first: no f32 copy of the log-mel goes through HBM.
+template <int JT, typename TO>
 __global__ __launch_bounds__(256, 1) void logmel_fused_kernel(const float* __restrict__ audio, const float* __restrict__ chunks,
-                                                              const int* __restrict__ jrange, int n_mels, float* __restrict__ logmel,
+                                                              const int* __restrict__ jrange, int n_mels, TO* __restrict__ out,
                                                               unsigned* __restrict__ gmax) {
     constexpr int CHUNK = CHUNK_F + JT * 256;   // floats per frequency tile: cos | sin | mel fragments
     constexpr int NDMA = CHUNK * 4 / 1024;      // 1-KiB LDS-DMA transfers per chunk (25 + JT)
@@ -272,15 +286,17 @@ __global__ __launch_bounds__(256, 1) void logmel_fused_kernel(const float* __res
             f32x4_t v;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                v[r] = log10f(fmaxf(macc[jt][tt][r], 1e-10f));
-                if (t < WIPA_N_FRAMES && j + r < n_mels) mx = fmaxf(mx, v[r]);
+                const float x = log10f(fmaxf(macc[jt][tt][r], 1e-10f));
+                if (t < WIPA_N_FRAMES && j + r < n_mels) mx = fmaxf(mx, x);
+                v[r] = (x + 4.0f) / 4.0f;
             }
+            TO* row = out + ((int64_t)b * (WIPA_N_FRAMES + 2) + t + 1) * n_mels;  // frame t is row t + 1 of the halo layout
             if (t < WIPA_N_FRAMES && j + 3 < n_mels)
-                *reinterpret_cast<f32x4_t*>(logmel + ((int64_t)b * WIPA_N_FRAMES + t) * n_mels + j) = v;
+                store4(row + j, v);
             else if (t < WIPA_N_FRAMES) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (j + r < n_mels) logmel[((int64_t)b * WIPA_N_FRAMES + t) * n_mels + j + r] = v[r];
+                    if (j + r < n_mels) row[j + r] = from_f32<TO>(v[r]);
             }
         }
     }
@@ -290,19 +306,52 @@ __global__ __launch_bounds__(256, 1) void logmel_fused_kernel(const float* __res
 
 constexpr size_t fused_lds(int JT) { return ((size_t)((SPAN_LDS + 3) & ~3) + 2 * (size_t)(CHUNK_F + JT * 256)) * sizeof(float); }
 
-template <int JT>
-int launch_fused(const float* audio, int batch, int n_mels, const char* tb, const TableLayout& L, float* logmel, unsigned* gmax,
-                 hipStream_t s) {
+// in place on out [B][3002][n_mels]: halo rows 0 and 3001 zero, every other value raised to the clip's floor ((max - 8) + 4) / 4;
+// only values below the floor (and the halo) are written
+template <typename TO>
+__global__ __launch_bounds__(256) void mel_clamp_kernel(const unsigned* __restrict__ gmax, int n_mels, TO* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int per_out = (WIPA_N_FRAMES + 2) * n_mels;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= per_out) return;
+    const int row = idx / n_mels;
+    TO* p = out + (int64_t)b * per_out + idx;
+    if (row < 1 || row > WIPA_N_FRAMES) {
+        *p = from_f32<TO>(0.f);
+        return;
+    }
+    const float floor_y = ((key_f32(gmax[b]) - 8.0f) + 4.0f) / 4.0f;
+    if ((float)*p < floor_y) *p = from_f32<TO>(floor_y);
+}
+
+template <int JT, typename TO>
+int launch_fused(const float* audio, int batch, int n_mels, const char* tb, const TableLayout& L, TO* out, unsigned* gmax, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        WIPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&logmel_fused_kernel<JT>),
+        WIPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&logmel_fused_kernel<JT, TO>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds(JT)));
         attr_done = true;
     }
-    hipLaunchKernelGGL((logmel_fused_kernel<JT>), dim3((WIPA_N_FRAMES + WG_FRAMES - 1) / WG_FRAMES, batch), dim3(256), fused_lds(JT), s,
-                       audio, (const float*)(tb + L.chunks), (const int*)(tb + L.jrange), n_mels, logmel, gmax);
+    hipLaunchKernelGGL((logmel_fused_kernel<JT, TO>), dim3((WIPA_N_FRAMES + WG_FRAMES - 1) / WG_FRAMES, batch), dim3(256), fused_lds(JT), s,
+                       audio, (const float*)(tb + L.chunks), (const int*)(tb + L.jrange), n_mels, out, gmax);
+    const int per_out = (WIPA_N_FRAMES + 2) * n_mels;
+    hipLaunchKernelGGL((mel_clamp_kernel<TO>), dim3((per_out + 255) / 256, batch), dim3(256), 0, s, gmax, n_mels, out);
     WIPA_LAUNCH_CHECK();
     return WIPA_OK;
+}
+
+template <typename TO>
+int launch_fused_jt(const float* audio, int batch, int n_mels, const char* tb, const TableLayout& L, TO* out, unsigned* gmax, hipStream_t s) {
+    switch (mel_tiles(n_mels)) {
+        case 1: return launch_fused<1, TO>(audio, batch, n_mels, tb, L, out, gmax, s);
+        case 2: return launch_fused<2, TO>(audio, batch, n_mels, tb, L, out, gmax, s);
+        case 3: return launch_fused<3, TO>(audio, batch, n_mels, tb, L, out, gmax, s);
+        case 4: return launch_fused<4, TO>(audio, batch, n_mels, tb, L, out, gmax, s);
+        case 5: return launch_fused<5, TO>(audio, batch, n_mels, tb, L, out, gmax, s);
+        case 6: return launch_fused<6, TO>(audio, batch, n_mels, tb, L, out, gmax, s);
+        case 7: return launch_fused<7, TO>(audio, batch, n_mels, tb, L, out, gmax, s);
+        default: return launch_fused<8, TO>(audio, batch, n_mels, tb, L, out, gmax, s);
+    }
 }
 
 bool use_fused(int n_mels) {
@@ -417,19 +466,14 @@ extern "C" int wipa_logmel(const float* audio, int batch, int n_mels, const void
     const int per_clip = WIPA_N_FRAMES * n_mels;
     const int per_out = (WIPA_N_FRAMES + 2) * n_mels;
     if (use_fused(n_mels)) {
+        WIPA_REQUIRE(mel_dtype == WIPA_F32 || mel_dtype == WIPA_BF16, "wipa_logmel: bad mel dtype %d", mel_dtype);
         WIPA_CHECK_HIP(hipMemsetAsync(gmax, 0, batch * sizeof(unsigned), s));
-        int rc;
-        switch (mel_tiles(n_mels)) {
-            case 1: rc = launch_fused<1>(audio, batch, n_mels, tb, L, logmel, gmax, s); break;
-            case 2: rc = launch_fused<2>(audio, batch, n_mels, tb, L, logmel, gmax, s); break;
-            case 3: rc = launch_fused<3>(audio, batch, n_mels, tb, L, logmel, gmax, s); break;
-            case 4: rc = launch_fused<4>(audio, batch, n_mels, tb, L, logmel, gmax, s); break;
-            case 5: rc = launch_fused<5>(audio, batch, n_mels, tb, L, logmel, gmax, s); break;
-            case 6: rc = launch_fused<6>(audio, batch, n_mels, tb, L, logmel, gmax, s); break;
-            case 7: rc = launch_fused<7>(audio, batch, n_mels, tb, L, logmel, gmax, s); break;
-            default: rc = launch_fused<8>(audio, batch, n_mels, tb, L, logmel, gmax, s); break;
-        }
+        const int rc = mel_dtype == WIPA_F32 ? launch_fused_jt<float>(audio, batch, n_mels, tb, L, (float*)mel, gmax, s)
+                                             : launch_fused_jt<__bf16>(audio, batch, n_mels, tb, L, (__bf16*)mel, gmax, s);
         if (rc != WIPA_OK) return rc;
+        const size_t esz = wipa_dtype_size(mel_dtype);
+        WIPA_CHECK_HIP(hipMemsetAsync((char*)mel + (size_t)batch * per_out * esz, 0, 4 * (size_t)n_mels * esz, s));
+        return WIPA_OK;
     } else {
     const int64_t total = (int64_t)batch * PAD_CLIP + PAD_SLACK;
     hipLaunchKernelGGL(reflect_pad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, audio, padded,
