@@ -324,14 +324,30 @@ __global__ __launch_bounds__(256) void mel_clamp_kernel(const unsigned* __restri
     if ((float)*p < floor_y) *p = from_f32<TO>(floor_y);
 }
 
+// the dynamic-LDS limit of the fused kernel is raised by wipa_logmel_init (once per n_mels, outside any stream capture)
+template <int JT>
+int fused_attrs() {
+    WIPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&logmel_fused_kernel<JT, float>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds(JT)));
+    WIPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&logmel_fused_kernel<JT, __bf16>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds(JT)));
+    return WIPA_OK;
+}
+int fused_attrs_for(int n_mels) {
+    switch (mel_tiles(n_mels)) {
+        case 1: return fused_attrs<1>();
+        case 2: return fused_attrs<2>();
+        case 3: return fused_attrs<3>();
+        case 4: return fused_attrs<4>();
+        case 5: return fused_attrs<5>();
+        case 6: return fused_attrs<6>();
+        case 7: return fused_attrs<7>();
+        default: return fused_attrs<8>();
+    }
+}
+
 template <int JT, typename TO>
 int launch_fused(const float* audio, int batch, int n_mels, const char* tb, const TableLayout& L, TO* out, unsigned* gmax, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        WIPA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&logmel_fused_kernel<JT, TO>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds(JT)));
-        attr_done = true;
-    }
     hipLaunchKernelGGL((logmel_fused_kernel<JT, TO>), dim3((WIPA_N_FRAMES + WG_FRAMES - 1) / WG_FRAMES, batch), dim3(256), fused_lds(JT), s,
                        audio, (const float*)(tb + L.chunks), (const int*)(tb + L.jrange), n_mels, out, gmax);
     const int per_out = (WIPA_N_FRAMES + 2) * n_mels;
@@ -365,6 +381,10 @@ extern "C" size_t wipa_logmel_tables_bytes(int n_mels) { return table_layout(n_m
 
 extern "C" int wipa_logmel_init(void* tables, int n_mels, wipa_stream_t stream) {
     WIPA_REQUIRE(tables && n_mels > 0 && n_mels <= 256, "wipa_logmel_init: bad arguments");
+    if (use_fused(n_mels)) {
+        const int rc = fused_attrs_for(n_mels);
+        if (rc != WIPA_OK) return rc;
+    }
     const TableLayout L = table_layout(n_mels);
     std::vector<char> host(L.total, 0);
     float* dft = reinterpret_cast<float*>(host.data() + L.dft);
