@@ -14,14 +14,15 @@
 // arithmetic -- the contraction runs over d = 768 channels instead of 64 per head, 12x the FLOPs -- which is why it only works
 // on the matrix cores, with the 12 heads of a clip as one 16-wide MFMA dimension:
 //
-//   wipa_cross_absorb_q      Qp[b][h][:] = scale * q_h[b] Wk_h              [B, 16, d] bf16 (heads 12..15 stay zero)
-//   wipa_cross_absorbed_attn one workgroup per (clip, frame split): 32-frame tiles of xa stream through LDS by LDS-DMA
-//                            (2 x 48 KiB, two tiles in flight); per tile S^T[32 frames, 16 heads] = tile Qp^T (channels split
-//                            over the 4 waves, partial sums exchanged through LDS in a fixed order), online softmax per
-//                            head, O'[16 heads, d] += P tile with the SAME tile read column-wise by ds_read_b64_tr_b16 --
-//                            the P accumulator tile is the A operand as it stands (k order 4g+j | 16+4g+j, which the
-//                            transposed reads follow); partial (m, l, O') per split
-//   wipa_cross_merge_proj    merges the splits (fixed order), out_h = (O'_h / l_h) Wv_h^T + bv_h -> [B, d] bf16
+//   cross_absorb_q_kernel    Qp[b][h][:] = scale * q_h[b] Wk_h              [B, 16, d] bf16 (heads 12..15 stay zero)
+//   cross_absorbed_v2_kernel (d <= 768, the default) one workgroup per (clip, frame split) of three INDEPENDENT waves: a wave owns
+//                            16-frame groups of xa in two private LDS slots filled by LDS-DMA (no barrier in the loop), computes
+//                            S^T[16 frames, 16 heads] over all channels against the absorbed queries held in registers, a
+//                            softmax against a fixed per-head reference, and O'[16 heads, d] += P group with the SAME group read
+//                            column-wise by ds_read_b64_tr_b16; the three waves' (m, l, O') merge through LDS at the end
+//   cross_absorbed_kernel    (d = 1024, and WIPA_ABS_KERNEL=1 for A/B runs) the first form: 32-frame tiles shared by 4 waves
+//                            that split the CHANNELS, partial scores exchanged through LDS in a fixed order, online softmax
+//   cross_merge_proj_kernel  merges the splits (fixed order), out_h = (O'_h / l_h) Wv_h^T + bv_h -> [B, d] bf16
 //
 // Rounding points differ from the cached-K/V path (K and V are never rounded to bf16 here; Qp and O' are): the results
 // are equal up to bf16 noise, and closer to the f32 arithmetic.  bf16 models with <= 16 heads and d in {384, 512, 768, 1024}.
@@ -54,22 +55,12 @@ __device__ __forceinline__ int swz(int row) { return (row & 7) << 1; }
 // the buffer that is re-staged.
 template <int D>
 struct AbsCfg {
-#ifndef WIPA_ABS_NW
-#define WIPA_ABS_NW 4
-#endif
-#ifndef WIPA_ABS_NBUF
-#define WIPA_ABS_NBUF 3
-#endif
-    static constexpr int NW = (WIPA_ABS_NW == 8 && D % 256 == 0) ? 8 : 4;
+    static constexpr int NW = 4;  // (8 waves and two / three buffers were measured for d = 768: no faster)
     static constexpr int ROWB = D * 2;
     static constexpr int TILE = FT * ROWB;
     static constexpr int SX = NW * 2 * 64 * 4 * (int)sizeof(float);
-    static constexpr int NBUF = (WIPA_ABS_NBUF == 3 && 3 * TILE + SX <= 160 * 1024) ? 3 : 2;
-#ifdef WIPA_ABS_FULL_LDS
-    static constexpr int SMEM = 160 * 1024;  // experiment: the whole CU's LDS, no co-resident workgroup
-#else
+    static constexpr int NBUF = (3 * TILE + SX <= 160 * 1024) ? 3 : 2;
     static constexpr int SMEM = NBUF * TILE + SX;
-#endif
 };
 
 template <int D>
@@ -109,9 +100,6 @@ __global__ __launch_bounds__(512, 1) void cross_absorbed_kernel(AbsParams p) {
         dch[i] = ((off % ROWB) >> 4) ^ swz(off / ROWB);
     }
     auto stage = [&](int t, int buf) {
-#if defined(WIPA_ABS_DEBUG) && WIPA_ABS_DEBUG == 2
-        if (t > 1) return;  // timing experiment: the arithmetic alone on whatever the buffers hold
-#endif
         const int f0 = (tile0 + t) * FT;
 #pragma unroll
         for (int i = 0; i < NDMA; ++i) {
@@ -148,9 +136,6 @@ __global__ __launch_bounds__(512, 1) void cross_absorbed_kernel(AbsParams p) {
         if constexpr (NBUF == 3) {
             if (t + 2 < nt) stage(t + 2, (t + 2) % 3);  // into the buffer tile t - 1 has just left
         }
-#if defined(WIPA_ABS_DEBUG) && WIPA_ABS_DEBUG == 1
-        continue;  // timing experiment: the stream alone (DMA + one barrier per tile), no arithmetic
-#endif
         const char* tb = smem + buf * TILE;
         // ---- partial scores over this wave's channels: S^T[frame 16 ft + 4g + r][head l15]
         f32x4 s[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
