@@ -304,6 +304,13 @@ int wipa_cross_absorbed_init(int d);
 int wipa_cross_absorbed_attention(const void* q, int64_t q_row_stride, const void* wkT, const void* xa, const void* wv, const float* bv,
                                   void* out, int64_t out_row_stride, void* scratch, size_t scratch_bytes, int B, int H, int d, int Tk,
                                   float k_scale, wipa_stream_t s);
+/* The absorbed cross block of ONE decode step in three launches (the decode loop's form; wipa_cross_absorbed_attention with a
+ * given query serves the prompt prefill and the tests): [split-K slab sum + residual + cross_attn_ln + cross query + absorbed query]
+ * -> streaming kernel -> [merge + value projection].  The descriptor is wipa_decode_cross_block's with c->kv = the encoder output
+ * xa [B][Tk][d] and c->out [B][d] bf16; bias_o must be NULL (slab 0 carries the out-projection bias), n_slabs <= 4;
+ * wkT / wv / bv / scratch as above.  c->x_out must not alias c->x_in. */
+int wipa_decode_cross_absorbed_block(const wipa_cross_block_desc* c, const void* wkT, const void* wv, const float* bv, void* scratch,
+                                     size_t scratch_bytes, wipa_stream_t s);
 /* measurement aid: the streaming kernel of wipa_cross_absorbed_attention alone, on a scratch a full call has filled */
 int wipa_cross_absorbed_stream(const void* xa, void* scratch, size_t scratch_bytes, int B, int H, int d, int Tk, wipa_stream_t s);
 

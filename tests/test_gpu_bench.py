@@ -39,18 +39,20 @@ def test_bench_single_rank_contract_and_rooflines():
         r = out[key]
         assert r["bound"] in ("hbm", "mfma") and r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3, key
     # convs + 5 GEMMs x 4 encoder layers; the 4 cross-K/V projections only run with a K/V cache (absorbed projections: none)
-    assert out["config"]["cross_attention"] == "cached"  # the default: mlx_whisper's projected K / V caches
-    assert out["roofline_mfma"]["gemm_launches"] == 2 + 5 * 4 + 4
-    assert "decode_cross_block" in out["roofline"]["kernel"]
+    # the default: absorbed-projection cross-attention (no cross-K/V GEMMs, the streaming kernel is the roofline kernel, half the
+    # cross bytes per step)
+    assert out["config"]["cross_attention"] == "absorbed"
+    assert out["roofline_mfma"]["gemm_launches"] == 2 + 5 * 4
+    assert "cross_absorbed_v2_kernel" in out["roofline"]["kernel"] and out["roofline"]["layer_call"]["avg_ms"] > out["roofline"]["avg_launch_ms"]
     assert out["decode_step"]["bytes_per_step"] > out["decode_step"]["cross_kv_bytes"] > 0
-    # the absorbed-projection cross-attention (opt-in): no cross-K/V GEMMs, the streaming kernel is the roofline kernel, half the
-    # cross bytes per step, and the same greedy ids on this tiny model's 8 clips
-    ab = _run(["--steps", "3", "--warmup", "1", "--model", "tiny", "--batch", "8", "--pipeline", "2", "--no-cpu-baseline", "--cross-attention", "absorbed"])
-    assert ab["config"]["cross_attention"] == "absorbed" and ab["passes_identical"] is True
-    assert ab["roofline_mfma"]["gemm_launches"] == 2 + 5 * 4
-    assert "cross_absorbed_v2_kernel" in ab["roofline"]["kernel"] and ab["roofline"]["layer_call"]["avg_ms"] > ab["roofline"]["avg_launch_ms"]
-    assert ab["decode_step"]["cross_kv_bytes"] * 2 == out["decode_step"]["cross_kv_bytes"]
-    assert ab["decode_step"]["cached_kv_accounting"]["bytes_per_step"] == out["decode_step"]["bytes_per_step"]
+    # mlx_whisper's projected K / V caches (opt-in): four more GEMM launches, the fused cross block as the roofline kernel, twice
+    # the cross bytes, and the same accounting when the absorbed line is read in cached-K/V terms
+    ck = _run(["--steps", "3", "--warmup", "1", "--model", "tiny", "--batch", "8", "--pipeline", "2", "--no-cpu-baseline", "--cross-attention", "cached"])
+    assert ck["config"]["cross_attention"] == "cached" and ck["passes_identical"] is True
+    assert ck["roofline_mfma"]["gemm_launches"] == 2 + 5 * 4 + 4
+    assert "decode_cross_block" in ck["roofline"]["kernel"]
+    assert out["decode_step"]["cross_kv_bytes"] * 2 == ck["decode_step"]["cross_kv_bytes"]
+    assert out["decode_step"]["cached_kv_accounting"]["bytes_per_step"] == ck["decode_step"]["bytes_per_step"]
 
 
 def test_bench_experiment_flags_keep_the_ids():

@@ -218,7 +218,7 @@ def test_fused_decode_step_equals_unfused_step(micro, small2, monkeypatch, dtype
     always, first = R.suppress_lists(sp)
     init = list(sp.sot_sequence_including_notimestamps(0))
     for dims, (W, mels, xa), n_new in ((MICRO, micro, 40), (SMALL2, small2, 12)):
-        m = _model(dims, W, dtype)
+        m = _model(dims, W, dtype, cross_attention="cached")  # the step variants of the cached-K/V form
         feats = xa.cuda().to(dtype)
         out = {}
         for fused in ("1", "2", "0"):
@@ -248,6 +248,36 @@ def test_fused_decode_step_equals_unfused_step(micro, small2, monkeypatch, dtype
             rows = same.all(axis=1)
             if rows.any():
                 assert (a[2][rows] - b[2][rows]).abs().max() < 0.25
+
+
+def test_absorbed_cross_block_fused_prologue_equals_separate_launches(small2, monkeypatch):
+    """The absorbed cross block of the decode step: [slab sum + LayerNorm + cross query + absorbed query] in ONE launch
+    (cross_absorb_prologue_kernel, the default) against the three separate launches (WIPA_ABS_FUSED_PROLOGUE=0:
+    add_slabs_layernorm, query GEMM, cross_absorb_q).  Same bf16 rounding points; the f32 summation orders differ (LayerNorm
+    statistics per wave instead of per block, K split over eight waves), which can move a stored bf16 value by one ulp: the
+    logits along a fixed token history agree to a small fraction of their spread, graph replay == eager bit for bit."""
+    from whisper_ipa_amd.decoding import forced_decode_logits, greedy_decode_tokens
+
+    W, mels, xa = small2
+    sp = R.SpecialTokens.multilingual()
+    always, first = R.suppress_lists(sp)
+    init = list(sp.sot_sequence_including_notimestamps(0))
+    m = _model(SMALL2, W, torch.bfloat16, cross_attention="absorbed")
+    feats = xa.cuda().to(torch.bfloat16)
+    base = greedy_decode_tokens(m, feats, init, always, first, sp.eot, max_new_tokens=16, stop_on_eot=False)
+    traces = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("WIPA_ABS_FUSED_PROLOGUE", flag)
+        t_graph, _ = forced_decode_logits(m, feats, base.tokens, 4, always, first, sp.eot, use_graph=True)
+        t_eager, _ = forced_decode_logits(m, feats, base.tokens, 4, always, first, sp.eot, use_graph=False)
+        assert torch.equal(t_graph, t_eager), flag
+        traces[flag] = t_graph.float().cpu()
+    monkeypatch.delenv("WIPA_ABS_FUSED_PROLOGUE")
+    finite = torch.isfinite(traces["1"]) & torch.isfinite(traces["0"])
+    diff = (traces["1"] - traces["0"])[finite].abs().max().item()
+    spread = traces["0"][finite].std().item()
+    print(f"\nabsorbed cross block, fused prologue vs separate launches: max logit difference {diff:.4f} = {diff / spread:.4f} of the logit std")
+    assert diff < 0.03 * spread, (diff, spread)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -699,6 +699,168 @@ __global__ __launch_bounds__(64 * MergeCfg<D>::NWM) void cross_merge_proj_kernel
     }
 }
 
+// Prologue of the absorbed cross block in ONE launch (instead of add_slabs_layernorm + query GEMM + cross_absorb_q): one
+// workgroup per (head, 16 clips), eight waves.
+//   1. rows: x = x_in + slabs (fixed order) -> LayerNorm -> bf16 in LDS; the h = 0 workgroup writes x to x_out (the other
+//      residual buffer: the 12 head workgroups of a clip group all read the row one of them rewrites) and zero-fills the padded
+//      heads' rows of Qp;
+//   2. q_h[16 clips][64] = LN(x) Wq_h^T + bq_h, times the query's share of the score scale: MFMA, the waves split K (24 k-steps),
+//      partial tiles meet in LDS in a fixed order, rounded to bf16 like the separate query GEMM's output;
+//   3. Qp_h[16 clips][d] = k_scale * q_h Wk_h: MFMA, the waves split the d / 16 column tiles; WkT rows are the B fragments.
+// Weight fragments of steps 2 and 3 are requested before step 1 (196 KB per workgroup, from L2).
+struct AbsPrologueParams {
+    const float* x_in;
+    float* x_out;
+    const float* slabs;
+    const float* ln_w;
+    const float* ln_b;
+    const __bf16* wq;    // [d][d]  ([out][in])
+    const float* bq;     // [d]
+    const __bf16* wkT;   // [d][d]  ([channel][out])
+    __bf16* qp;          // [B][16][d]
+    int64_t slab_stride;
+    int n_slabs, B, H;
+    float eps, q_scale, k_scale;
+};
+
+template <int D>
+__global__ __launch_bounds__(512) void cross_absorb_prologue_kernel(AbsPrologueParams p) {
+    constexpr int KS = D / 32;          // k-steps of the query projection
+    constexpr int KSW = (KS + 7) / 8;   // per wave
+    constexpr int NT = D / 16;          // column tiles of Qp
+    constexpr int NTW = (NT + 7) / 8;   // per wave
+    constexpr int LROW = D + 8;         // padded LDS row of the normalised activations (bf16)
+    constexpr int V4 = D / 256;         // float4 per lane of a row (D / 4 / 64)
+    static_assert(D % 256 == 0 || D == 384, "width");
+    __shared__ __attribute__((aligned(16))) __bf16 lnx[16][LROW];
+    __shared__ __attribute__((aligned(16))) float red[8][16][64 + 4];
+    __shared__ __attribute__((aligned(16))) __bf16 qh[16][64 + 8];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x, b0 = blockIdx.y * 16;
+    // ---- weight fragments first: Wq rows h*64 + 16 nt + l15 at this wave's k-steps; WkT rows (channels) of this wave's column tiles
+    bf16x8 wqf[4][KSW];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int i = 0; i < KSW; ++i) {
+            const int ks = min(wave * KSW + i, KS - 1);
+            wqf[nt][i] = *reinterpret_cast<const bf16x8*>(p.wq + (int64_t)(h * 64 + 16 * nt + l15) * D + 32 * ks + 8 * g);
+        }
+    bf16x8 wkf[NTW][2];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int nt = min(wave * NTW + i, NT - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            wkf[i][ks] = *reinterpret_cast<const bf16x8*>(p.wkT + (int64_t)(16 * nt + l15) * D + h * 64 + 32 * ks + 8 * g);
+    }
+    // ---- 1. slab sum + LayerNorm of rows 2 wave, 2 wave + 1 (one wave per row: 4 consecutive floats per lane and 256-column block)
+    constexpr int NV = (D + 255) / 256;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int row = 2 * wave + rr;
+        const int b = min(b0 + row, p.B - 1);
+        f32x4 v[NV], ww[NV], bb[NV];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = 4 * lane + 256 * i;
+            v[i] = ww[i] = bb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < D) {
+                v[i] = *reinterpret_cast<const f32x4*>(p.x_in + (int64_t)b * D + c);
+                f32x4 sl[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    sl[s] = (s < p.n_slabs) ? *reinterpret_cast<const f32x4*>(p.slabs + (int64_t)s * p.slab_stride + (int64_t)b * D + c)
+                                            : f32x4{0.f, 0.f, 0.f, 0.f};
+                ww[i] = *reinterpret_cast<const f32x4*>(p.ln_w + c);
+                bb[i] = *reinterpret_cast<const f32x4*>(p.ln_b + c);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    if (s < p.n_slabs) v[i] += sl[s];  // fixed order
+                sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+                if (h == 0 && b0 + row < p.B) *reinterpret_cast<f32x4*>(p.x_out + (int64_t)b * D + c) = v[i];
+            }
+        }
+        const float mean = wave_reduce_sum(sum) / (float)D;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (4 * lane + 256 * i < D) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dv = v[i][e] - mean;
+                    sq += dv * dv;
+                }
+            }
+        const float rstd = rsqrtf(wave_reduce_sum(sq) / (float)D + p.eps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = 4 * lane + 256 * i;
+            if (c < D) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) lnx[row][c + e] = (__bf16)((v[i][e] - mean) * rstd * ww[i][e] + bb[i][e]);
+            }
+        }
+    }
+    if (h == 0) {  // padded heads of Qp: zero (the streaming kernel multiplies all 16 rows of the head dimension)
+        for (int e = tid; e < 16 * (16 - p.H) * (D / 8); e += 512) {
+            const int row = e / ((16 - p.H) * (D / 8)), rem = e - row * ((16 - p.H) * (D / 8));
+            const int hp = p.H + rem / (D / 8), c8 = rem % (D / 8);
+            if (b0 + row < p.B) *reinterpret_cast<bf16x8*>(p.qp + ((int64_t)(b0 + row) * 16 + hp) * D + 8 * c8) = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    __syncthreads();
+    // ---- 2. query of the head: partial over this wave's k-steps
+    {
+        f32x4 acc[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int i = 0; i < KSW; ++i) {
+            const int ks = wave * KSW + i;
+            if (ks < KS) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&lnx[l15][32 * ks + 8 * g]);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wqf[nt][i], acc[nt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][4 * g + r][16 * nt + l15] = acc[nt][r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = tid + 512 * i, row = e >> 6, j = e & 63;
+        float q = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) q += red[w][row][j];  // fixed order
+        qh[row][j] = (__bf16)((q + p.bq[h * 64 + j]) * p.q_scale);
+    }
+    __syncthreads();
+    // ---- 3. absorbed query: this wave's column tiles
+    {
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&qh[l15][8 * g]);
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&qh[l15][32 + 8 * g]);
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            const int nt = wave * NTW + i;
+            if (nt < NT) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wkf[i][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wkf[i][1], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int bb_ = b0 + 4 * g + r;
+                    if (bb_ < p.B) p.qp[((int64_t)bb_ * 16 + h) * D + 16 * nt + l15] = (__bf16)(acc[r] * p.k_scale);
+                }
+            }
+        }
+    }
+}
+
 // WIPA_ABS_KERNEL=1 keeps the channel-split kernel (A/B runs); default: the independent-wave kernel
 template <int D>
 int launch_attn(const AbsParams& p_in, int B, hipStream_t s) {
@@ -840,6 +1002,58 @@ extern "C" int wipa_cross_absorbed_attention(const void* q, int64_t q_row_stride
     else if (d == 768) ABS_RUN(768);
     else ABS_RUN(1024);
 #undef ABS_RUN
+    if (rc != WIPA_OK) return rc;
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+// The whole absorbed cross block of a decode step in three launches: [slab sum + residual + cross_attn_ln + cross query + absorbed
+// query] -> streaming kernel -> [merge + value projection].  c->kv is the encoder output xa [B][Tk][d]; c->x_out must not alias
+// c->x_in (the caller swaps its two residual buffers afterwards, as with wipa_decode_cross_block).
+extern "C" int wipa_decode_cross_absorbed_block(const wipa_cross_block_desc* c, const void* wkT, const void* wv, const float* bv, void* scratch,
+                                                size_t scratch_bytes, wipa_stream_t stream) {
+    WIPA_REQUIRE(c && c->x_in && c->x_out && c->ln_w && c->ln_b && c->wq && c->bq && c->kv && c->out && wkT && wv && bv && scratch,
+                 "wipa_decode_cross_absorbed_block: null pointer");
+    WIPA_REQUIRE(c->x_in != c->x_out, "wipa_decode_cross_absorbed_block: x_out must not alias x_in");
+    const int B = c->B, H = c->H, d = c->d, Tk = c->Tk;
+    WIPA_REQUIRE(c->dtype == WIPA_BF16 && B > 0 && B <= 65535 * 16 && H >= 1 && H <= 16 && d == H * 64 &&
+                     (d == 384 || d == 512 || d == 768 || d == 1024) && Tk >= 1 && c->n_slabs >= 0 && c->n_slabs <= 4 && !c->bias_o,
+                 "wipa_decode_cross_absorbed_block: bf16, <= 16 heads of 64, d in {384, 512, 768, 1024}, <= 4 slabs, no separate bias");
+    WIPA_REQUIRE(c->n_slabs == 0 || c->slabs, "wipa_decode_cross_absorbed_block: slabs missing");
+    WIPA_REQUIRE((int64_t)Tk * d * 2 < ((int64_t)1 << 31), "wipa_decode_cross_absorbed_block: clip too long for 32-bit tile offsets");
+    WIPA_REQUIRE(scratch_bytes >= wipa_cross_absorbed_scratch_bytes(B, d, Tk), "wipa_decode_cross_absorbed_block: scratch too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int S = wipa_cross_absorbed_splits(B, Tk);
+    char* sc = (char*)scratch;
+    __bf16* qp = (__bf16*)sc;
+    float* part_m = (float*)(sc + (size_t)B * 16 * d * 2);
+    float* part_l = part_m + (size_t)B * S * 16;
+    float* part_o = part_l + (size_t)B * S * 16;
+    AbsPrologueParams q = {};
+    q.x_in = c->x_in; q.x_out = c->x_out; q.slabs = c->slabs; q.ln_w = c->ln_w; q.ln_b = c->ln_b;
+    q.wq = (const __bf16*)c->wq; q.bq = c->bq; q.wkT = (const __bf16*)wkT; q.qp = qp;
+    q.slab_stride = c->slab_stride; q.n_slabs = c->n_slabs; q.B = B; q.H = H;
+    q.eps = c->eps; q.q_scale = c->qk_scale; q.k_scale = c->qk_scale;
+    AbsParams p = {};
+    p.qp = qp; p.xa = (const __bf16*)c->kv; p.part_m = part_m; p.part_l = part_l; p.part_o = part_o;
+    p.Tk = Tk; p.n_splits = S; p.H = H;
+    const int tiles = (Tk + FT - 1) / FT;
+    p.tiles_per_split = (tiles + S - 1) / S;
+    const dim3 gp(H, (B + 15) / 16), gm(H, (B + 3) / 4);
+    int rc = WIPA_OK;
+#define ABS_BLOCK(D)                                                                                                                       \
+    do {                                                                                                                                   \
+        hipLaunchKernelGGL((cross_absorb_prologue_kernel<D>), gp, dim3(512), 0, s, q);                                                     \
+        rc = launch_attn<D>(p, B, s);                                                                                                      \
+        if (rc == WIPA_OK)                                                                                                                 \
+            hipLaunchKernelGGL((cross_merge_proj_kernel<D>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o, S,             \
+                               (const __bf16*)wv, bv, (__bf16*)c->out, (int64_t)d, B);                                                     \
+    } while (0)
+    if (d == 384) ABS_BLOCK(384);
+    else if (d == 512) ABS_BLOCK(512);
+    else if (d == 768) ABS_BLOCK(768);
+    else ABS_BLOCK(1024);
+#undef ABS_BLOCK
     if (rc != WIPA_OK) return rc;
     WIPA_LAUNCH_CHECK();
     return WIPA_OK;

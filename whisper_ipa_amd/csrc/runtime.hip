@@ -370,6 +370,12 @@ __global__ void fill_tokens_kernel(int32_t* tokens, int64_t ld_tok, int B, int n
 }
 
 // one decoder step (all layers + logits + greedy update + position advance)
+// WIPA_ABS_FUSED_PROLOGUE=0 keeps the separate LayerNorm / query GEMM / absorb launches of the absorbed cross block (A/B runs)
+bool absorbed_block_fused() {
+    const char* e = getenv("WIPA_ABS_FUSED_PROLOGUE");
+    return !(e && atoi(e) == 0);
+}
+
 int enqueue_step(const wipa_model_cfg* cfg, const void* const* w, char* st, const wipa_dec_layout& L, int B, int n_init,
                  int eot, const float* mask_first, const float* mask_always, wipa_stream_t stream) {
     const int dt = cfg->dtype;
@@ -448,6 +454,20 @@ int enqueue_step(const wipa_model_cfg* cfg, const void* const* w, char* st, cons
             c.kv = ckv; c.out = ao; c.slab_stride = slab_stride;
             c.n_slabs = pend; c.B = B; c.d = d; c.H = H; c.Tk = Ta; c.dtype = dt; c.eps = 1e-5f; c.qk_scale = QK_SCALE;
             RT_CALL(wipa_decode_cross_block(&c, stream));
+            pend = 0;
+            std::swap(x, x_other);
+        } else if (absorbed && absorbed_block_fused() && pend <= 4) {
+            // three launches: [slab sum + residual + cross_attn_ln + cross query + absorbed query] -> stream over the encoder output
+            // -> [merge + value projection]; the residual row moves to the other buffer like in the fused cross block
+            const void* wkT = w[WIPA_DEC_GLOBAL + WIPA_DEC_PER_LAYER * cfg->n_text_layer + WIPA_DEC_ABSORBED_PER_LAYER * l];
+            wipa_cross_block_desc c;
+            memset(&c, 0, sizeof(c));
+            c.x_in = x; c.x_out = x_other; c.slabs = slabs; c.bias_o = nullptr;
+            c.ln_w = (const float*)lw[6]; c.ln_b = (const float*)lw[7]; c.wq = lw[8]; c.bq = (const float*)lw[9];
+            c.kv = st + L.cross_kv; c.out = ao; c.slab_stride = slab_stride;
+            c.n_slabs = pend; c.B = B; c.d = d; c.H = H; c.Tk = Ta; c.dtype = dt; c.eps = 1e-5f; c.qk_scale = QK_SCALE;
+            RT_CALL(wipa_decode_cross_absorbed_block(&c, wkT, (const char*)lw[10] + (size_t)d * d * e, (const float*)lw[11] + d,
+                                                     sc + S.absorbed, S.total - S.absorbed, stream));
             pend = 0;
             std::swap(x, x_other);
         } else {
@@ -834,7 +854,7 @@ extern "C" int wipa_decoder_run(const wipa_model_cfg* cfg, const void* const* w,
     }
     WIPA_REQUIRE(s != nullptr, "wipa_decoder_run: graph capture needs a non-default stream");
     hipGraphExec_t exec = nullptr;
-    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * decode_mode(cfg, B) + 16 * cfg->dec_w_dtype + 64 * cfg->dec_cross_absorbed, cfg->weights_generation, 0);
+    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * decode_mode(cfg, B) + 16 * cfg->dec_w_dtype + 64 * cfg->dec_cross_absorbed * (absorbed_block_fused() ? 2 : 1), cfg->weights_generation, 0);
     {
         std::lock_guard<std::mutex> lk(g_graph_mu);
         auto it = g_graphs.find(key);
@@ -876,7 +896,7 @@ extern "C" int wipa_decoder_prefill(const wipa_model_cfg* cfg, const void* const
     RT_CALL(init_before_capture(cfg));
     if (!use_graph || s == nullptr || !graphs_allowed()) return enqueue();
     hipGraphExec_t exec = nullptr;
-    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * decode_mode(cfg, B) + 16 * cfg->dec_w_dtype + 64 * cfg->dec_cross_absorbed, cfg->weights_generation, 1);
+    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * decode_mode(cfg, B) + 16 * cfg->dec_w_dtype + 64 * cfg->dec_cross_absorbed * (absorbed_block_fused() ? 2 : 1), cfg->weights_generation, 1);
     {
         std::lock_guard<std::mutex> lk(g_graph_mu);
         auto it = g_graphs.find(key);

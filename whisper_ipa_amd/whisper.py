@@ -129,10 +129,11 @@ class Whisper:
         per decoder layer and streamed every step, as mlx_whisper caches them.  "absorbed": Wk is absorbed into the query and
         Wv into the output, and every layer streams the encoder output xa itself -- half the bytes per step, no K/V cache, no
         projection GEMMs (csrc/cross_absorbed.hip); bf16 models with <= 16 heads and d in {384, 512, 768, 1024}, no fp8 tables.
-        "auto" (default): cached, unless WIPA_CROSS_ABSORB=1 asks for absorbed where it applies.  Same mathematics, other bf16
-        rounding points.  Measured on MI355X: absorbed wins when a pass is encoder-heavy or the batch is
-        large (whisper-small, 64 clips x 64 new tokens: 80.4 vs 82.5 ms; whisper-medium, 256 clips: 823 vs 867 ms) and loses
-        when the pass is decode-dominated (224 new tokens: 279.8 vs 244.4 ms -- its four extra launches per layer).  The choice is
+        "auto" (default): absorbed where it applies (WIPA_CROSS_ABSORB=0 turns that off).  Same mathematics, other bf16
+        rounding points.  Measured on MI355X, absorbed against cached: whisper-small, 64 clips: +5.8 % at
+        32 and 64 new tokens, +2.8 % at 128, -6.5 % at 224 (its extra launches per layer weigh most when every pass in flight
+        is decoding and the batch is small); 128 clips: +9.1 % at 64 tokens, +2.6 % at 224; whisper-medium, 256 clips: +5 % / +3.4 %.
+        Serving long outputs at small batch is the one case for cross_attention="cached".  The choice is
         explicit here and in the CPU checker, and both settings are pinned by golden fixtures (tests/golden/wide_model.npz)."""
         if cross_attention not in ("auto", "absorbed", "cached"):
             raise _lib.WipaError(f"cross_attention must be 'auto', 'absorbed' or 'cached', got {cross_attention!r}")
@@ -302,7 +303,7 @@ class Whisper:
             return True
         if self.cross_attention == "cached":
             return False
-        return eligible and os.environ.get("WIPA_CROSS_ABSORB", "0") == "1"
+        return eligible and os.environ.get("WIPA_CROSS_ABSORB", "1") != "0"
 
     # ---- packing -------------------------------------------------------------------
     def _cfg(self, fp8: bool = False) -> _lib.ModelCfg:
