@@ -15,11 +15,11 @@ echo "== kernel trace of the default bench command"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o bench -- python3 $ROOT/bench.py --no-cpu-baseline --no-finetune --steps 6 > $OUT/kt.log 2>&1 || exit 1
 echo "== kernel trace, one pass in flight"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt1 -o bench -- python3 $ROOT/bench.py --no-cpu-baseline --no-finetune --steps 3 --pipeline 1 > $OUT/kt1.log 2>&1 || exit 1
-echo "== counters: fused cross block (the dominant kernel of the default decode step)"
+echo "== counters: fused cross block on cached K / V (cross_attention=cached)"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_c1 -- python3 $ROOT/tools/pmc_cross_block.py > $OUT/pmc_c1.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_c2 -- python3 $ROOT/tools/pmc_cross_block.py > $OUT/pmc_c2.log 2>&1 || exit 1
 python3 $ROOT/tools/pmc_cross_block.py > $OUT/pmc_c_timing.log 2>&1 || exit 1
-echo "== counters: streaming kernel of the absorbed cross-attention (opt-in)"
+echo "== counters: streaming kernel of the absorbed cross-attention (the dominant kernel of the default decode step)"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_x1 -- python3 $ROOT/tools/pmc_cross_absorbed.py > $OUT/pmc_x1.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_x2 -- python3 $ROOT/tools/pmc_cross_absorbed.py > $OUT/pmc_x2.log 2>&1 || exit 1
 python3 $ROOT/tools/pmc_cross_absorbed.py > $OUT/pmc_x_timing.log 2>&1 || exit 1
@@ -35,17 +35,19 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_lm1 -- python3 $ROOT/
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_lm2 -- python3 $ROOT/tools/logmel_bench.py 64 80 > $OUT/pmc_lm2.log 2>&1 || exit 1
 python3 $ROOT/tools/logmel_bench.py 64 80 > $OUT/logmel_80.log 2>&1 || exit 1
 python3 $ROOT/tools/logmel_bench.py 64 128 > $OUT/logmel_128.log 2>&1 || exit 1
-echo "== absorbed-projection cross-attention (opt-in) for comparison: 64 and 224 new tokens, with the default beside it"
-$B --cross-attention absorbed > $OUT/bench_absorbed.json 2> /dev/null || exit 1
-$B --cross-attention absorbed --new-tokens 224 --steps 6 > $OUT/bench_absorbed_n224.json 2> /dev/null || exit 1
+echo "== cached K / V cross-attention (opt-in) for comparison: 64 and 224 new tokens, with the default beside it"
+$B --cross-attention cached > $OUT/bench_cached.json 2> /dev/null || exit 1
+$B --cross-attention cached --new-tokens 224 --steps 6 > $OUT/bench_cached_n224.json 2> /dev/null || exit 1
 $B --new-tokens 224 --steps 6 > $OUT/size_small_n224.json 2> /dev/null || exit 1
+echo "== cached vs absorbed over output lengths and batch sizes"
+bash $ROOT/tools/r03_cross_sweep.sh || exit 1
 echo "== done a"; cat $OUT/bench_default.json
 else
 echo "== fine-tune step"
 python3 $ROOT/bench.py --mode train --steps 5 --warmup 1 > $OUT/train_exact.json 2> $OUT/train_exact.err || exit 1
 python3 $ROOT/bench.py --mode train --steps 5 --warmup 1 --f32 split > $OUT/train_split.json 2> $OUT/train_split.err || exit 1
 echo "== medium B=256";          $B --model medium --batch 256 --pipeline 2 --steps 4 > $OUT/size_medium_b256.json 2> /dev/null || exit 1
-echo "== medium B=256 absorbed"; $B --model medium --batch 256 --pipeline 2 --steps 4 --cross-attention absorbed > $OUT/size_medium_b256_absorbed.json 2> /dev/null || exit 1
+echo "== medium B=256 cached";   $B --model medium --batch 256 --pipeline 2 --steps 4 --cross-attention cached > $OUT/size_medium_b256_cached.json 2> /dev/null || exit 1
 echo "== large-v3 B=128 bf16";   $B --model large-v3 --batch 128 --pipeline 2 --steps 4 > $OUT/size_large_b128_bf16.json 2> /dev/null || exit 1
 echo "== large-v3 B=128 fp8 w";  $B --model large-v3 --batch 128 --pipeline 2 --steps 4 --weights fp8 > $OUT/size_large_b128_fp8.json 2> /dev/null || exit 1
 echo "== large-v3 B=128 fp8 w+a"; $B --model large-v3 --batch 128 --pipeline 2 --steps 4 --weights fp8 --activations fp8 > $OUT/size_large_b128_fp8_act.json 2> /dev/null || exit 1

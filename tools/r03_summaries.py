@@ -194,7 +194,28 @@ if have("kt_lm"):
     json.dump(out, open(os.path.join(DST, "r03_logmel.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
-for n in ("bench_default.json", "bench_absorbed.json", "bench_absorbed_n224.json", "size_medium_b256_absorbed.json", "train_exact.json", "train_split.json", "size_small_n224.json", "size_medium_b256.json",
+# ---- cached K / V vs absorbed projections: one table
+rows = []
+cases = [("whisper-small, 64 clips, 32 new tokens", "sw_{m}_s64_n32.json"), ("whisper-small, 64 clips, 64 new tokens (headline)", None),
+         ("whisper-small, 64 clips, 128 new tokens", "sw_{m}_s64_n128.json"), ("whisper-small, 64 clips, 224 new tokens", None),
+         ("whisper-small, 128 clips, 64 new tokens", "sw_{m}_s128_n64.json"), ("whisper-small, 128 clips, 224 new tokens", "sw_{m}_s128_n224.json"),
+         ("whisper-medium, 256 clips, 64 new tokens, 2 passes in flight", None), ("whisper-medium, 256 clips, 224 new tokens, 2 passes in flight", "sw_{m}_m256_n224.json")]
+special = {1: ("bench_cached.json", "bench_default.json"), 3: ("bench_cached_n224.json", "size_small_n224.json"),
+           6: ("size_medium_b256_cached.json", "size_medium_b256.json")}
+for i, (label, pat) in enumerate(cases):
+    files = special[i] if pat is None else (pat.format(m="cached"), pat.format(m="absorbed"))
+    if all(have(f) and os.path.getsize(os.path.join(SRC, f)) > 0 for f in files):
+        c, a = (json.loads(open(os.path.join(SRC, f)).read().strip().splitlines()[-1]) for f in files)
+        rows.append((label, c["ms_per_step"], c["value"], a["ms_per_step"], a["value"]))
+if rows:
+    with open(os.path.join(DST, "r03_cached_vs_absorbed.txt"), "w") as f:
+        f.write("# bench.py --no-cpu-baseline --no-finetune --cross-attention {cached,absorbed} [...]   (MI355X, round 3; tools/r03_gpu_profile.sh, tools/r03_cross_sweep.sh)\n")
+        f.write(f"# {'workload':66s} {'cached ms':>10s} {'audio-s/s':>10s} {'absorbed ms':>12s} {'audio-s/s':>10s} {'absorbed vs cached':>19s}\n")
+        for label, cm, cv, am, av in rows:
+            f.write(f"  {label:66s} {cm:10.2f} {cv:10.0f} {am:12.2f} {av:10.0f} {100 * (av / cv - 1):+18.1f}%\n")
+    print(open(os.path.join(DST, "r03_cached_vs_absorbed.txt")).read())
+
+for n in ("bench_default.json", "bench_cached.json", "bench_cached_n224.json", "size_medium_b256_cached.json", "train_exact.json", "train_split.json", "size_small_n224.json", "size_medium_b256.json",
           "size_large_b128_bf16.json", "size_large_b128_fp8.json", "size_large_b128_fp8_act.json", "size_small_fp8.json", "size_small_p1.json"):
     if have(n) and os.path.getsize(os.path.join(SRC, n)) > 0:
         shutil.copy(os.path.join(SRC, n), os.path.join(DST, "r03_" + n))

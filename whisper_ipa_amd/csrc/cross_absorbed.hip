@@ -723,7 +723,7 @@ struct AbsPrologueParams {
     float eps, q_scale, k_scale;
 };
 
-template <int D>
+template <int D, int CG>  // CG clips per workgroup: 16 (every MFMA row a clip) or 8 (twice the workgroups, half the rows each)
 __global__ __launch_bounds__(512) void cross_absorb_prologue_kernel(AbsPrologueParams p) {
     constexpr int KS = D / 32;          // k-steps of the query projection
     constexpr int KSW = (KS + 7) / 8;   // per wave
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(512) void cross_absorb_prologue_kernel(AbsPrologueP
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
-    const int h = blockIdx.x, b0 = blockIdx.y * 16;
+    const int h = blockIdx.x, b0 = blockIdx.y * CG;
     // ---- weight fragments first: Wq rows h*64 + 16 nt + l15 at this wave's k-steps; WkT rows (channels) of this wave's column tiles
     bf16x8 wqf[4][KSW];
 #pragma unroll
@@ -759,8 +759,8 @@ __global__ __launch_bounds__(512) void cross_absorb_prologue_kernel(AbsPrologueP
     // ---- 1. slab sum + LayerNorm of rows 2 wave, 2 wave + 1 (one wave per row: 4 consecutive floats per lane and 256-column block)
     constexpr int NV = (D + 255) / 256;
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-        const int row = 2 * wave + rr;
+    for (int rr = 0; rr < CG / 8; ++rr) {
+        const int row = (CG / 8) * wave + rr;
         const int b = min(b0 + row, p.B - 1);
         f32x4 v[NV], ww[NV], bb[NV];
         float sum = 0.f;
@@ -806,7 +806,7 @@ __global__ __launch_bounds__(512) void cross_absorb_prologue_kernel(AbsPrologueP
         }
     }
     if (h == 0) {  // padded heads of Qp: zero (the streaming kernel multiplies all 16 rows of the head dimension)
-        for (int e = tid; e < 16 * (16 - p.H) * (D / 8); e += 512) {
+        for (int e = tid; e < CG * (16 - p.H) * (D / 8); e += 512) {
             const int row = e / ((16 - p.H) * (D / 8)), rem = e - row * ((16 - p.H) * (D / 8));
             const int hp = p.H + rem / (D / 8), c8 = rem % (D / 8);
             if (b0 + row < p.B) *reinterpret_cast<bf16x8*>(p.qp + ((int64_t)(b0 + row) * 16 + hp) * D + 8 * c8) = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -832,12 +832,15 @@ __global__ __launch_bounds__(512) void cross_absorb_prologue_kernel(AbsPrologueP
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < CG / 8; ++i) {
         const int e = tid + 512 * i, row = e >> 6, j = e & 63;
         float q = 0.f;
 #pragma unroll
         for (int w = 0; w < 8; ++w) q += red[w][row][j];  // fixed order
         qh[row][j] = (__bf16)((q + p.bq[h * 64 + j]) * p.q_scale);
+    }
+    if constexpr (CG < 16) {  // the unused MFMA rows: defined values (their products are dropped)
+        for (int e = tid; e < (16 - CG) * 64; e += 512) qh[CG + (e >> 6)][e & 63] = (__bf16)0.f;
     }
     __syncthreads();
     // ---- 3. absorbed query: this wave's column tiles
@@ -854,7 +857,7 @@ __global__ __launch_bounds__(512) void cross_absorb_prologue_kernel(AbsPrologueP
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int bb_ = b0 + 4 * g + r;
-                    if (bb_ < p.B) p.qp[((int64_t)bb_ * 16 + h) * D + 16 * nt + l15] = (__bf16)(acc[r] * p.k_scale);
+                    if (4 * g + r < CG && bb_ < p.B) p.qp[((int64_t)bb_ * 16 + h) * D + 16 * nt + l15] = (__bf16)(acc[r] * p.k_scale);
                 }
             }
         }
@@ -1039,11 +1042,13 @@ extern "C" int wipa_decode_cross_absorbed_block(const wipa_cross_block_desc* c, 
     p.Tk = Tk; p.n_splits = S; p.H = H;
     const int tiles = (Tk + FT - 1) / FT;
     p.tiles_per_split = (tiles + S - 1) / S;
-    const dim3 gp(H, (B + 15) / 16), gm(H, (B + 3) / 4);
+    static const int cg = [] { const char* e = getenv("WIPA_ABS_PROLOGUE_CLIPS"); return e ? atoi(e) : 16; }();  // A/B: 8 or 16
+    const dim3 gp(H, cg == 8 ? (B + 7) / 8 : (B + 15) / 16), gm(H, (B + 3) / 4);
     int rc = WIPA_OK;
 #define ABS_BLOCK(D)                                                                                                                       \
     do {                                                                                                                                   \
-        hipLaunchKernelGGL((cross_absorb_prologue_kernel<D>), gp, dim3(512), 0, s, q);                                                     \
+        if (cg == 8) hipLaunchKernelGGL((cross_absorb_prologue_kernel<D, 8>), gp, dim3(512), 0, s, q);                                     \
+        else hipLaunchKernelGGL((cross_absorb_prologue_kernel<D, 16>), gp, dim3(512), 0, s, q);                                            \
         rc = launch_attn<D>(p, B, s);                                                                                                      \
         if (rc == WIPA_OK)                                                                                                                 \
             hipLaunchKernelGGL((cross_merge_proj_kernel<D>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o, S,             \
