@@ -594,13 +594,21 @@ __global__ __launch_bounds__(64) void cross_absorb_q_kernel(const __bf16* __rest
 // fragments need (4 splits x 2 float4 per k-step, rounded through bf16, the activation dtype), the weight fragments come straight
 // from L2, and the slice sums meet in LDS in a fixed order.  Measured alternatives at 64 clips: one workgroup per (head, clip)
 // reading the head's 98 KB of weights each -- 75 MB of L2 reads, 8.7 us; one per (head, 16 clips) -- 48 workgroups pull the
-// 9.4 MB of partials through 48 CUs, 11.7 us.
+// 9.4 MB of partials through 48 CUs, 11.7 us.  Compile-time variants of this form (-DWIPA_MERGE_KQ / -DWIPA_MERGE_CL): 192 channels
+// per wave 10.9 us, 2 clips per workgroup 13.8, 8 clips 10.8, 8 clips x 192 channels 11.5 -- all within a microsecond of the 10.4 us
+// of (96, 4): the kernel sits on its chain of dependent round trips (weights and partials in, LDS reduction, out), not on its shape.
 template <int D>
 struct MergeCfg {
-    static constexpr int KQ = (D % 96 == 0) ? 96 : (D == 512 ? 64 : 128);  // channels per wave
+#ifndef WIPA_MERGE_KQ
+#define WIPA_MERGE_KQ 96
+#endif
+#ifndef WIPA_MERGE_CL
+#define WIPA_MERGE_CL 4
+#endif
+    static constexpr int KQ = (D % 96 == 0) ? WIPA_MERGE_KQ : (D == 512 ? 64 : 128);  // channels per wave
     static constexpr int NWM = D / KQ;                                       // waves: 4 (d = 384), 8 (512, 768, 1024)
     static constexpr int KS = KQ / 32;
-    static constexpr int CL = 4;  // clips per workgroup
+    static constexpr int CL = WIPA_MERGE_CL;  // clips per workgroup (1, 2, 4, 8 or 16)
 };
 
 template <int D>
@@ -682,12 +690,12 @@ __global__ __launch_bounds__(64 * MergeCfg<D>::NWM) void cross_merge_proj_kernel
         for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wq[nt][ks], acc[nt], 0, 0, 0);
     }
     // acc[nt][r] = this wave's share of the sum for tile row 4g + r (clip b0 + r in lane group 0), output 16 nt + l15
-    static_assert(CL == 4, "rows 0..3 of the tile are lane group 0");
-    if (g == 0) {
+    if (4 * g < CL) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[w][r][16 * nt + l15] = acc[nt][r];
+            for (int r = 0; r < 4; ++r)
+                if (4 * g + r < CL) red[w][4 * g + r][16 * nt + l15] = acc[nt][r];
     }
     __syncthreads();
     for (int e = tid; e < CL * 64; e += 64 * NWM) {
@@ -987,7 +995,7 @@ extern "C" int wipa_cross_absorbed_attention(const void* q, int64_t q_row_stride
     p.Tk = Tk; p.n_splits = S; p.H = H;
     const int tiles = (Tk + FT - 1) / FT;
     p.tiles_per_split = (tiles + S - 1) / S;
-    const dim3 gq(16, (B + 15) / 16, 4), gm(H, (B + 3) / 4);
+    const dim3 gq(16, (B + 15) / 16, 4), gm(H, (B + WIPA_MERGE_CL - 1) / WIPA_MERGE_CL);
     int rc = WIPA_OK;
     const char* st_env = getenv("WIPA_ABS_STAGES");  // debugging: bit 0 absorb-q, bit 1 stream, bit 2 merge (default all)
     const int stages = st_env ? atoi(st_env) : 7;
@@ -1043,7 +1051,7 @@ extern "C" int wipa_decode_cross_absorbed_block(const wipa_cross_block_desc* c, 
     const int tiles = (Tk + FT - 1) / FT;
     p.tiles_per_split = (tiles + S - 1) / S;
     static const int cg = [] { const char* e = getenv("WIPA_ABS_PROLOGUE_CLIPS"); return e ? atoi(e) : 16; }();  // A/B: 8 or 16
-    const dim3 gp(H, cg == 8 ? (B + 7) / 8 : (B + 15) / 16), gm(H, (B + 3) / 4);
+    const dim3 gp(H, cg == 8 ? (B + 7) / 8 : (B + 15) / 16), gm(H, (B + WIPA_MERGE_CL - 1) / WIPA_MERGE_CL);
     int rc = WIPA_OK;
 #define ABS_BLOCK(D)                                                                                                                       \
     do {                                                                                                                                   \
