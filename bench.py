@@ -959,8 +959,8 @@ def main():
                     help="fp8: BASELINE.json configs[4] sizing runs (e4m3 weights with per-row scales, bf16 activations); the "
                          "benchmark metric is quoted on bf16 weights")
     ap.add_argument("--cross-attention", default="auto", choices=["auto", "cached", "absorbed"],
-                    help="decode-step cross-attention: projected K / V caches (the default) or the encoder output with absorbed "
-                         "projections (Whisper(cross_attention=...); absorbed: bf16, <= 16 heads)")
+                    help="decode-step cross-attention: the encoder output with absorbed key / value projections (what auto picks for "
+                         "bf16 models of <= 16 heads) or mlx_whisper's projected K / V caches (Whisper(cross_attention=...))")
     ap.add_argument("--activations", default="bf16", choices=["bf16", "fp8"],
                     help="with --weights fp8: fp8 also runs the encoder's q|k, value, mlp1, mlp2 projections fp8 x fp8 on the "
                          "block-scaled fp8 MFMA (LayerNorm / GELU outputs quantised per row) -- configs[4] '(CDNA4 fp8 MFMA)'")
