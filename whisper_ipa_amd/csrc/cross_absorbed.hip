@@ -309,7 +309,7 @@ __global__ __launch_bounds__(64 * NW_, 1) void cross_absorbed_v2_kernel(AbsParam
     constexpr int NDMA = SLOT / 1024;  // LDS-DMA transfers per group (24 for d = 768)
     constexpr int KS = D / 32;         // k-steps of the score product
     constexpr int CT = D / 16;         // column tiles of O'
-    static_assert(SLOT % 1024 == 0 && NDMA <= 32 && CT % 8 == 0 && KS % 4 == 0 && CT / 8 <= 6 && D % 128 == 0, "width");
+    static_assert(SLOT % 1024 == 0 && NDMA <= 32 && CT % 8 == 0 && KS % 4 == 0 && CT / 8 <= 8 && D % 128 == 0, "width");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -389,7 +389,8 @@ __global__ __launch_bounds__(64 * NW_, 1) void cross_absorbed_v2_kernel(AbsParam
     }
     auto wait_slot = [&](bool more_in_flight) {
         if (more_in_flight) {
-            if constexpr (NDMA == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            if constexpr (NDMA == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else if constexpr (NDMA == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
             else if constexpr (NDMA == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else if constexpr (NDMA == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -475,6 +476,8 @@ __global__ __launch_bounds__(64 * NW_, 1) void cross_absorbed_v2_kernel(AbsParam
                 WIPA_PV_BLK(3, 768)
                 WIPA_PV_BLK(4, 1024)
                 WIPA_PV_BLK(5, 1280)
+                WIPA_PV_BLK(6, 1536)
+                WIPA_PV_BLK(7, 1792)
 #undef WIPA_PV_BLK
             }
             // every read of this slot has completed (score fragments are spent, the transposed reads were waited for): re-stage
@@ -877,9 +880,14 @@ template <int D>
 int launch_attn(const AbsParams& p_in, int B, hipStream_t s) {
     const char* e = getenv("WIPA_ABS_KERNEL");
     const AbsParams& p = p_in;
-    if ((e && atoi(e) == 1) || D > 768)  // d = 1024: 64 column tiles are all 256 accumulation registers -- the channel-split form
+    // d = 1024: 64 column tiles are all 256 accumulation registers and a 16-frame group is 32 KiB, so the independent-wave form fits
+    // with TWO waves only -- measured slower than the channel-split form there (whisper-medium, 256 clips: 191.5 vs 171.7 us per
+    // launch, 845 vs 821 ms per pass); WIPA_ABS_KERNEL=2 selects it for A/B runs
+    if ((e && atoi(e) == 1) || (D > 768 && !(e && atoi(e) == 2)))
         hipLaunchKernelGGL((cross_absorbed_kernel<D>), dim3(p.n_splits, B), dim3(64 * AbsCfg<D>::NW), AbsCfg<D>::SMEM, s, p);
-    else if constexpr (D <= 768) {
+    else if constexpr (D > 768)
+        hipLaunchKernelGGL((cross_absorbed_v2_kernel<D, 2>), dim3(p.n_splits, B), dim3(128), (AbsCfg2<D, 2>::SMEM), s, p);
+    else {
         static const int waves = [] { const char* w = getenv("WIPA_ABS_WAVES"); return w ? atoi(w) : 3; }();  // A/B: 2 leaves 64 KiB of LDS and two SIMDs to other kernels
         if (waves == 2) hipLaunchKernelGGL((cross_absorbed_v2_kernel<D, 2>), dim3(p.n_splits, B), dim3(128), (AbsCfg2<D, 2>::SMEM), s, p);
         else hipLaunchKernelGGL((cross_absorbed_v2_kernel<D, 3>), dim3(p.n_splits, B), dim3(192), (AbsCfg2<D, 3>::SMEM), s, p);
@@ -916,13 +924,11 @@ extern "C" int wipa_cross_absorbed_init(int d) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_absorbed_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize,      \
                                 AbsCfg<D>::SMEM);                                                                                          \
         if (e == hipSuccess && D <= 768)                                                                                                   \
-        {                                                                                                                                  \
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_absorbed_v2_kernel<(D <= 768 ? D : 768), 3>),                     \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, AbsCfg2<(D <= 768 ? D : 768), 3>::SMEM);                   \
-            if (e == hipSuccess)                                                                                                           \
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_absorbed_v2_kernel<(D <= 768 ? D : 768), 2>),                 \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, AbsCfg2<(D <= 768 ? D : 768), 2>::SMEM);               \
-        }                                                                                                                                  \
+        if (e == hipSuccess)                                                                                                               \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_absorbed_v2_kernel<D, 2>),                                        \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, AbsCfg2<D, 2>::SMEM);                                      \
     }
     if (d == 384) ABS_ATTR(384)
     else if (d == 512) ABS_ATTR(512)
