@@ -18,6 +18,8 @@
 #include <cstring>
 #include <mutex>
 
+#include <type_traits>
+
 #include "wipa_common.h"
 
 namespace {
@@ -604,6 +606,56 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p) {
     }
 }
 
+// Wide skinny GEMM (the logits projection: M <= 64 rows, N = 51 865 columns, K <= 1024), persistent form.  gemm_skinny_kernel
+// gives every 64-column workgroup its own copy of the activation matrix from L2 -- 811 workgroups x 98 KB = as many bytes as the
+// weights themselves, through the same per-CU load path.  Here one workgroup per CU stages the activations ONCE into LDS
+// ([64][K + 8] bf16) and its eight waves then walk 16-column tiles of the weight matrix on their own (tile = wave index + k x
+// number of waves): a tile is 16 rows x K, all of its 16-byte loads in flight together, multiplied against the four 16-row
+// activation tiles read from LDS; no reduction between waves.  bf16 in, any epilogue of the skinny kernel.
+template <typename OutT, int KS>
+__global__ __launch_bounds__(512) void gemm_wide_persistent_kernel(GemmParams p) {
+    typedef Mma<__bf16>::Frag Frag;
+    constexpr int K = KS * 32, LROW = K + 8;
+    extern __shared__ __attribute__((aligned(16))) char smem_wide[];
+    __bf16* sa = reinterpret_cast<__bf16*>(smem_wide);  // [64][LROW]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fq = lane >> 4;
+    // activations -> LDS (rows past M repeat the last row; their results are dropped by the epilogue's row test)
+    for (int c = tid; c < 64 * (K / 8); c += 512) {
+        const int row = c / (K / 8), ch = c - row * (K / 8);
+        const Frag v = *reinterpret_cast<const Frag*>(p.A + (int64_t)min(row, p.M - 1) * p.lda_b + ch * 16);
+        *reinterpret_cast<Frag*>(sa + row * LROW + ch * 8) = v;
+    }
+    const bool vec = p.vec_ok != 0;
+    int64_t coff_dev = p.c_offset;
+    if (p.c_offset_dev) coff_dev += *p.c_offset_dev;
+    __syncthreads();
+    const int n_tiles = (p.N + 15) / 16;
+    const int stride = gridDim.x * 8;
+    for (int tile = blockIdx.x * 8 + wave; tile < n_tiles; tile += stride) {
+        const int n0 = tile * 16;
+        const char* wp = p.W + (int64_t)min(n0 + frow, p.N - 1) * p.ldw_b + fq * 16;
+        Frag fw[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) fw[ks] = *reinterpret_cast<const Frag*>(wp + ks * 64);
+        const EpiCol cc = epi_col(p, n0 + 4 * fq);
+        f32x4 acc[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            Frag fx[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fx[j] = *reinterpret_cast<const Frag*>(sa + (16 * j + frow) * LROW + 32 * ks + 8 * fq);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Mma<__bf16>::run(fw[ks], fx[j], acc[j]);
+            // keep the LDS reads of the later k-steps where they are: hoisted over the whole unrolled loop they need 384 registers
+            if ((ks & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) epilogue4<OutT>(p, acc[j], epi_row(p, 16 * j + frow, coff_dev), cc, vec);
+    }
+}
+
 // Skinny GEMM with fp8 (OCP e4m3fn) weights and bf16 activations: the decode step streams every decoder matrix once per
 // step, so halving the weight bytes halves that stream.  W [N, K] one byte per element, dequantised as code * w_scale[n]:
 // the codes are widened to bf16 in registers (exact: e4m3 has 3 mantissa bits) and fed to the bf16 MFMA; the per-column
@@ -885,10 +937,34 @@ int launch_skinny_cfg(const GemmParams& p, hipStream_t s) {
     return WIPA_OK;
 }
 
+template <typename OutT, int KS>
+int launch_wide_persistent_ks(const GemmParams& p, hipStream_t s) {
+    const size_t lds = (size_t)64 * (KS * 32 + 8) * 2;
+    hipLaunchKernelGGL((gemm_wide_persistent_kernel<OutT, KS>), dim3(256), dim3(512), lds, s, p);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+template <typename OutT>
+int launch_wide_persistent(const GemmParams& p, hipStream_t s) {
+    switch (p.K) {
+        case 384: return launch_wide_persistent_ks<OutT, 12>(p, s);
+        case 512: return launch_wide_persistent_ks<OutT, 16>(p, s);
+        case 768: return launch_wide_persistent_ks<OutT, 24>(p, s);
+        default: return launch_wide_persistent_ks<OutT, 32>(p, s);
+    }
+}
+
 template <typename T, typename OutT, int MT>
 int launch_skinny_mt(const GemmParams& p, hipStream_t s) {
     const int ksteps = p.K * (int)sizeof(T) / 64 / p.k_slices;
     static const int wide_nt = [] { const char* e = getenv("WIPA_SKINNY_WIDE_NT"); return e ? atoi(e) : 4; }();  // A/B timing
+    if constexpr (std::is_same<T, __bf16>::value && MT == 4) {
+        // the persistent form for wide outputs (logits): WIPA_WIDE_PERSISTENT=0 keeps the 64-column workgroups for A/B runs
+        static const bool persistent = [] { const char* e = getenv("WIPA_WIDE_PERSISTENT"); return !(e && atoi(e) == 0); }();
+        if (persistent && p.N >= 8192 && p.k_slices == 1 && p.M <= 64 && !p.ln_x && !p.w_scale && !p.a_scale &&
+            (p.K == 384 || p.K == 512 || p.K == 768 || p.K == 1024) && p.lda_b % 16 == 0 && p.ldw_b % 16 == 0)
+            return launch_wide_persistent<OutT>(p, s);
+    }
     if (p.N >= 8192 && MT == 4 && wide_nt == 4) return launch_skinny_cfg<T, OutT, MT, 4, 4>(p, s);  // logits: 64 columns per workgroup
     if (p.N >= 8192 && wide_nt == 1) return launch_skinny_cfg<T, OutT, MT, 1, 4>(p, s);
     if (p.N >= 8192) return launch_skinny_cfg<T, OutT, MT, 2, 4>(p, s);
@@ -1692,6 +1768,18 @@ int init_attrs() {
                               reinterpret_cast<const void*>(&gemm_skinny_ln_kernel<float, float, 4>)};
         for (const void* f : lnk) {
             const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            if (e != hipSuccess) err = e;
+        }
+        const void* widek[] = {reinterpret_cast<const void*>(&gemm_wide_persistent_kernel<float, 12>),
+                               reinterpret_cast<const void*>(&gemm_wide_persistent_kernel<float, 16>),
+                               reinterpret_cast<const void*>(&gemm_wide_persistent_kernel<float, 24>),
+                               reinterpret_cast<const void*>(&gemm_wide_persistent_kernel<float, 32>),
+                               reinterpret_cast<const void*>(&gemm_wide_persistent_kernel<__bf16, 12>),
+                               reinterpret_cast<const void*>(&gemm_wide_persistent_kernel<__bf16, 16>),
+                               reinterpret_cast<const void*>(&gemm_wide_persistent_kernel<__bf16, 24>),
+                               reinterpret_cast<const void*>(&gemm_wide_persistent_kernel<__bf16, 32>)};
+        for (const void* f : widek) {
+            const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (1024 + 8) * 2);
             if (e != hipSuccess) err = e;
         }
     });
