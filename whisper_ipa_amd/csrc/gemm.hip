@@ -976,6 +976,16 @@ template <typename T, typename OutT>
 int launch_skinny(const GemmParams& p, hipStream_t s) {
     if (p.M <= 16) return launch_skinny_mt<T, OutT, 1>(p, s);
     if (p.M <= 32) return launch_skinny_mt<T, OutT, 2>(p, s);
+    // Narrow outputs (the decode-step projections, N < 8192): 32-row workgroups -- twice the workgroups of the 64-row form, each
+    // fetching half of the activation matrix, which is 4/5 of a 64-row workgroup's bytes (98 KB against 24 KB of weights) and what
+    // its single CU spends its time pulling: whisper-small, 64 rows: decode step 1.332 -> 1.311 ms, 78.1 -> 75.8 ms per pass with four
+    // passes in flight; 16-row workgroups 77.3 ms.  Results are bit-identical (the same fragments in the same order).
+    // WIPA_SKINNY_ROWS=64 | 16 for A/B runs.  The wide logits projection keeps 64 rows.
+    static const int rows = [] { const char* e = getenv("WIPA_SKINNY_ROWS"); return e ? atoi(e) : 32; }();
+    // Up to 128 rows only: every row group streams the weight slice again, and at 256 rows (whisper-medium, batch 256) eight
+    // 32-row groups measured slower than four 64-row ones (decode step 8.66 vs 8.41 ms); 128 rows: 2.02 vs 2.06 ms.
+    if (rows == 32 && p.N < 8192 && p.M <= 128) return launch_skinny_mt<T, OutT, 2>(p, s);
+    if (rows == 16 && p.N < 8192 && p.M <= 128) return launch_skinny_mt<T, OutT, 1>(p, s);
     return launch_skinny_mt<T, OutT, 4>(p, s);
 }
 
