@@ -984,6 +984,8 @@ int launch_skinny(const GemmParams& p, hipStream_t s) {
     static const int rows = [] { const char* e = getenv("WIPA_SKINNY_ROWS"); return e ? atoi(e) : 32; }();
     // Up to 128 rows only: every row group streams the weight slice again, and at 256 rows (whisper-medium, batch 256) eight
     // 32-row groups measured slower than four 64-row ones (decode step 8.66 vs 8.41 ms); 128 rows: 2.02 vs 2.06 ms.
+    // (restricting the rule to launches that stay within one round of workgroups measured worse: 77.1 / 76.4 ms with caps of
+    // 200 / 300 workgroups against 75.4 without)
     if (rows == 32 && p.N < 8192 && p.M <= 128) return launch_skinny_mt<T, OutT, 2>(p, s);
     if (rows == 16 && p.N < 8192 && p.M <= 128) return launch_skinny_mt<T, OutT, 1>(p, s);
     return launch_skinny_mt<T, OutT, 4>(p, s);
