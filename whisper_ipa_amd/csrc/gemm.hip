@@ -795,6 +795,9 @@ template <typename OutT>
 int launch_skinny_w8(const GemmParams& p, hipStream_t s) {
     if (p.M <= 16) return launch_skinny_w8_mt<OutT, 1>(p, s);
     if (p.M <= 32) return launch_skinny_w8_mt<OutT, 2>(p, s);
+    // 32-row workgroups for the narrow projections, as in launch_skinny (WIPA_SKINNY_W8_ROWS=32 | 64; see there)
+    static const int rows = [] { const char* e = getenv("WIPA_SKINNY_W8_ROWS"); return e ? atoi(e) : 64; }();
+    if (rows == 32 && p.N < 8192 && p.M <= 128) return launch_skinny_w8_mt<OutT, 2>(p, s);
     return launch_skinny_w8_mt<OutT, 4>(p, s);
 }
 
