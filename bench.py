@@ -503,7 +503,7 @@ def roofline_mfma(model, audio, pmc_file: str = "r03_pmc_encoder_gemm.json"):
             try:
                 mel = A.log_mel_padded(audio, d.n_mels, model.dtype)
                 feats = model.encode_padded(mel, B)
-                _lib.check(L.wipa_decoder_set_audio(C.byref(pk["cfg"]), pk["dec_tab"], ptr(feats), ptr(st.blob), B, sptr(s)),
+                _lib.check(L.wipa_decoder_set_audio(C.byref(pk["cfg"]), pk["dec_tab"], ptr(feats), ptr(st.blob), st.blob.numel(), B, sptr(s)),
                            "wipa_decoder_set_audio")
             finally:
                 _lib.check(L.wipa_profile_end(ms, cnt), "wipa_profile_end")
@@ -552,7 +552,7 @@ def decode_step_roofline(model, B: int, n_steps: int = 48):
         st = _state_for(model, B)  # holds the caches of the last pass on library stream 0
         p0 = int(st.pos.cpu())
         n_steps = max(1, min(n_steps, d.n_text_ctx - 2 - p0))
-        args = (C.byref(pk["cfg"]), pk["dec_tab"], ptr(st.blob), B, len(init), eot, ptr(m_first), ptr(m_always))
+        args = (C.byref(pk["cfg"]), pk["dec_tab"], ptr(st.blob), st.blob.numel(), B, len(init), eot, ptr(m_first), ptr(m_always))
         _lib.check(L.wipa_decoder_run(*args, 2, 1, sptr(s)), "wipa_decoder_run")
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record(s)

@@ -434,24 +434,27 @@ typedef struct wipa_dec_layout {
     int64_t scratch;
 } wipa_dec_layout;
 int wipa_decoder_layout(const wipa_model_cfg* cfg, int B, wipa_dec_layout* out);
+/* Every entry point that writes into the blob takes `state_bytes`, the size of the caller's allocation, and refuses
+ * (WIPA_ERR_ARG) a blob smaller than wipa_decoder_layout(cfg, B).total_bytes: the layout depends on cfg (dtype,
+ * dec_cross_absorbed, dec_w_dtype ...), so a blob sized for one configuration must not be reused for another. */
 /* cross K/V projection of the encoder output (MultiHeadAttention with xa, computed once). */
 int wipa_decoder_set_audio(const wipa_model_cfg* cfg, const void* const* weights, const void* features, void* state,
-                           int B, wipa_stream_t s);
+                           size_t state_bytes, int B, wipa_stream_t s);
 /* write the prompt (host int32 [n_init]) to every row, pos = 0, clear counters. */
-int wipa_decoder_begin(const wipa_model_cfg* cfg, void* state, int B, const int32_t* initial_tokens_host, int n_init,
-                       wipa_stream_t s);
+int wipa_decoder_begin(const wipa_model_cfg* cfg, void* state, size_t state_bytes, int B, const int32_t* initial_tokens_host,
+                       int n_init, wipa_stream_t s);
 /* n_steps decoder steps (each: one token position through all layers + greedy update).
  * The prompt is consumed one position per step.  use_graph != 0 captures one step into a
  * hipGraph and replays it. */
-int wipa_decoder_run(const wipa_model_cfg* cfg, const void* const* weights, void* state, int B, int n_init, int eot,
-                     const float* mask_first, const float* mask_always, int n_steps, int use_graph,
+int wipa_decoder_run(const wipa_model_cfg* cfg, const void* const* weights, void* state, size_t state_bytes, int B, int n_init,
+                     int eot, const float* mask_first, const float* mask_always, int n_steps, int use_graph,
                      wipa_stream_t s);
 /* The first n_init steps (the prompt positions 0..n_init-1 and the first generated token) as ONE batched pass: same
  * resulting state as wipa_decoder_run(..., n_steps = n_init, ...) right after wipa_decoder_begin, but the cached cross K/V
  * are streamed once for all prompt positions and the small per-step kernels run once (mlx_whisper also feeds the whole
  * prompt through the decoder in one forward).  Continue with wipa_decoder_run for the remaining steps. */
-int wipa_decoder_prefill(const wipa_model_cfg* cfg, const void* const* w, void* state, int B, int n_init, int eot,
-                         const float* mask_first, const float* mask_always, int use_graph, wipa_stream_t s);
+int wipa_decoder_prefill(const wipa_model_cfg* cfg, const void* const* w, void* state, size_t state_bytes, int B, int n_init,
+                         int eot, const float* mask_first, const float* mask_always, int use_graph, wipa_stream_t s);
 /* drop the cached step graphs that reference this state blob (call before freeing it). */
 int wipa_decoder_release(void* state);
 

@@ -90,3 +90,27 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in txt.replace("# oracle", ""), f"{f} mentions the oracle"
+
+
+def test_decoder_entry_points_refuse_a_state_blob_smaller_than_the_layout(built):
+    """wipa_decoder_begin / run / prefill / set_audio take the caller's blob size and return an error BEFORE any launch when it
+    is smaller than wipa_decoder_layout(cfg, B).total_bytes -- the layout depends on the configuration (cached vs absorbed
+    cross-attention: 24 x at whisper-small), so a blob must never outlive a change of it.  No GPU is touched on this path."""
+    lib = built.lib()
+    small = dict(n_mels=80, n_audio_ctx=1500, n_audio_state=768, n_audio_head=12, n_audio_layer=12, n_vocab=51865, n_text_ctx=448,
+                 n_text_state=768, n_text_head=12, n_text_layer=12, dtype=built.WIPA_BF16)
+    cached, absorbed = built.ModelCfg(**small, dec_cross_absorbed=0), built.ModelCfg(**small, dec_cross_absorbed=1)
+    lc, la = built.DecLayout(), built.DecLayout()
+    assert lib.wipa_decoder_layout(C.byref(cached), 64, C.byref(lc)) == 0 and lib.wipa_decoder_layout(C.byref(absorbed), 64, C.byref(la)) == 0
+    assert lc.total_bytes > 1.5 * la.total_bytes  # 3.5 GB of K / V against 0.15 GB of features
+    fake = C.c_void_p(0x1000)  # never dereferenced: the size check comes first
+    init = (C.c_int32 * 4)(1, 2, 3, 4)
+    tab = (C.c_void_p * 4)()
+    rc = lib.wipa_decoder_begin(C.byref(cached), fake, la.total_bytes, 64, init, 4, None)
+    assert rc != 0 and b"state blob" in lib.wipa_last_error()
+    rc = lib.wipa_decoder_run(C.byref(cached), tab, fake, la.total_bytes, 64, 4, 50257, fake, fake, 1, 0, None)
+    assert rc != 0 and b"state blob" in lib.wipa_last_error()
+    rc = lib.wipa_decoder_prefill(C.byref(cached), tab, fake, la.total_bytes, 64, 4, 50257, fake, fake, 0, None)
+    assert rc != 0 and b"state blob" in lib.wipa_last_error()
+    rc = lib.wipa_decoder_set_audio(C.byref(cached), tab, fake, fake, la.total_bytes, 64, None)
+    assert rc != 0 and b"state blob" in lib.wipa_last_error()

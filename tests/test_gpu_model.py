@@ -307,6 +307,57 @@ def test_decode_never_reads_unwritten_state(micro, monkeypatch, dtype, mode):
         assert np.isfinite(b[1]).all() and (a[0] == b[0]).all() and np.array_equal(a[1], b[1]), (mode, len(prompt), a[0].tolist(), b[0].tolist())
 
 
+def test_decode_blob_follows_the_layout_after_quantize_and_cross_attention_changes(small2):
+    """the blob layout depends on the configuration.  A bf16 model that has decoded with the absorbed
+    cross-attention owns a blob with ONE copy of the features; quantize_weights() (fp8 tables -> cached K / V) or a switch to
+    cross_attention="cached" needs K and V of every layer.  The state must be re-made (decoding._state_for compares the
+    layouts), the result must equal a FRESH model in the new configuration, and the C ABI must refuse a blob that is too small."""
+    import ctypes as C
+
+    from whisper_ipa_amd import _lib
+    from whisper_ipa_amd.decoding import _state_for, greedy_decode_tokens
+    from whisper_ipa_amd.runtime import on_stream, ptr, sptr
+
+    W, mels, xa = small2
+    sp = R.SpecialTokens.multilingual()
+    always, first = R.suppress_lists(sp)
+    init = list(sp.sot_sequence_including_notimestamps(0))
+    feats = xa.cuda().to(torch.bfloat16)
+
+    def run(m):
+        return greedy_decode_tokens(m, feats, init, always, first, sp.eot, max_new_tokens=8, stop_on_eot=False)
+
+    m = _model(SMALL2, W, torch.bfloat16)
+    assert m.cross_absorbed
+    run(m)
+    small_blob = _state_for(m, 2).blob
+    small_bytes = small_blob.numel()
+    # (a) the same model, now with fp8 tables: cached K / V, a much larger blob
+    m.quantize_weights()
+    assert not m.cross_absorbed
+    got = run(m)
+    assert _state_for(m, 2).blob.numel() > 4 * small_bytes
+    fresh = _model(SMALL2, W, torch.bfloat16)
+    fresh.quantize_weights()
+    want = run(fresh)
+    assert (got.tokens == want.tokens).all() and np.array_equal(got.sum_logprobs, want.sum_logprobs)
+    # (b) absorbed -> cached by attribute on a model that has already decoded
+    m2 = _model(SMALL2, W, torch.bfloat16)
+    a = run(m2)
+    m2.cross_attention = "cached"
+    m2._invalidate()
+    b = run(m2)
+    c = run(_model(SMALL2, W, torch.bfloat16, cross_attention="cached"))
+    assert (b.tokens == c.tokens).all() and np.array_equal(b.sum_logprobs, c.sum_logprobs)
+    assert a.tokens.shape == b.tokens.shape
+    # (c) the ABI itself refuses the old blob under the new configuration (no launch, an error string)
+    L = _lib.lib()
+    pk = m2.packed()
+    with on_stream() as s:
+        rc = L.wipa_decoder_set_audio(C.byref(pk["cfg"]), pk["dec_tab"], ptr(feats), ptr(small_blob), small_bytes, 2, sptr(s))
+    assert rc != 0 and b"state blob" in L.wipa_last_error()
+
+
 def test_no_graph_replay_while_hardware_counters_are_attached(micro, monkeypatch):
     """rocprofv3 --pmc sets ROCPROF_COUNTER_COLLECTION; the runtime then enqueues the decode steps eagerly instead of capturing
     / replaying hipGraphs (runtime.hip counters_attached).  Same ids either way."""

@@ -141,11 +141,11 @@ SIGNATURES = {
     "wipa_encoder_workspace_bytes": (c_size_t, [_P(ModelCfg), c_int]),
     "wipa_encoder_forward": (c_int, [_P(ModelCfg), _P(c_void_p), c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "wipa_decoder_layout": (c_int, [_P(ModelCfg), c_int, _P(DecLayout)]),
-    "wipa_decoder_set_audio": (c_int, [_P(ModelCfg), _P(c_void_p), c_void_p, c_void_p, c_int, c_void_p]),
-    "wipa_decoder_begin": (c_int, [_P(ModelCfg), c_void_p, c_int, _P(C.c_int32), c_int, c_void_p]),
-    "wipa_decoder_run": (c_int, [_P(ModelCfg), _P(c_void_p), c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
+    "wipa_decoder_set_audio": (c_int, [_P(ModelCfg), _P(c_void_p), c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "wipa_decoder_begin": (c_int, [_P(ModelCfg), c_void_p, c_size_t, c_int, _P(C.c_int32), c_int, c_void_p]),
+    "wipa_decoder_run": (c_int, [_P(ModelCfg), _P(c_void_p), c_void_p, c_size_t, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
                                  c_int, c_void_p]),
-    "wipa_decoder_prefill": (c_int, [_P(ModelCfg), _P(c_void_p), c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
+    "wipa_decoder_prefill": (c_int, [_P(ModelCfg), _P(c_void_p), c_void_p, c_size_t, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
                                      c_void_p]),
     "wipa_decode_cross_attn_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "wipa_decoder_release": (c_int, [c_void_p]),

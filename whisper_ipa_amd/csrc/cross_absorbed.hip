@@ -27,6 +27,7 @@
 // Rounding points differ from the cached-K/V path (K and V are never rounded to bf16 here; Qp and O' are): the results
 // are equal up to bf16 noise, and closer to the f32 arithmetic.  bf16 models with <= 16 heads and d in {384, 512, 768, 1024}.
 #include <cstdlib>
+#include <mutex>
 
 #include "wipa_common.h"
 
@@ -915,9 +916,14 @@ extern "C" size_t wipa_cross_absorbed_scratch_bytes(int B, int d, int Tk) {
 }
 
 extern "C" int wipa_cross_absorbed_init(int d) {
-    // raise the dynamic-LDS limit outside any stream capture
-    AbsParams p = {};
-    (void)p;
+    // raise the dynamic-LDS limit outside any stream capture; once per width and process (the driver calls are not free and a
+    // caller may sit inside a capture: after the first call this function issues nothing)
+    static std::mutex mu;
+    static bool done[4] = {false, false, false, false};
+    const int wi = d == 384 ? 0 : d == 512 ? 1 : d == 768 ? 2 : d == 1024 ? 3 : -1;
+    if (wi < 0) return WIPA_ERR_ARG;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done[wi]) return WIPA_OK;
     hipError_t e = hipSuccess;
 #define ABS_ATTR(D)                                                                                                                        \
     {                                                                                                                                      \
@@ -937,6 +943,7 @@ extern "C" int wipa_cross_absorbed_init(int d) {
     else return WIPA_ERR_ARG;
 #undef ABS_ATTR
     WIPA_CHECK_HIP(e);
+    done[wi] = true;
     return WIPA_OK;
 }
 
@@ -982,13 +989,8 @@ extern "C" int wipa_cross_absorbed_attention(const void* q, int64_t q_row_stride
     WIPA_REQUIRE(scratch_bytes >= wipa_cross_absorbed_scratch_bytes(B, d, Tk), "wipa_cross_absorbed_attention: scratch too small");
     hipStream_t s = (hipStream_t)stream;
     {
-        static bool attr_done[4] = {false, false, false, false};
-        const int wi = d == 384 ? 0 : d == 512 ? 1 : d == 768 ? 2 : 3;
-        if (!attr_done[wi]) {
-            const int rc0 = wipa_cross_absorbed_init(d);
-            if (rc0 != WIPA_OK) return rc0;
-            attr_done[wi] = true;
-        }
+        const int rc0 = wipa_cross_absorbed_init(d);  // once per width
+        if (rc0 != WIPA_OK) return rc0;
     }
     const int S = wipa_cross_absorbed_splits(B, Tk);
     char* sc = (char*)scratch;

@@ -709,17 +709,17 @@ int enqueue_prefill(const wipa_model_cfg* cfg, const void* const* w, char* st, c
 }
 
 // Hardware-counter collection (rocprofv3 --pmc sets ROCPROF_COUNTER_COLLECTION) serialises every dispatch and intercepts the
-// queues; a captured step replayed under it hung once in round 1.  No artefact of that run survives (its output directory was
-// reused by the next, successful collection), so whether it stalled in capture or in replay is NOT known -- this guard is a
-// MITIGATION of an unknown root cause, not a fix.  What the code guarantees instead: (i) nothing but
-// kernel launches is issued between hipStreamBeginCapture and hipStreamEndCapture -- every hipFuncSetAttribute of the library
-// sits behind wipa_gemm_init / wipa_decode_fused_init, which the decode entry points call BEFORE they begin a capture (before
-// round 2 the once-only attribute pass ran inside the first wipa_gemm call, i.e. inside the relaxed capture whenever a decode
-// step was the first GEMM of the process, as in a counter micro-target); (ii) while
-// counters are attached the same kernels are enqueued eagerly, which is also what a per-kernel counter run wants; (iii) any
-// other tool that intercepts queues can ask for the eager path with WIPA_DECODE_GRAPH=0.  WIPA_DECODE_GRAPH=force keeps
-// the graphs under counters: the one bounded confirmation run of round 3 (tools/pmc_graph_confirm.py, profiles/r03_graph_replay_under_counters.txt)
-// captured and replayed a step with counters attached and got the eager ids.  Kernel tracing alone keeps the graphs.
+// queues; a captured step replayed under it hung once in round 1 and no artefact of that run survives.  CANDIDATE cause (the only
+// one the code ever offered, not a confirmed one): before round 2 the once-only hipFuncSetAttribute pass ran inside the first
+// wipa_gemm call, i.e. INSIDE the relaxed capture whenever a decode step was the first GEMM of the process -- exactly the shape
+// of a counter micro-target.  Since round 2 every attribute call sits behind wipa_gemm_init / wipa_decode_fused_init /
+// wipa_cross_absorbed_init (each a once-per-process pass), which the decode entry points call BEFORE they begin a capture, so
+// nothing but kernel launches is issued between hipStreamBeginCapture and hipStreamEndCapture; with that change the one bounded
+// confirmation run (WIPA_DECODE_GRAPH=force under --pmc, tools/pmc_graph_confirm.py, profiles/r03_graph_replay_under_counters.txt)
+// captured and replayed a step with counters attached and reproduced the eager ids.  The eager-under-counters DEFAULT stays for a
+// different reason: a per-kernel counter run wants the dispatches separate anyway, and graphs_allowed() prints one line when it
+// takes that path so that PMC numbers are not mistaken for graph-replay numbers.  WIPA_DECODE_GRAPH=0 asks for the eager path
+// explicitly (any other queue-intercepting tool), =force keeps the graphs under counters.  Kernel tracing alone keeps the graphs.
 bool counters_attached() {
     const char* e = getenv("ROCPROF_COUNTER_COLLECTION");
     return e && *e && strcmp(e, "0") != 0 && strcasecmp(e, "false") != 0;
@@ -728,13 +728,31 @@ bool graphs_allowed() {
     const char* g = getenv("WIPA_DECODE_GRAPH");
     if (g && (strcmp(g, "0") == 0 || strcasecmp(g, "off") == 0)) return false;
     if (g && strcasecmp(g, "force") == 0) return true;
-    return !counters_attached();
+    if (counters_attached()) {
+        // say so once: numbers collected under --pmc are those of the EAGER step (same kernels, host-enqueued), not of graph replay
+        static std::once_flag once;
+        std::call_once(once, [] {
+            fprintf(stderr, "libwipa: hardware counters attached (ROCPROF_COUNTER_COLLECTION): decode steps are enqueued eagerly, not "
+                            "replayed from the captured graph (WIPA_DECODE_GRAPH=force keeps the graphs)\n");
+        });
+        return false;
+    }
+    return true;
 }
 // every kernel attribute the step needs, set outside any capture
 int init_before_capture(const wipa_model_cfg* cfg) {
     RT_CALL(wipa_decode_fused_init());
     RT_CALL(wipa_gemm_init());
     if (cfg && cfg->dec_cross_absorbed) RT_CALL(wipa_cross_absorbed_init(cfg->n_text_state));
+    return WIPA_OK;
+}
+
+// The blob layout depends on the configuration (dtype, absorbed / cached cross-attention, fp8 tables): a blob allocated for one
+// cfg and handed in with another would be written far past its end.  Every entry point checks the caller's size.
+int state_fits(const char* who, const wipa_dec_layout& L, size_t state_bytes) {
+    WIPA_REQUIRE((int64_t)state_bytes >= L.total_bytes,
+                 "%s: the state blob holds %zu bytes, this configuration needs %lld (wipa_decoder_layout); re-allocate it after a "
+                 "change of dtype / cross-attention form / weight format", who, state_bytes, (long long)L.total_bytes);
     return WIPA_OK;
 }
 
@@ -785,11 +803,12 @@ extern "C" int wipa_decoder_layout(const wipa_model_cfg* cfg, int B, wipa_dec_la
 }
 
 extern "C" int wipa_decoder_set_audio(const wipa_model_cfg* cfg, const void* const* w, const void* features, void* state,
-                                      int B, wipa_stream_t stream) {
+                                      size_t state_bytes, int B, wipa_stream_t stream) {
     RT_CALL(cfg_check(cfg));
     SplitScope split_scope(cfg);
     WIPA_REQUIRE(w && features && state && B > 0, "wipa_decoder_set_audio: null pointer / bad batch");
     const wipa_dec_layout L = dec_layout(cfg, B);
+    RT_CALL(state_fits("wipa_decoder_set_audio", L, state_bytes));
     const int dt = cfg->dtype;
     const size_t e = wipa_dtype_size(dt);
     const int d = cfg->n_text_state, H = cfg->n_text_head, Ta = cfg->n_audio_ctx;
@@ -812,13 +831,14 @@ extern "C" int wipa_decoder_set_audio(const wipa_model_cfg* cfg, const void* con
     return WIPA_OK;
 }
 
-extern "C" int wipa_decoder_begin(const wipa_model_cfg* cfg, void* state, int B, const int32_t* initial_tokens_host,
-                                  int n_init, wipa_stream_t stream) {
+extern "C" int wipa_decoder_begin(const wipa_model_cfg* cfg, void* state, size_t state_bytes, int B,
+                                  const int32_t* initial_tokens_host, int n_init, wipa_stream_t stream) {
     RT_CALL(cfg_check(cfg));
     SplitScope split_scope(cfg);
     WIPA_REQUIRE(state && initial_tokens_host && n_init >= 1 && n_init <= 4 && B > 0,
                  "wipa_decoder_begin: need 1..4 prompt tokens (got %d)", n_init);
     const wipa_dec_layout L = dec_layout(cfg, B);
+    RT_CALL(state_fits("wipa_decoder_begin", L, state_bytes));
     hipStream_t s = (hipStream_t)stream;
     char* st = (char*)state;
     const DecScratch S = dec_scratch(cfg, B);
@@ -836,14 +856,15 @@ extern "C" int wipa_decoder_begin(const wipa_model_cfg* cfg, void* state, int B,
     return WIPA_OK;
 }
 
-extern "C" int wipa_decoder_run(const wipa_model_cfg* cfg, const void* const* w, void* state, int B, int n_init, int eot,
-                                const float* mask_first, const float* mask_always, int n_steps, int use_graph,
+extern "C" int wipa_decoder_run(const wipa_model_cfg* cfg, const void* const* w, void* state, size_t state_bytes, int B, int n_init,
+                                int eot, const float* mask_first, const float* mask_always, int n_steps, int use_graph,
                                 wipa_stream_t stream) {
     RT_CALL(cfg_check(cfg));
     SplitScope split_scope(cfg);
     WIPA_REQUIRE(w && state && mask_first && mask_always && B > 0 && n_steps >= 0, "wipa_decoder_run: bad arguments");
     W8Scope w8_scope(cfg, w);
     const wipa_dec_layout L = dec_layout(cfg, B);
+    RT_CALL(state_fits("wipa_decoder_run", L, state_bytes));
     char* st = (char*)state;
     hipStream_t s = (hipStream_t)stream;
     RT_CALL(init_before_capture(cfg));
@@ -879,14 +900,16 @@ extern "C" int wipa_decoder_run(const wipa_model_cfg* cfg, const void* const* w,
     return WIPA_OK;
 }
 
-extern "C" int wipa_decoder_prefill(const wipa_model_cfg* cfg, const void* const* w, void* state, int B, int n_init, int eot,
-                                    const float* mask_first, const float* mask_always, int use_graph, wipa_stream_t stream) {
+extern "C" int wipa_decoder_prefill(const wipa_model_cfg* cfg, const void* const* w, void* state, size_t state_bytes, int B,
+                                    int n_init, int eot, const float* mask_first, const float* mask_always, int use_graph,
+                                    wipa_stream_t stream) {
     RT_CALL(cfg_check(cfg));
     SplitScope split_scope(cfg);
     WIPA_REQUIRE(w && state && mask_first && mask_always && B > 0, "wipa_decoder_prefill: bad arguments");
     WIPA_REQUIRE(n_init >= 1 && n_init <= MAX_PROMPT, "wipa_decoder_prefill: 1..%d prompt tokens (got %d)", MAX_PROMPT, n_init);
     W8Scope w8_scope(cfg, w);
     const wipa_dec_layout L = dec_layout(cfg, B);
+    RT_CALL(state_fits("wipa_decoder_prefill", L, state_bytes));
     char* st = (char*)state;
     auto enqueue = [&]() -> int {
         if (n_init == 1) return enqueue_decode_step(cfg, w, st, L, B, n_init, eot, mask_first, mask_always, stream);

@@ -73,6 +73,7 @@ class DecoderState:
         pk = model.packed()
         self.layout = _lib.DecLayout()
         _lib.check(L.wipa_decoder_layout(C.byref(pk["cfg"]), B, C.byref(self.layout)), "wipa_decoder_layout")
+        self.layout_key = tuple(getattr(self.layout, f) for f, _ in self.layout._fields_)
         with on_stream():
             self.blob = torch.empty(self.layout.total_bytes, dtype=torch.uint8, device=model.device)
 
@@ -107,17 +108,27 @@ class DecoderState:
             pass
 
 
+def _layout_of(model, B: int) -> tuple:
+    """the blob layout the model's CURRENT configuration needs, as a comparable tuple"""
+    lay = _lib.DecLayout()
+    _lib.check(_lib.lib().wipa_decoder_layout(C.byref(model.packed()["cfg"]), B, C.byref(lay)), "wipa_decoder_layout")
+    return tuple(getattr(lay, f) for f, _ in lay._fields_)
+
+
 def _state_for(model, B: int) -> DecoderState:
-    """one decode blob per (model, library stream); re-made when the batch or dtype changes"""
+    """one decode blob per (model, library stream); re-made when the batch, the device or the LAYOUT changes.  The layout
+    follows the configuration (dtype, cached / absorbed cross-attention, fp8 tables): a bf16 model that decoded with the
+    absorbed form holds ONE copy of the features where the cached form needs K and V of every layer (24 x the bytes at
+    whisper-small), so e.g. quantize_weights() after a first decode must not find the old blob."""
     states = model.__dict__.setdefault("_dec_states", {})
     sid = stream_id()
     st = states.get(sid)
-    if st is None or st.B != B or st.blob.device != model.device or st.cfg_dtype != model.dtype:
-        if st is not None:
-            stream().synchronize()
-            st.release()
+    if st is not None and (st.B != B or st.blob.device != model.device or st.layout_key != _layout_of(model, B)):
+        stream().synchronize()
+        st.release()
+        st = None
+    if st is None:
         st = DecoderState(model, B)
-        st.cfg_dtype = model.dtype
         states[sid] = st
     return st
 
@@ -168,15 +179,15 @@ def greedy_launch(model, audio_features: torch.Tensor, initial_tokens: Sequence[
     with on_stream() as s:
         st = _state_for(model, B)
         feats = audio_features.to(device=model.device, dtype=model.dtype).contiguous()
-        _lib.check(L.wipa_decoder_set_audio(C.byref(pk["cfg"]), pk["dec_tab"], ptr(feats), ptr(st.blob), B, sptr(s)),
+        _lib.check(L.wipa_decoder_set_audio(C.byref(pk["cfg"]), pk["dec_tab"], ptr(feats), ptr(st.blob), st.blob.numel(), B, sptr(s)),
                    "wipa_decoder_set_audio")
-        _lib.check(L.wipa_decoder_begin(C.byref(pk["cfg"]), ptr(st.blob), B, init, n_init, sptr(s)), "wipa_decoder_begin")
+        _lib.check(L.wipa_decoder_begin(C.byref(pk["cfg"]), ptr(st.blob), st.blob.numel(), B, init, n_init, sptr(s)), "wipa_decoder_begin")
         rest = total
         if _use_prefill(n_init, total):  # the prompt positions and the first new token in one batched pass
-            _lib.check(L.wipa_decoder_prefill(C.byref(pk["cfg"]), pk["dec_tab"], ptr(st.blob), B, n_init, eot, ptr(m_first),
+            _lib.check(L.wipa_decoder_prefill(C.byref(pk["cfg"]), pk["dec_tab"], ptr(st.blob), st.blob.numel(), B, n_init, eot, ptr(m_first),
                                               ptr(m_always), int(use_graph), sptr(s)), "wipa_decoder_prefill")
             rest = total - n_init
-        _lib.check(L.wipa_decoder_run(C.byref(pk["cfg"]), pk["dec_tab"], ptr(st.blob), B, n_init, eot, ptr(m_first),
+        _lib.check(L.wipa_decoder_run(C.byref(pk["cfg"]), pk["dec_tab"], ptr(st.blob), st.blob.numel(), B, n_init, eot, ptr(m_first),
                                       ptr(m_always), rest, int(use_graph), sptr(s)), "wipa_decoder_run")
     return GreedyHandle(st, s, n_init, total, (feats, m_always, m_first))
 
@@ -210,18 +221,18 @@ def greedy_decode_tokens(model, audio_features: torch.Tensor, initial_tokens: Se
     done_steps = 0
     with on_stream() as s:
         feats = audio_features.to(device=model.device, dtype=model.dtype).contiguous()
-        _lib.check(L.wipa_decoder_set_audio(C.byref(pk["cfg"]), pk["dec_tab"], ptr(feats), ptr(st.blob), B, sptr(s)),
+        _lib.check(L.wipa_decoder_set_audio(C.byref(pk["cfg"]), pk["dec_tab"], ptr(feats), ptr(st.blob), st.blob.numel(), B, sptr(s)),
                    "wipa_decoder_set_audio")
-        _lib.check(L.wipa_decoder_begin(C.byref(pk["cfg"]), ptr(st.blob), B, init, n_init, sptr(s)), "wipa_decoder_begin")
+        _lib.check(L.wipa_decoder_begin(C.byref(pk["cfg"]), ptr(st.blob), st.blob.numel(), B, init, n_init, sptr(s)), "wipa_decoder_begin")
         if _use_prefill(n_init, total):
-            _lib.check(L.wipa_decoder_prefill(C.byref(pk["cfg"]), pk["dec_tab"], ptr(st.blob), B, n_init, eot, ptr(m_first),
+            _lib.check(L.wipa_decoder_prefill(C.byref(pk["cfg"]), pk["dec_tab"], ptr(st.blob), st.blob.numel(), B, n_init, eot, ptr(m_first),
                                               ptr(m_always), int(use_graph), sptr(s)), "wipa_decoder_prefill")
             done_steps = n_init
         while done_steps < total:
             n = min(check_every if stop_on_eot else total, total - done_steps)
             if done_steps == 0:
                 n = min(total, n + n_init - 1)
-            _lib.check(L.wipa_decoder_run(C.byref(pk["cfg"]), pk["dec_tab"], ptr(st.blob), B, n_init, eot, ptr(m_first),
+            _lib.check(L.wipa_decoder_run(C.byref(pk["cfg"]), pk["dec_tab"], ptr(st.blob), st.blob.numel(), B, n_init, eot, ptr(m_first),
                                           ptr(m_always), n, int(use_graph), sptr(s)), "wipa_decoder_run")
             done_steps += n
             if stop_on_eot and done_steps >= n_init:
@@ -267,10 +278,10 @@ def forced_decode_logits(model, audio_features: torch.Tensor, tokens: np.ndarray
         trace = torch.empty(B, n_steps, V, dtype=torch.float32, device=model.device)
         chosen = torch.empty(B, n_steps, dtype=torch.int32, device=model.device)
         feats = audio_features.to(device=model.device, dtype=model.dtype).contiguous()
-        _lib.check(L.wipa_decoder_set_audio(C.byref(pk["cfg"]), pk["dec_tab"], ptr(feats), ptr(st.blob), B, sptr(s)),
+        _lib.check(L.wipa_decoder_set_audio(C.byref(pk["cfg"]), pk["dec_tab"], ptr(feats), ptr(st.blob), st.blob.numel(), B, sptr(s)),
                    "wipa_decoder_set_audio")
-        _lib.check(L.wipa_decoder_begin(C.byref(pk["cfg"]), ptr(st.blob), B, init, n_init, sptr(s)), "wipa_decoder_begin")
-        _lib.check(L.wipa_decoder_prefill(C.byref(pk["cfg"]), pk["dec_tab"], ptr(st.blob), B, n_init, eot, ptr(m_first),
+        _lib.check(L.wipa_decoder_begin(C.byref(pk["cfg"]), ptr(st.blob), st.blob.numel(), B, init, n_init, sptr(s)), "wipa_decoder_begin")
+        _lib.check(L.wipa_decoder_prefill(C.byref(pk["cfg"]), pk["dec_tab"], ptr(st.blob), st.blob.numel(), B, n_init, eot, ptr(m_first),
                                           ptr(m_always), int(use_graph), sptr(s)), "wipa_decoder_prefill")
         for i in range(n_steps):
             p = n_init + i  # the token position the last step has just filled
@@ -278,7 +289,7 @@ def forced_decode_logits(model, audio_features: torch.Tensor, tokens: np.ndarray
             chosen[:, i].copy_(st.tokens[:, p])
             st.tokens[:, p].copy_(forced[:, p])
             if i + 1 < n_steps:
-                _lib.check(L.wipa_decoder_run(C.byref(pk["cfg"]), pk["dec_tab"], ptr(st.blob), B, n_init, eot, ptr(m_first),
+                _lib.check(L.wipa_decoder_run(C.byref(pk["cfg"]), pk["dec_tab"], ptr(st.blob), st.blob.numel(), B, n_init, eot, ptr(m_first),
                                               ptr(m_always), 1, int(use_graph), sptr(s)), "wipa_decoder_run")
         out_chosen = chosen.cpu().numpy().astype(np.int64)
     return trace, out_chosen

@@ -41,8 +41,10 @@ class FrozenFeatureCache:
     features are 1500 x 768 f32 = 4.6 MB per clip, so the 7 000 training clips of data/v2_filtered are 32 GB of a 288 GB
     HBM: keep them.  A clip's features are computed once, by the same kernels, and are bit-identical whatever batch they are
     computed in (tests/test_gpu_training.py), so training with the cache gives bit-identical losses and parameters.
-    Clips beyond ``max_clips`` are simply recomputed every time (spill to recompute, no eviction).  The cache must be
-    dropped when the encoder weights change (``clear``); DecoderTrainer never touches them."""
+    Clips beyond ``max_clips`` are simply recomputed every time (spill to recompute, no eviction).  The entries are
+    functions of the encoder weights: the model counts every change of an ``encoder.*`` tensor (load_weights / update /
+    set_dtype / quantize_weights -> ``Whisper._enc_generation``) and the cache drops itself when the count moved, so stale
+    features cannot survive an encoder update; DecoderTrainer itself never touches encoder tensors."""
 
     def __init__(self, model: Whisper, max_clips: int):
         d = model.dims
@@ -53,6 +55,12 @@ class FrozenFeatureCache:
         self._pinned = None  # ring of [pinned int64 [2, n], event of the last upload]: host staging of the gather indices
         self._ring = 0
         self.hits = self.misses = 0
+        self._enc_generation = model._enc_generation
+
+    def _drop_if_encoder_changed(self) -> None:
+        if self._enc_generation != self.model._enc_generation:
+            self.clear()
+            self._enc_generation = self.model._enc_generation
 
     @staticmethod
     def clips_that_fit(model: Whisper, fraction_of_free: float = 0.5) -> int:
@@ -65,11 +73,13 @@ class FrozenFeatureCache:
 
     def missing(self, keys) -> List[bool]:
         """per key: True when the clip's features are not cached (its audio / mel is needed)"""
+        self._drop_if_encoder_changed()
         return [int(k) not in self.slots for k in keys]
 
     def assemble(self, keys, mel_of_missing: Optional[torch.Tensor]) -> torch.Tensor:
         """features [B, 1500, d] f32 for ``keys``; ``mel_of_missing`` [n_missing, 3000, n_mels] holds the mel of the keys
         for which missing() is True, in order (None when there are none)."""
+        self._drop_if_encoder_changed()
         keys = [int(k) for k in keys]
         miss_pos = [i for i, k in enumerate(keys) if k not in self.slots]
         n_miss = 0 if mel_of_missing is None else mel_of_missing.shape[0]

@@ -150,6 +150,7 @@ class Whisper:
         self._fp8: Dict[str, tuple] = {}  # name -> (codes uint8 [N,K], scale f32 [N]) for the decode-step matrices
         self._fp8_enc: Dict[str, tuple] = {}  # ... and for the encoder's q|k, value, mlp1, mlp2 when activations are fp8 too
         self._frozen = set()
+        self._enc_generation = 0  # bumped whenever an encoder tensor changes: FrozenFeatureCache entries are functions of it
         self._packed = None
         self._packed_tf = None
         self._enc_ws: Dict[int, torch.Tensor] = {}  # per library stream
@@ -190,6 +191,7 @@ class Whisper:
             for k, v in list(self._params.items()):
                 if _is_matrix(k, v):
                     self._params[k] = v.to(dtype)
+        self._enc_generation += 1
         self._invalidate()
         return self
 
@@ -205,6 +207,8 @@ class Whisper:
                     t = torch.as_tensor(flat[n]).detach()
                     want = self.dtype if _is_matrix(n, t) else torch.float32
                     self._params[n] = t.to(device=self.device, dtype=want).contiguous()
+                    if n.startswith("encoder."):
+                        self._enc_generation += 1
         self._fp8 = {}  # new weights: any fp8 codes are stale (call quantize_weights again)
         self._fp8_enc = {}
         self._invalidate()
@@ -258,6 +262,7 @@ class Whisper:
                     fp8[n] = (codes, scale)
                 if n in enc_f8:
                     fp8_enc[n] = (codes, scale)
+        self._enc_generation += 1
         self._invalidate()
         self._fp8 = fp8
         self._fp8_enc = fp8_enc
