@@ -68,6 +68,29 @@ def host_cores() -> int:
     return max(1, min(n, 16))
 
 
+def bench_absorbed(model, B: int) -> bool:
+    """the decode-step cross-attention form this run's (batch, --new-tokens) takes: cross_attention='auto' decides by the
+    measured table (Whisper.use_absorbed), exactly as greedy_launch does for the timed passes"""
+    return model.use_absorbed(B, NEW_TOKENS)
+
+
+def bench_packed(model, B: int):
+    return model.packed(absorbed=bench_absorbed(model, B))
+
+
+def bench_state(model, B: int):
+    from whisper_ipa_amd.decoding import _state_for
+
+    return _state_for(model, B, bench_packed(model, B))
+
+
+def rank_threads() -> int:
+    """torch CPU threads of THIS rank: the host's usable cores shared among the ranks on it (parallel.host_threads_per_rank)"""
+    from whisper_ipa_amd.parallel import host_threads_per_rank
+
+    return host_threads_per_rank()
+
+
 BATCH = 64          # clips per GPU
 N_PIPELINE = 4      # consecutive passes kept in flight on separate HIP streams (see --pipeline).  Measured r01 with
                     # GPU_MAX_HW_QUEUES=8 (ms per 64-clip pass, repeatable to 0.5 %): 1 -> 133.2, 3 -> 98.8, 4 -> 94.7,
@@ -269,9 +292,9 @@ def roofline_cross_attn(model, B: int, iters: int = 48):
 
     d = model.dims
     H, Ta = d.n_text_head, d.n_audio_ctx
-    st = model._dec_states[0]
+    st = bench_state(model, B)
     lay = st.layout
-    if model.cross_absorbed:
+    if bench_absorbed(model, B):
         return roofline_cross_absorbed(model, B, st, iters)
     e = 2 if model.dtype == torch.bfloat16 else 4
     per_layer = B * 2 * H * Ta * 64
@@ -318,7 +341,7 @@ def roofline_cross_attn(model, B: int, iters: int = 48):
             x = torch.randn(B, dd, device=model.device)
             x_out = torch.empty_like(x)
             slabs = torch.randn(2, B, dd, device=model.device) * 0.3
-            pk = model.packed()
+            pk = bench_packed(model, B)
             desc = []
             for l in range(d.n_text_layer):
                 lw = pk["dec"][_lib.DEC_GLOBAL + _lib.DEC_PER_LAYER * l: _lib.DEC_GLOBAL + _lib.DEC_PER_LAYER * (l + 1)]
@@ -411,7 +434,7 @@ def roofline_cross_absorbed(model, B: int, st, iters: int = 48):
     L = _lib.lib()
     d = model.dims
     H, Ta, dd = d.n_text_head, d.n_audio_ctx, d.n_text_state
-    pk = model.packed()
+    pk = model.packed(absorbed=True)
     # launch order of the real decode loop: the n_layer launches of a step read the SAME encoder output (the first finds it cold,
     # the others largely in the 256 MB Infinity Cache), then another in-flight pass's step runs on its own encoder output
     n_buf, per_buf = N_PIPELINE, d.n_text_layer
@@ -489,16 +512,16 @@ def roofline_mfma(model, audio, pmc_file: str = "r03_pmc_encoder_gemm.json"):
     # 2*M*N*K of: conv1 (K = 3 n_mels, 3000 frames), conv2 (K = 3 d, 1500 frames), per layer q,k,v,out (4 d^2) + MLP (8 d^2),
     # and the decoder's cross key / value projections of the encoder output (2 d^2 per decoder layer)
     enc = 2.0 * (3000 * de * 3 * d.n_mels + Ta * de * 3 * de + d.n_audio_layer * Ta * 12 * de * de)
-    ckv = 0.0 if model.cross_absorbed else 2.0 * d.n_text_layer * Ta * 2 * dd * dd  # absorbed projections: no cross-K/V GEMMs
+    ckv = 0.0 if bench_absorbed(model, B) else 2.0 * d.n_text_layer * Ta * 2 * dd * dd  # absorbed projections: no cross-K/V GEMMs
     flops = B * (enc + ckv)
     L = _lib.lib()
-    pk = model.packed()
+    pk = bench_packed(model, B)
     ms = (C.c_float * 4)()
     cnt = (C.c_int * 4)()
     best = None
     for _ in range(3):
         with on_stream() as s:
-            st = _state_for(model, B)
+            st = bench_state(model, B)
             _lib.check(L.wipa_profile_begin(sptr(s)), "wipa_profile_begin")
             try:
                 mel = A.log_mel_padded(audio, d.n_mels, model.dtype)
@@ -512,7 +535,7 @@ def roofline_mfma(model, audio, pmc_file: str = "r03_pmc_encoder_gemm.json"):
     gemm_ms, n_gemm, attn_ms, norm_ms = best
     achieved = flops / (gemm_ms * 1e-3) / 1e12
     attn_flops = B * d.n_audio_layer * 4.0 * Ta * Ta * de
-    out = {"kernel": "gemm_nt384/gemm_nt256 (encoder GEMM + conv" + ("" if model.cross_absorbed else " + cross-K/V projection") + " set)", "bound": "mfma",
+    out = {"kernel": "gemm_nt384/gemm_nt256 (encoder GEMM + conv" + ("" if bench_absorbed(model, B) else " + cross-K/V projection") + " set)", "bound": "mfma",
            "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "algorithmic_tflop_per_pass": round(flops / 1e12, 3),
            "gemm_ms_per_pass": round(gemm_ms, 3), "gemm_launches": n_gemm,
@@ -543,13 +566,14 @@ def decode_step_roofline(model, B: int, n_steps: int = 48):
     from whisper_ipa_amd.runtime import on_stream, ptr, sptr
 
     L = _lib.lib()
-    pk = model.packed()
+    pk = bench_packed(model, B)
+    absorbed = bench_absorbed(model, B)
     d = model.dims
     e = 2 if model.dtype == torch.bfloat16 else 4
     init, always, first, eot = decode_setup()
     m_always, m_first = _mask(model, always), _mask(model, list(always) + list(first))
     with on_stream() as s:
-        st = _state_for(model, B)  # holds the caches of the last pass on library stream 0
+        st = bench_state(model, B)  # holds the caches of the last pass on library stream 0
         p0 = int(st.pos.cpu())
         n_steps = max(1, min(n_steps, d.n_text_ctx - 2 - p0))
         args = (C.byref(pk["cfg"]), pk["dec_tab"], ptr(st.blob), st.blob.numel(), B, len(init), eot, ptr(m_first), ptr(m_always))
@@ -563,7 +587,7 @@ def decode_step_roofline(model, B: int, n_steps: int = 48):
     t_mean = p0 + 2 + n_steps / 2.0
     dd, Ld = d.n_text_state, d.n_text_layer
     cross = B * Ld * 2 * d.n_audio_ctx * dd * e
-    if model.cross_absorbed:  # one pass over the encoder output per layer instead of one over K and one over V
+    if absorbed:  # one pass over the encoder output per layer instead of one over K and one over V
         cross = B * Ld * d.n_audio_ctx * dd * e
     self_kv = B * Ld * 2 * t_mean * dd * e
     dec_params = d.n_vocab * dd + d.n_text_ctx * dd + Ld * (4 * dd * dd + 4 * dd * dd + 8 * dd * dd) + Ld * 11 * dd + 2 * dd
@@ -575,8 +599,8 @@ def decode_step_roofline(model, B: int, n_steps: int = 48):
     out = {"what": "one decode step, hipGraph replay, one pass in flight", "bound": "hbm", "ms_per_step": round(ms, 4),
            "bytes_per_step": int(total), "cross_kv_bytes": int(cross), "self_kv_bytes": int(self_kv), "weight_bytes": int(weights),
            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-           "cross_attention": "absorbed projections: the encoder output streamed once per layer" if model.cross_absorbed else "cached K / V"}
-    if model.cross_absorbed:
+           "cross_attention": "absorbed projections: the encoder output streamed once per layer" if absorbed else "cached K / V"}
+    if absorbed:
         # the figure of the earlier rounds (SURVEY.md 8d bytes: cached K AND V of every layer) over the same time, so the rounds compare
         kv_total = total + cross
         out["cached_kv_accounting"] = {"bytes_per_step": int(kv_total), "achieved": round(kv_total / (ms * 1e-3) / 1e9, 1),
@@ -973,7 +997,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     DECODE_SPLIT, ENCODER_CUS, NEW_TOKENS = args.decode_split, args.encoder_cus, args.new_tokens
-    torch.set_num_threads(host_cores())
+    torch.set_num_threads(rank_threads())  # cores / LOCAL_WORLD_SIZE: eight ranks must not ask for 8 x 16 host threads
     if args.mode == "train":
         return run_train(args)
     rank, world, dist, device_index = init_ranks(args)
@@ -987,7 +1011,7 @@ def main():
             limit_stream_cus(sid, args.decoder_cus)
 
     B = args.batch
-    log(f"start: rank {rank}/{world}, host cores {host_cores()}")
+    log(f"start: rank {rank}/{world}, host cores {host_cores()}, torch threads of this rank {torch.get_num_threads()}")
     dims, W = synthetic_weights_small(0, args.model)
     log("weights generated")
     model = Whisper(dims, dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32, f32_split=(args.f32 == "split"),
@@ -1002,7 +1026,7 @@ def main():
     audio_dev = torch.from_numpy(synthetic_audio(rank * B, B)).cuda()
     audio_chunks = [c.contiguous() for c in audio_dev.chunk(args.streams)]
     setup = decode_setup()
-    model.packed()
+    bench_packed(model, audio_chunks[0].shape[0])
     torch.cuda.synchronize()
     log("model + audio resident on the GPU")
 
@@ -1041,6 +1065,7 @@ def main():
     elapsed = max_over_ranks(dist, time.perf_counter() - t0)
 
     out = None
+    absorbed_run = bench_absorbed(model, audio_chunks[0].shape[0])
     if rank == 0:
         audio_seconds = world * B * 30.0 * args.steps
         out = {
@@ -1057,10 +1082,15 @@ def main():
             "dtype": args.dtype,
             "data": f"synthetic (seeded noise clips, random-init whisper-{args.model} weights)",
             "config": {"weights": model.weights_format, "encoder_activations": model.activations_format,
-                       "cross_attention": "absorbed" if model.cross_absorbed else "cached",
+                       "cross_attention": "absorbed" if absorbed_run else "cached",
+                       # what a pass really runs: with the absorbed form there is NO cross-K/V projection (the decode steps stream
+                       # the encoder output itself); with cached K / V the projection of every decoder layer is part of the pass
                        "workload": f"whisper-{args.model} {args.dtype}{' (fp8 e4m3 weights)' if args.weights == 'fp8' else ''} batched inference, batch={B}x30s synthetic clips per GPU, "
-                                   f"log-mel + encoder + cross-KV + {NEW_TOKENS} greedy KV-cached decode steps",
-                       "clips_per_gpu": B, "new_tokens": NEW_TOKENS, "streams_per_gpu": args.streams, "passes_in_flight": args.pipeline, "decode_group": args.decode_group,
+                                   f"log-mel + encoder{'' if absorbed_run else ' + cross-K/V projection'} + {NEW_TOKENS} greedy KV-cached decode steps"
+                                   f" ({'cross-attention on the encoder output, key / value projections absorbed' if absorbed_run else 'cross-attention on cached K / V'});"
+                                   f" {args.pipeline} such passes ({args.pipeline * B} clips) in flight per GPU",
+                       "clips_per_gpu": B, "clips_in_flight_per_gpu": args.pipeline * B, "new_tokens": NEW_TOKENS, "streams_per_gpu": args.streams,
+                       "passes_in_flight": args.pipeline, "decode_group": args.decode_group,
                        "encoder_cus": args.encoder_cus, "decoder_cus": args.decoder_cus,
                        "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "parallelism": f"dp{world} (clip sharding, no collective)"},
@@ -1074,6 +1104,8 @@ def main():
         t1 = time.perf_counter()
         single = one_pass(model, audio_chunks, setup)
         out["ms_per_pass_single_in_flight"] = round((time.perf_counter() - t1) * 1e3, 2)
+        # the same metric with ONE pass (B clips) resident at a time: the latency figure next to the throughput figure `value`
+        out["value_single_in_flight"] = round(world * B * 30.0 / (out["ms_per_pass_single_in_flight"] * 1e-3), 1)
         assert args.decode_group > 1 or (single == tokens).all(), "the pipelined and the single pass disagree on the ids"
         assert args.decode_group > 1 or out["passes_identical"], "timed passes over the same clips produced different ids"
         if args.decode_split == 1:

@@ -326,6 +326,22 @@ int wipa_greedy_step(const float* logits, int64_t ldl, int B, int V, const float
                      const float* mask_always, int32_t* tokens, int64_t ld_tok, const int32_t* pos_dev, int n_init,
                      int eot, float* sum_logprobs, int32_t* not_done, wipa_stream_t s);
 int wipa_add_i32(int32_t* p, int32_t v, wipa_stream_t s);
+/* The decode step's tail in ONE launch (round 4; the step replayed by wipa_decoder_run ends with it): wipa_greedy_step as above
+ * (at a prompt position, p + 1 < n_init, the given token is taken), THEN the next step's input row -- x[b] = tok_emb[next] +
+ * pos_emb[min(p + 1, n_ctx - 1)] (f32) and y[b] = LayerNorm(x[b]; ln_w, ln_b) in y_dtype (the first block's attn_ln) -- and, by
+ * the last workgroup to arrive on *done_counter (int32, zero between launches), *pos_dev = p + 1 and *posd_dev = (p + 1) * D.
+ * tok_emb: emb_dtype WIPA_F32 / WIPA_BF16 / WIPA_FP8_E4M3 (codes, with emb_scale [V] f32).  TextDecoder's
+ * token_embedding + positional_embedding + blocks[0].attn_ln of the NEXT position (mlx_whisper; transcribe_single.py:55). */
+int wipa_greedy_step_embed(const float* logits, int64_t ldl, int B, int V, const float* mask_first, const float* mask_always,
+                           int32_t* tokens, int64_t ld_tok, int32_t* pos_dev, int64_t* posd_dev, int32_t* done_counter, int n_init,
+                           int eot, float* sum_logprobs, int32_t* not_done, const void* tok_emb, int emb_dtype,
+                           const float* emb_scale, const float* pos_emb, int n_ctx, float* x, const float* ln_w, const float* ln_b,
+                           void* y, int y_dtype, int D, float eps, wipa_stream_t s);
+/* The same row routine alone, for the token ALREADY at position p = *pos_dev: x[b] = tok_emb[tokens[b][p]] + pos_emb[p],
+ * y[b] = LayerNorm(x[b]).  wipa_decoder_run launches it once before its first step. */
+int wipa_embed_layernorm(const int32_t* tokens, int64_t ld_tok, int B, const int32_t* pos_dev, const void* tok_emb, int emb_dtype,
+                         const float* emb_scale, const float* pos_emb, int n_ctx, float* x, const float* ln_w, const float* ln_b,
+                         void* y, int y_dtype, int D, float eps, wipa_stream_t s);
 
 /* ------------------------------------------------------------------ host-side text plumbing (no GPU work)
  * Byte-level BPE of mlx_whisper.tokenizer (tiktoken's CoreBPE) and the token-batch builder of

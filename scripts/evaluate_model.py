@@ -185,6 +185,7 @@ def main(argv=None) -> Dict:
 
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group("nccl")
+    torch.set_num_threads(parallel.host_threads_per_rank())  # the host's cores shared among the ranks on it
     rank, _ = parallel.world()
     num_samples = None if args.num_samples == 0 else args.num_samples
     base_results = None

@@ -119,6 +119,51 @@ def freeze_encoder(model) -> None:
     print(f"\nTrainable parameters: {trainable:,} / {total:,} ({100 * trainable / total:.1f}%)")
 
 
+def compute_loss(model, batch: Dict, tokenizer) -> torch.Tensor:
+    """The reference's loss function (:207-263), name and signature kept, written against ``model.logits`` so that it is the
+    template for a MODIFIED loss: frozen encoder forward (:223), teacher forcing on tokens[:, :-1] (:228-232), per-token CE
+    (reduction 'none', :256), mask = (tgt != eot) | (cumsum(tgt == eot) == 1) (:242-247), sum / max(count, 1) (:260-261).
+    ``model.logits`` is differentiable w.r.t. the decoder tensors (whisper_ipa_amd.training._DecoderLogits), so
+    ``value_and_grad(model, compute_loss)`` below is the reference's ``nn.value_and_grad(model, loss_fn)`` (:284).  The
+    production step (train_step / DecoderTrainer.loss_and_grads) computes the same loss with the fused CE kernels instead of
+    torch ops on a [B, T, V] tensor."""
+    tokens = batch["tokens"].to(model.device)
+    with torch.no_grad():
+        feats = model.embed_audio(batch["mel_features"]) if "audio_features" not in batch else batch["audio_features"]
+    dec_in, tgt = tokens[:, :-1], tokens[:, 1:].long()
+    logits = model.logits(dec_in, feats)
+    is_eot = tgt == tokenizer.eot
+    mask = (~is_eot) | (torch.cumsum(is_eot.long(), dim=1) == 1)
+    ce = torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]).float(), tgt.reshape(-1), reduction="none")
+    return (ce.reshape(tgt.shape) * mask).sum() / torch.clamp(mask.sum(), min=1)
+
+
+def value_and_grad(model, loss_fn):
+    """``nn.value_and_grad(model, loss_fn)`` of the reference (:284) for a model whose decoder a DecoderTrainer owns: returns
+    ``fn(model, batch, tokenizer) -> (loss, grads)`` with ``grads`` the nested dict of the TRAINABLE (decoder) tensors in
+    mlx_whisper's names -- what ``clip_grad_dict`` (:287-303) walks.  The gradients are also left in the trainer's flat
+    buffer, so ``trainer.apply_update()`` (per-tensor clip + AdamW) can follow directly."""
+    trainer = getattr(model, "_trainer", None)
+    if trainer is None:
+        raise RuntimeError("value_and_grad: create a whisper_ipa_amd.training.DecoderTrainer(model) first (it owns the decoder tensors)")
+
+    def fn(model, batch, tokenizer):
+        from whisper_ipa_amd.runtime import on_stream
+        from whisper_ipa_amd.whisper import _unflatten
+
+        leaves = trainer.leaves()
+        for t in leaves.values():
+            t.grad = None
+        with torch.enable_grad(), on_stream():
+            loss = loss_fn(model, batch, tokenizer)
+            loss.backward()
+            for n, t in leaves.items():  # the flat buffer holds d(logits-path) only if the loss used other leaves too: copy .grad
+                trainer.g(n).copy_(t.grad if t.grad is not None else torch.zeros_like(t))
+        return loss.detach(), _unflatten({n: trainer.g(n) for n in trainer.names})
+
+    return fn
+
+
 def train_step(trainer: DecoderTrainer, batch: Dict, tokenizer):
     """reference :266-311 -> (loss, clipped grads); the arithmetic is DecoderTrainer.train_step.  ``batch["clip_keys"]``
     (dataset indices) is present when the frozen-encoder feature cache is on: mel_features then covers the uncached clips only."""
@@ -208,6 +253,8 @@ def _init_distributed():
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # RCCL over xGMI
+    # host threads: the usable cores shared among the ranks on this host (8 ranks x all cores would oversubscribe the node)
+    torch.set_num_threads(parallel.host_threads_per_rank())
     return parallel.world()
 
 

@@ -250,6 +250,57 @@ def test_fused_decode_step_equals_unfused_step(micro, small2, monkeypatch, dtype
                 assert (a[2][rows] - b[2][rows]).abs().max() < 0.25
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_step_tail_is_bit_identical_to_the_separate_launches(micro, small2, monkeypatch, dtype):
+    """Round 4: a decode step ends with ONE launch -- greedy update + embedding of the chosen token + first LayerNorm of the next
+    position + position advance (wipa_greedy_step_embed; wipa_embed_layernorm once before the first step of a run) -- instead
+    of greedy_step, advance_pos, embed and add_slabs_layernorm (WIPA_DECODE_TAIL=0).  Same arithmetic in the same order: token
+    ids, log-probability sums and last logits must be BIT-identical, with the batched prompt pass and with the prompt walked
+    position by position, graph replay and eager, several run() calls per decode (check_every), a forced history, a bare
+    [sot] prompt, both cross-attention forms and fp8 tables."""
+    from whisper_ipa_amd.decoding import forced_decode_logits, greedy_decode_tokens
+
+    sp = R.SpecialTokens.multilingual()
+    always, first = R.suppress_lists(sp)
+    init = list(sp.sot_sequence_including_notimestamps(0))
+    cases = [(MICRO, micro, "auto", False)]
+    if dtype == torch.bfloat16:
+        cases += [(SMALL2, small2, "absorbed", False), (SMALL2, small2, "cached", False), (SMALL2, small2, "auto", True)]
+    for dims, (W, mels, xa), cross, fp8 in cases:
+        m = _model(dims, W, dtype, cross_attention=cross)
+        if fp8:
+            m.quantize_weights()
+        feats = xa.cuda().to(dtype)
+        out = {}
+        for tail in ("1", "0"):
+            monkeypatch.setenv("WIPA_DECODE_TAIL", tail)
+            res = []
+            for use_graph in (True, False):
+                r = greedy_decode_tokens(m, feats, init, always, first, sp.eot, max_new_tokens=21, stop_on_eot=False, use_graph=use_graph)
+                res.append((r.tokens, r.sum_logprobs.copy(), r.last_logits.float().cpu().clone()))
+            r = greedy_decode_tokens(m, feats, init, always, first, sp.eot, max_new_tokens=21, stop_on_eot=True, check_every=3)
+            res.append((r.tokens, r.sum_logprobs.copy(), None))
+            monkeypatch.setenv("WIPA_NO_PREFILL", "1")
+            r = greedy_decode_tokens(m, feats, init, always, first, sp.eot, max_new_tokens=9, stop_on_eot=False)
+            res.append((r.tokens, r.sum_logprobs.copy(), r.last_logits.float().cpu().clone()))
+            monkeypatch.delenv("WIPA_NO_PREFILL")
+            r = greedy_decode_tokens(m, feats, init[:1], always, first, sp.eot, max_new_tokens=5, stop_on_eot=False)  # bare [sot]
+            res.append((r.tokens, r.sum_logprobs.copy(), r.last_logits.float().cpu().clone()))
+            hist = res[0][0][:, : 4 + 10].copy()
+            hist[:, 6] = 1000 + np.arange(hist.shape[0])  # a history the path would not have chosen itself
+            tr, chosen = forced_decode_logits(m, feats, hist, 4, always, first, sp.eot)
+            res.append((chosen, np.zeros(1), tr.float().cpu().clone()))
+            out[tail] = res
+        monkeypatch.delenv("WIPA_DECODE_TAIL")
+        for k, (a, b) in enumerate(zip(out["1"], out["0"])):
+            assert a[0].shape == b[0].shape and (a[0] == b[0]).all(), (dims.n_text_state, cross, fp8, k, a[0].tolist(), b[0].tolist())
+            assert np.array_equal(a[1], b[1]), (cross, fp8, k)
+            if a[2] is not None:
+                assert torch.equal(a[2], b[2]), (cross, fp8, k)
+        g, e = out["1"][0], out["1"][1]
+        assert (g[0] == e[0]).all() and torch.equal(g[2], e[2])  # graph == eager
+
+
 def test_absorbed_cross_block_fused_prologue_equals_separate_launches(small2, monkeypatch):
     """The absorbed cross block of the decode step: [slab sum + LayerNorm + cross query + absorbed query] in ONE launch
     (cross_absorb_prologue_kernel, the default) against the three separate launches (WIPA_ABS_FUSED_PROLOGUE=0:
@@ -336,7 +387,7 @@ def test_decode_blob_follows_the_layout_after_quantize_and_cross_attention_chang
     m.quantize_weights()
     assert not m.cross_absorbed
     got = run(m)
-    assert _state_for(m, 2).blob.numel() > 4 * small_bytes
+    assert _state_for(m, 2).blob.numel() > 1.5 * small_bytes  # K and V of both layers against one copy of the features
     fresh = _model(SMALL2, W, torch.bfloat16)
     fresh.quantize_weights()
     want = run(fresh)
@@ -350,6 +401,19 @@ def test_decode_blob_follows_the_layout_after_quantize_and_cross_attention_chang
     c = run(_model(SMALL2, W, torch.bfloat16, cross_attention="cached"))
     assert (b.tokens == c.tokens).all() and np.array_equal(b.sum_logprobs, c.sum_logprobs)
     assert a.tokens.shape == b.tokens.shape
+    # (d) cross_attention="auto" decides per call from (batch, new tokens) by the measured table: long outputs at a small batch
+    # take the cached form (profiles/r03_cached_vs_absorbed.txt: -4.6 % for absorbed at 64 clips x 224 tokens), everything else
+    # the absorbed one; both forms live side by side on one model and give the ids of a model pinned to that form
+    m3 = _model(SMALL2, W, torch.bfloat16)
+    assert m3.use_absorbed(64, 64) and m3.use_absorbed(128, 224) and m3.use_absorbed() and not m3.use_absorbed(64, 224)
+    assert not m3.use_absorbed(2, 192) and m3.use_absorbed(2, 191)
+    short = greedy_decode_tokens(m3, feats, init, always, first, sp.eot, max_new_tokens=8, stop_on_eot=False)
+    long_ = greedy_decode_tokens(m3, feats, init, always, first, sp.eot, max_new_tokens=200, stop_on_eot=False)
+    short2 = greedy_decode_tokens(m3, feats, init, always, first, sp.eot, max_new_tokens=8, stop_on_eot=False)
+    assert sorted(k[1] for k in m3._dec_states) == [0, 1]  # one blob per form
+    ref_long = greedy_decode_tokens(_model(SMALL2, W, torch.bfloat16, cross_attention="cached"), feats, init, always, first, sp.eot,
+                                    max_new_tokens=200, stop_on_eot=False)
+    assert (long_.tokens == ref_long.tokens).all() and (short.tokens == a.tokens).all() and (short2.tokens == short.tokens).all()
     # (c) the ABI itself refuses the old blob under the new configuration (no launch, an error string)
     L = _lib.lib()
     pk = m2.packed()

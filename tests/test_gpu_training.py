@@ -248,11 +248,74 @@ def test_train_step_matches_oracle_clip_and_adamw(setup, f32_mode):
             # round-off is 1e-5 of parameter, so the end-to-end bound is loose; the exact update rule
             # is pinned by test_clip_adamw_kernel_exact below
             assert (tr.p(n).cpu() - Wo[n]).abs().max() < p_tol, (step, "param", n)
-    # the model's inference tables see the updated weights
-    lg = m.logits(tokens[:, :-1].cuda(), xa.cuda())
+    # the model's inference tables see the updated weights (no_grad: the forward-only C++ pass over the packed tables)
     with torch.no_grad():
+        lg = m.logits(tokens[:, :-1].cuda(), xa.cuda())
         ref_lg = R.decoder_forward(Wo, MICRO, tokens[:, :-1], xa)
     assert (lg.cpu() - ref_lg).abs().max() < 5e-3
+
+
+def test_model_logits_is_differentiable_and_the_scripts_value_and_grad_matches_loss_and_grads(setup):
+    """``model.logits`` differentiable; reference scripts/train_whisper_ipa.py:207-263 (compute_loss) and :284
+    (nn.value_and_grad).  (a) the script's compute_loss -- torch ops on model.logits -- through value_and_grad gives the loss
+    and EVERY decoder gradient of DecoderTrainer.loss_and_grads (same HIP forward / backward, the CE in torch instead of the
+    fused kernels) and of the oracle's autograd; (b) a MODIFIED loss (label smoothing 0.1, which the fused path cannot
+    express) matches the oracle's autograd of the same loss; (c) under no_grad the call is the forward-only pass."""
+    import os
+    import sys
+    import types
+
+    from whisper_ipa_amd.training import DecoderTrainer
+    from whisper_ipa_amd.whisper import ModelDimensions, Whisper
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import train_whisper_ipa as T
+
+    W, xa, tokens = setup
+    ref_loss, ref = _oracle_grads(W, xa, tokens)
+    m = Whisper(ModelDimensions(**MICRO.__dict__), dtype=torch.float32)
+    m.load_weights(W)
+    tr = DecoderTrainer(m)
+    tok = types.SimpleNamespace(eot=EOT)
+    batch = {"tokens": tokens.cuda(), "audio_features": xa.cuda()}
+    # (a)
+    loss, grads = T.value_and_grad(m, T.compute_loss)(m, batch, tok)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - ref_loss) < 1e-3
+    got = {n: tr.g(n).clone() for n in tr.names}
+    assert grads["decoder"]["blocks"][1]["mlp1"]["weight"].shape == ref["decoder.blocks.1.mlp1.weight"].shape  # mlx-style tree
+    loss2, _, _ = tr.loss_and_grads(xa.cuda(), tokens.cuda(), EOT)
+    torch.cuda.synchronize()
+    assert abs(float(loss2) - float(loss)) < 1e-5
+    for n in tr.names:
+        assert _rel(got[n], tr.g(n)) < 2e-5, ("vs loss_and_grads", n, _rel(got[n], tr.g(n)))
+        assert _rel(got[n], ref[n]) < 2e-3, ("vs oracle", n)
+
+    # (b) a loss the fused kernels do not implement
+    def smoothed(model, batch, tokenizer):
+        tgt = batch["tokens"][:, 1:].long()
+        lg = model.logits(batch["tokens"][:, :-1], batch["audio_features"])
+        return torch.nn.functional.cross_entropy(lg.reshape(-1, lg.shape[-1]), tgt.reshape(-1), label_smoothing=0.1)
+
+    loss_s, _ = T.value_and_grad(m, smoothed)(m, batch, tok)
+    names = [k for k in W if k.startswith("decoder.")]
+    leaves = {k: W[k].detach().clone().requires_grad_(True) for k in names}
+    Wl = dict(W)
+    Wl.update(leaves)
+    lg_ref = R.decoder_forward(Wl, MICRO, tokens[:, :-1], xa)
+    ref_s = torch.nn.functional.cross_entropy(lg_ref.reshape(-1, lg_ref.shape[-1]), tokens[:, 1:].reshape(-1), label_smoothing=0.1)
+    ref_g = dict(zip(names, torch.autograd.grad(ref_s, [leaves[k] for k in names])))
+    torch.cuda.synchronize()
+    assert abs(float(loss_s) - float(ref_s)) < 1e-3
+    for n in tr.names:
+        assert _rel(tr.g(n), ref_g[n]) < 3e-3, ("label smoothing", n, _rel(tr.g(n), ref_g[n]))
+    # (c)
+    with torch.no_grad():
+        plain = m.logits(tokens[:, :-1].cuda(), xa.cuda())
+    assert plain.grad_fn is None and (plain.cpu() - lg_ref.detach()).abs().max() < 1e-3
+    with torch.enable_grad():
+        diff = m.logits(tokens[:, :-1].cuda(), xa.cuda())
+    assert diff.grad_fn is not None and (diff.detach() - plain).abs().max() < 1e-3
 
 
 def test_train_script_end_to_end_artefacts(tmp_path, capsys):

@@ -228,6 +228,130 @@ def test_dp_sharding_and_collectives_gloo_world2():
         assert r[1] is True and abs(r[3] - 4.5) < 1e-6 and abs(r[4] - 30.0) < 1e-6 and r[5] is True
 
 
+# ---------------------------------------------------------------- world_size 8 on gloo: BASELINE configs[2]'s partition
+TINY_DP = dict(n_mels=80, n_audio_ctx=12, n_audio_state=64, n_audio_head=1, n_audio_layer=1, n_vocab=96, n_text_ctx=16,
+               n_text_state=64, n_text_head=1, n_text_layer=2)
+TINY_EOT = 90
+
+
+def _tiny_dp_problem():
+    """global batch 256 of a tiny decoder (the oracle's arithmetic on 64-wide, 2-layer dims): weights, features, ragged
+    EOT-padded token rows and ONE shared draw -- every rank rebuilds the same objects from the same seeds"""
+    from oracle import whisper_ref as R
+
+    dims = R.ModelDimensions(**TINY_DP)
+    W = R.synthetic_weights(dims, seed=3)
+    g = torch.Generator().manual_seed(11)
+    n_clips = 300  # the "dataset"; the step draws 256 of them
+    xa = torch.randn(n_clips, dims.n_audio_ctx, dims.n_audio_state, generator=g) * 0.5
+    rng = np.random.default_rng(5)
+    rows = []
+    for i in range(n_clips):
+        n = int(rng.integers(2, 9))
+        rows.append([1, 2] + rng.integers(3, 80, size=n).tolist() + [TINY_EOT] * (11 - 2 - n))
+    tokens = torch.tensor(rows, dtype=torch.int64)
+    draw = [int(i) for i in np.random.default_rng(0).choice(n_clips, 256, replace=False)]
+    return R, dims, W, xa, tokens, draw
+
+
+def _tiny_flat_layout(W):
+    names = [k for k in W if k.startswith("decoder.")]
+    offs, total = {}, 0
+    for k in names:
+        offs[k] = total
+        total += W[k].numel()
+    # segments in the order the trainer's backward finishes them: [final ln] <- block 1 <- block 0 <- [embeddings]
+    first_block = [min(offs[k] for k in names if k.startswith(f"decoder.blocks.{l}.")) for l in range(2)]
+    tail = min(offs[k] for k in names if k.startswith("decoder.ln."))
+    assert first_block[0] < first_block[1] < tail  # parameter_names() order: embeddings, blocks, final ln
+    segs = [(tail, total), (first_block[1], tail), (first_block[0], first_block[1]), (0, first_block[0])]
+    return names, offs, total, segs
+
+
+def _dp8_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from whisper_ipa_amd import parallel as P
+
+    torch.set_num_threads(1)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_WORLD_SIZE"] = str(world)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        R, dims, W, xa, tokens, draw = _tiny_dp_problem()
+        per = P.require_even_shards(len(draw), world)                     # 256 -> 8 x 32
+        mine = P.shard_indices(draw, world, rank)                         # slice r of the ONE shared draw
+        width = P.agree_on_step(int(tokens[mine].shape[1]) - (rank % 3))  # ranks may see narrower batches: the MAX is used
+        names, offs, total, segs = _tiny_flat_layout(W)
+        leaves = {k: W[k].detach().clone().requires_grad_(True) for k in names}
+        Wl = dict(W)
+        Wl.update(leaves)
+        tok = tokens[mine]
+        logits = R.decoder_forward(Wl, dims, tok[:, :-1], xa[mine])
+        tgt = tok[:, 1:]
+        mask = R.loss_mask(tgt, TINY_EOT).reshape(-1)
+        ce = torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]), tgt.reshape(-1), reduction="none")
+        local_sum = torch.where(mask, ce, torch.zeros_like(ce)).sum()
+        # exchange 1: (sum CE, valid count) BEFORE the backward, so every rank divides by the GLOBAL count
+        g_sum, g_cnt = P.allreduce_loss_stats(local_sum.detach(), mask.sum())
+        grads = torch.autograd.grad(local_sum / torch.clamp(g_cnt, min=1), [leaves[k] for k in names])
+        flat = torch.empty(total)
+        for k, gk in zip(names, grads):
+            flat[offs[k]: offs[k] + gk.numel()] = gk.reshape(-1)
+        # exchange 2: finished segments of the flat buffer, asynchronously, in the backward's order
+        red = P.SegmentReducer(flat)
+        for lo, hi in segs:
+            red.reduce(lo, hi)
+        joined = red.wait()
+        fail_seen = P.agree_on_step(11, failed=(rank == 5))  # one rank cannot build its batch: EVERY rank must see -1
+        q.put((rank, per, mine, width, float(g_sum / g_cnt), int(g_cnt), joined, fail_seen, P.host_threads_per_rank(cores=64),
+               flat.numpy().tobytes() if rank in (0, 7) else None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_world8_global_batch_256_gradients_equal_single_process():
+    """VERDICT r3 next #7(a) / SURVEY 8(e) / BASELINE configs[2]: world 8 has never run anywhere.  Eight gloo ranks train ONE
+    step of a tiny decoder on a global batch of 256 = 8 x 32 (require_even_shards, shard_indices of one shared draw,
+    agree_on_step, allreduce_loss_stats before the backward, SegmentReducer over the flat gradient buffer in the backward's
+    segment order): loss and the reduced gradients on every rank equal the single-process loss / autograd over the 256 clips
+    (reference scripts/train_whisper_ipa.py:260-261,287-303,548)."""
+    import torch.multiprocessing as mp
+
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 1000
+    procs = [ctx.Process(target=_dp8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    R, dims, W, xa, tokens, draw = _tiny_dp_problem()
+    names, offs, total, segs = _tiny_flat_layout(W)
+    leaves = {k: W[k].detach().clone().requires_grad_(True) for k in names}
+    Wl = dict(W)
+    Wl.update(leaves)
+    loss = R.loss_from_features(Wl, dims, xa[draw], tokens[draw], TINY_EOT)
+    grads = torch.autograd.grad(loss, [leaves[k] for k in names])
+    want = torch.cat([g.reshape(-1) for g in grads])
+    assert [r[0] for r in res] == list(range(world))
+    assert sum((r[2] for r in res), []) == draw and all(r[1] == 32 and len(r[2]) == 32 for r in res)  # the shared draw, in rank order
+    n_valid = int(R.loss_mask(tokens[draw][:, 1:], TINY_EOT).sum())
+    for r in res:
+        assert r[3] == tokens.shape[1]  # agree_on_step: the widest batch
+        assert abs(r[4] - float(loss.detach())) < 1e-5 and r[5] == n_valid  # the GLOBAL loss on every rank
+        assert r[6] == len(segs) and r[7] == -1
+        assert r[8] == 8  # 64 usable cores shared by LOCAL_WORLD_SIZE = 8 ranks
+    for r in (res[0], res[7]):
+        got = torch.from_numpy(np.frombuffer(r[9], dtype=np.float32).copy())
+        assert got.shape == want.shape
+        assert float((got - want).abs().max() / want.abs().max()) < 2e-5  # same gradients as ONE process over 256 clips
+    assert float(want.abs().max()) > 1e-4
+
+
 class _FakeValModel:
     """decode() returns the clip's index spelled out, so the gathered hypotheses reveal which rank decoded what"""
 

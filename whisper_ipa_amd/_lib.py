@@ -131,6 +131,11 @@ SIGNATURES = {
     "wipa_greedy_step": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int,
                                  c_int, c_void_p, c_void_p, c_void_p]),
     "wipa_add_i32": (c_int, [c_void_p, C.c_int32, c_void_p]),
+    "wipa_greedy_step_embed": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                       c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "wipa_embed_layernorm": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "wipa_bpe_create": (c_void_p, [c_void_p, c_void_p, c_void_p, c_int]),
     "wipa_bpe_free": (None, [c_void_p]),
     "wipa_bpe_encode_piece": (c_int, [c_void_p, C.c_char_p, c_int, c_void_p, c_int]),

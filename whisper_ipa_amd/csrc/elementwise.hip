@@ -341,6 +341,192 @@ __global__ __launch_bounds__(GS_THREADS) void greedy_step_reg_kernel(const float
     }
 }
 
+// ------------------------------------------------------------------ decode-step tail / head (round 4)
+// A decode step used to end with greedy_step + advance_pos and the next one to begin with embed + the first LayerNorm: four
+// launches of 4-16 us whose only content is a few dependent round trips.  greedy_tail_kernel does all of it in the launch that
+// already owns the row: arg-max / log-prob of the filtered logits (greedy_step_reg_kernel's arithmetic, unchanged), the EOT
+// latch, then x = tok_emb[next] + pos_emb[p + 1] and LayerNorm(x) with the first block's attn_ln for position p + 1, and -- by
+// the LAST workgroup to finish (device counter) -- the position advance.  embed_layernorm_kernel is the same row routine alone:
+// wipa_decoder_run launches it once before the first step (the prompt walk, forced histories and the first step after a
+// prefill start from tokens the tail has not embedded).  The row routine repeats add_slabs_layernorm_kernel's reduction order
+// (256 threads, float4 per thread, wave shuffle tree, ((s0+s1)+(s2+s3))), so fused and unfused steps agree bit for bit.
+__device__ __forceinline__ f32x4 emb_row_ld4(const void* emb, int emb_dtype, const float* emb_scale, int tok, int D, int c) {
+    if (emb_dtype == WIPA_F32) return *reinterpret_cast<const f32x4*>((const float*)emb + (int64_t)tok * D + c);
+    if (emb_dtype == WIPA_BF16) return ld4<__bf16>((const __bf16*)emb + (int64_t)tok * D + c);
+    // e4m3fn codes x per-row scale, rounded to bf16 like embed_fp8_kernel
+    const unsigned int u = *reinterpret_cast<const unsigned int*>((const unsigned char*)emb + (int64_t)tok * D + c);
+    const float sc = emb_scale[tok];
+    const auto lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)u, false);
+    const auto hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)u, true);
+    return f32x4{(float)(__bf16)(lo[0] * sc), (float)(__bf16)(lo[1] * sc), (float)(__bf16)(hi[0] * sc), (float)(__bf16)(hi[1] * sc)};
+}
+
+// threads 0..255 of the workgroup embed token `tok` at position `pp` into xr[D] and write LayerNorm(xr) to yr[D]; EVERY thread
+// of the workgroup must call it (three workgroup barriers); s_red: 4 floats of LDS
+template <typename TO>
+__device__ __forceinline__ void row_embed_layernorm(int tid, int tok, int pp, const void* emb, int emb_dtype, const float* emb_scale,
+                                                    const float* pos_emb, float* xr, const float* w, const float* b, TO* yr, int D,
+                                                    float eps, float* s_red) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const bool active = tid < 256;
+    f32x4 v[2], ww[2], bb[2];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid * 4 + 1024 * i;
+        v[i] = ww[i] = bb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (active && c < D) {
+            const f32x4 a = emb_row_ld4(emb, emb_dtype, emb_scale, tok, D, c);
+            const f32x4 q = *reinterpret_cast<const f32x4*>(pos_emb + (int64_t)pp * D + c);
+            ww[i] = *reinterpret_cast<const f32x4*>(w + c);
+            bb[i] = *reinterpret_cast<const f32x4*>(b + c);
+            v[i] = a + q;
+            *reinterpret_cast<f32x4*>(xr + c) = v[i];
+            sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    sum = wave_reduce_sum(sum);
+    if (active && lane == 0) s_red[wave] = sum;
+    __syncthreads();
+    const float mean = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) / (float)D;
+    __syncthreads();
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid * 4 + 1024 * i;
+        if (active && c < D) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mean;
+                sq += d * d;
+            }
+        }
+    }
+    sq = wave_reduce_sum(sq);
+    if (active && lane == 0) s_red[wave] = sq;
+    __syncthreads();
+    const float rstd = rsqrtf(((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid * 4 + 1024 * i;
+        if (active && c < D) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * ww[i][e] + bb[i][e];
+            st4<TO>(yr + c, o);
+        }
+    }
+}
+
+struct TailParams {
+    const float* logits; int64_t ldl; int V;
+    const float* mask_first; const float* mask_always;
+    int32_t* tokens; int64_t ld_tok;
+    int32_t* pos; int64_t* posd; int32_t* done_counter;
+    int n_init, eot, n_ctx;
+    float* sum_logprobs; int32_t* not_done;
+    const void* emb; int emb_dtype; const float* emb_scale; const float* pos_emb;
+    float* x; const float* ln_w; const float* ln_b; void* y; int D; float eps;
+};
+
+template <typename TO>
+__global__ __launch_bounds__(256) void embed_layernorm_kernel(TailParams q) {
+    __shared__ float s_red[4];
+    const int b = blockIdx.x;
+    const int p = *q.pos;
+    const int tok = q.tokens[(int64_t)b * q.ld_tok + p];
+    row_embed_layernorm<TO>(threadIdx.x, tok, min(p, q.n_ctx - 1), q.emb, q.emb_dtype, q.emb_scale, q.pos_emb, q.x + (int64_t)b * q.D, q.ln_w,
+                            q.ln_b, (TO*)q.y + (int64_t)b * q.D, q.D, q.eps, s_red);
+}
+
+template <typename TO>
+__global__ __launch_bounds__(GS_THREADS) void greedy_tail_kernel(TailParams q) {
+    __shared__ float s_v[GS_THREADS / 64];
+    __shared__ int s_i[GS_THREADS / 64];
+    __shared__ float s_sum[GS_THREADS / 64];
+    __shared__ float s_red[4];
+    __shared__ int s_next;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = *q.pos;
+    const int V = q.V;
+    if (p + 1 < q.n_init) {  // prompt walk: the token is already in place (uniform branch: p is the same for every thread)
+        if (tid == 0) s_next = q.tokens[(int64_t)b * q.ld_tok + p + 1];
+    } else {
+        const float* mask = (p + 1 == q.n_init) ? q.mask_first : q.mask_always;
+        const float* row = q.logits + (int64_t)b * q.ldl;
+        const int nq = V >> 2;
+        f32x4 vals[GS_MAXQ];
+#pragma unroll
+        for (int j = 0; j < GS_MAXQ; ++j) {
+            const int qi = tid + j * GS_THREADS;
+            if (qi < nq) {
+                vals[j] = *reinterpret_cast<const f32x4*>(row + 4 * qi) + *reinterpret_cast<const f32x4*>(mask + 4 * qi);
+            } else {
+                vals[j] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            }
+        }
+        const int ti = 4 * nq + tid;  // the (V mod 4) trailing elements
+        const bool has_tail = tid < 4 && ti < V;
+        const float tailv = has_tail ? row[ti] + mask[ti] : -INFINITY;
+        MaxIdx m{tailv, has_tail ? ti : 0x7fffffff};
+#pragma unroll
+        for (int j = 0; j < GS_MAXQ; ++j) {
+            const int qi = tid + j * GS_THREADS;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m = better(m, MaxIdx{vals[j][e], qi < nq ? 4 * qi + e : 0x7fffffff});
+        }
+        m = wave_argmax(m);
+        if (lane == 0) {
+            s_v[wave] = m.v;
+            s_i[wave] = m.i;
+        }
+        __syncthreads();
+        MaxIdx bm{s_v[0], s_i[0]};
+#pragma unroll
+        for (int w = 1; w < GS_THREADS / 64; ++w) bm = better(bm, MaxIdx{s_v[w], s_i[w]});
+        float se = __expf(tailv - bm.v);
+#pragma unroll
+        for (int j = 0; j < GS_MAXQ; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) se += __expf(vals[j][e] - bm.v);
+        se = wave_reduce_sum(se);
+        if (lane == 0) s_sum[wave] = se;
+        __syncthreads();
+        if (tid == 0) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < GS_THREADS / 64; ++w) tot += s_sum[w];
+            const int prev = q.tokens[(int64_t)b * q.ld_tok + p];
+            int next = bm.i;
+            if (prev == q.eot) {
+                next = q.eot;
+            } else {
+                q.sum_logprobs[b] += -logf(tot);
+            }
+            q.tokens[(int64_t)b * q.ld_tok + p + 1] = next;
+            if (next != q.eot) atomicAdd(q.not_done, 1);
+            s_next = next;
+        }
+    }
+    __syncthreads();
+    const int next = s_next;
+    // the next step's input row: embedding of the chosen token at position p + 1, then the first block's LayerNorm
+    row_embed_layernorm<TO>(tid, next, min(p + 1, q.n_ctx - 1), q.emb, q.emb_dtype, q.emb_scale, q.pos_emb, q.x + (int64_t)b * q.D, q.ln_w,
+                            q.ln_b, (TO*)q.y + (int64_t)b * q.D, q.D, q.eps, s_red);
+    // position advance by the LAST workgroup: every thread of every workgroup read *pos at its start and has used it before
+    // its workgroup's barrier above, i.e. before its counter increment -- no workgroup can still see the old position late
+    if (tid == 0) {
+        __threadfence();
+        const int arrived = atomicAdd(q.done_counter, 1);
+        if (arrived == (int)gridDim.x - 1) {
+            *q.done_counter = 0;
+            *q.pos = p + 1;
+            *q.posd = (int64_t)(p + 1) * q.D;
+        }
+    }
+}
+
 __global__ void add_i32_kernel(int32_t* p, int32_t v) { *p += v; }
 
 // ------------------------------------------------------------------ masked cross entropy
@@ -518,6 +704,55 @@ extern "C" int wipa_greedy_step(const float* logits, int64_t ldl, int B, int V, 
     else
         hipLaunchKernelGGL(greedy_step_kernel, dim3(B), dim3(GS_THREADS), 0, (hipStream_t)stream, logits, ldl, V, mask_first,
                            mask_always, tokens, ld_tok, pos_dev, n_init, eot, sum_logprobs, not_done);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+static int tail_params_check(const char* who, const float* logits, int V, int64_t ldl, const float* mask_first, const float* mask_always,
+                             int D, int emb_dtype, const float* emb_scale) {
+    WIPA_REQUIRE(D % 4 == 0 && D > 0 && D <= 2048, "%s: D=%d must be a multiple of 4 and <= 2048", who, D);
+    WIPA_REQUIRE(emb_dtype == WIPA_F32 || emb_dtype == WIPA_BF16 || (emb_dtype == WIPA_FP8_E4M3 && emb_scale), "%s: bad embedding dtype %d", who, emb_dtype);
+    if (logits)
+        WIPA_REQUIRE(V <= 4 * GS_MAXQ * GS_THREADS && ldl % 4 == 0 && ((uintptr_t)logits % 16) == 0 && ((uintptr_t)mask_first % 16) == 0 &&
+                         ((uintptr_t)mask_always % 16) == 0, "%s: vocabulary of %d / unaligned logits or masks", who, V);
+    return WIPA_OK;
+}
+
+extern "C" int wipa_embed_layernorm(const int32_t* tokens, int64_t ld_tok, int B, const int32_t* pos_dev, const void* tok_emb,
+                                    int emb_dtype, const float* emb_scale, const float* pos_emb, int n_ctx, float* x, const float* ln_w,
+                                    const float* ln_b, void* y, int y_dtype, int D, float eps, wipa_stream_t stream) {
+    WIPA_REQUIRE(tokens && pos_dev && tok_emb && pos_emb && x && ln_w && ln_b && y && B > 0 && n_ctx > 0, "wipa_embed_layernorm: bad arguments");
+    const int rc = tail_params_check("wipa_embed_layernorm", nullptr, 0, 0, nullptr, nullptr, D, emb_dtype, emb_scale);
+    if (rc != WIPA_OK) return rc;
+    TailParams q = {};
+    q.tokens = const_cast<int32_t*>(tokens); q.ld_tok = ld_tok; q.pos = const_cast<int32_t*>(pos_dev); q.n_ctx = n_ctx;
+    q.emb = tok_emb; q.emb_dtype = emb_dtype; q.emb_scale = emb_scale; q.pos_emb = pos_emb;
+    q.x = x; q.ln_w = ln_w; q.ln_b = ln_b; q.y = y; q.D = D; q.eps = eps;
+    if (y_dtype == WIPA_F32) hipLaunchKernelGGL((embed_layernorm_kernel<float>), dim3(B), dim3(256), 0, (hipStream_t)stream, q);
+    else if (y_dtype == WIPA_BF16) hipLaunchKernelGGL((embed_layernorm_kernel<__bf16>), dim3(B), dim3(256), 0, (hipStream_t)stream, q);
+    else WIPA_REQUIRE(false, "wipa_embed_layernorm: bad dtype %d", y_dtype);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+extern "C" int wipa_greedy_step_embed(const float* logits, int64_t ldl, int B, int V, const float* mask_first, const float* mask_always,
+                                      int32_t* tokens, int64_t ld_tok, int32_t* pos_dev, int64_t* posd_dev, int32_t* done_counter,
+                                      int n_init, int eot, float* sum_logprobs, int32_t* not_done, const void* tok_emb, int emb_dtype,
+                                      const float* emb_scale, const float* pos_emb, int n_ctx, float* x, const float* ln_w,
+                                      const float* ln_b, void* y, int y_dtype, int D, float eps, wipa_stream_t stream) {
+    WIPA_REQUIRE(logits && mask_first && mask_always && tokens && pos_dev && posd_dev && done_counter && sum_logprobs && not_done &&
+                     tok_emb && pos_emb && x && ln_w && ln_b && y && B > 0 && n_ctx > 0, "wipa_greedy_step_embed: bad arguments");
+    const int rc = tail_params_check("wipa_greedy_step_embed", logits, V, ldl, mask_first, mask_always, D, emb_dtype, emb_scale);
+    if (rc != WIPA_OK) return rc;
+    TailParams q = {};
+    q.logits = logits; q.ldl = ldl; q.V = V; q.mask_first = mask_first; q.mask_always = mask_always;
+    q.tokens = tokens; q.ld_tok = ld_tok; q.pos = pos_dev; q.posd = posd_dev; q.done_counter = done_counter;
+    q.n_init = n_init; q.eot = eot; q.n_ctx = n_ctx; q.sum_logprobs = sum_logprobs; q.not_done = not_done;
+    q.emb = tok_emb; q.emb_dtype = emb_dtype; q.emb_scale = emb_scale; q.pos_emb = pos_emb;
+    q.x = x; q.ln_w = ln_w; q.ln_b = ln_b; q.y = y; q.D = D; q.eps = eps;
+    if (y_dtype == WIPA_F32) hipLaunchKernelGGL((greedy_tail_kernel<float>), dim3(B), dim3(GS_THREADS), 0, (hipStream_t)stream, q);
+    else if (y_dtype == WIPA_BF16) hipLaunchKernelGGL((greedy_tail_kernel<__bf16>), dim3(B), dim3(GS_THREADS), 0, (hipStream_t)stream, q);
+    else WIPA_REQUIRE(false, "wipa_greedy_step_embed: bad dtype %d", y_dtype);
     WIPA_LAUNCH_CHECK();
     return WIPA_OK;
 }

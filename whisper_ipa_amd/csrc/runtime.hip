@@ -376,9 +376,28 @@ bool absorbed_block_fused() {
     return !(e && atoi(e) == 0);
 }
 
+// WIPA_DECODE_TAIL=0 keeps the separate greedy_step / advance_pos / embed / first-LayerNorm launches (A/B runs, part of the graph
+// key); default: ONE launch, wipa_greedy_step_embed, ends a step and prepares the next one's input rows
+bool tail_fused() {
+    const char* e = getenv("WIPA_DECODE_TAIL");
+    return !(e && atoi(e) == 0);
+}
+int32_t* done_counter_of(char* st, const wipa_dec_layout& L) { return (int32_t*)(st + L.pos + 64); }  // zeroed with pos by wipa_decoder_begin
+
+// x = embedding of the token at the current position, ln = first block's LayerNorm of it: what a tail-fused step expects to find
+int enqueue_step_head(const wipa_model_cfg* cfg, const void* const* w, char* st, const wipa_dec_layout& L, int B, wipa_stream_t stream) {
+    const DecScratch S = dec_scratch(cfg, B);
+    char* sc = st + L.scratch;
+    const void* const* lw0 = w + WIPA_DEC_GLOBAL;
+    return wipa_embed_layernorm((const int32_t*)(st + L.tokens), L.ld_tok, B, (const int32_t*)(st + L.pos), w[0], emb_dtype(cfg), emb_scale(cfg, w),
+                                (const float*)w[1], cfg->n_text_ctx, (float*)(sc + S.x), (const float*)lw0[0], (const float*)lw0[1], sc + S.ln,
+                                cfg->dtype, cfg->n_text_state, 1e-5f, stream);
+}
+
 int enqueue_step(const wipa_model_cfg* cfg, const void* const* w, char* st, const wipa_dec_layout& L, int B, int n_init,
                  int eot, const float* mask_first, const float* mask_always, wipa_stream_t stream) {
     const int dt = cfg->dtype;
+    const bool tail = tail_fused();
     const size_t e = wipa_dtype_size(dt);
     const int d = cfg->n_text_state, H = cfg->n_text_head, nctx = cfg->n_text_ctx, Ta = cfg->n_audio_ctx;
     const DecScratch S = dec_scratch(cfg, B);
@@ -414,12 +433,15 @@ int enqueue_step(const wipa_model_cfg* cfg, const void* const* w, char* st, cons
         pend = g.k_slices;
         return gemm(A, K, W, K, slabs, d, B, d, K, dt, WIPA_F32, (const float*)bias, 0, nullptr, stream, &g);
     };
-    RT_CALL(wipa_embed_tokens(tokens, L.ld_tok, B, 1, 0, pos, w[0], emb_dtype(cfg), emb_scale(cfg, w), (const float*)w[1], x, d, stream));
+    // tail-fused steps find x (this position's embedding) and ln (the first block's LayerNorm of it) in place: written by the
+    // previous step's last launch, or by enqueue_step_head before the first step of a wipa_decoder_run call
+    float* const x_first = x;
+    if (!tail) RT_CALL(wipa_embed_tokens(tokens, L.ld_tok, B, 1, 0, pos, w[0], emb_dtype(cfg), emb_scale(cfg, w), (const float*)w[1], x, d, stream));
     for (int l = 0; l < cfg->n_text_layer; ++l) {
         const void* const* lw = w + WIPA_DEC_GLOBAL + WIPA_DEC_PER_LAYER * l;
         char* skv = st + L.self_kv + (size_t)l * 3 * B * nctx * d * e;  // [3][B][nctx][d]
         char* ckv = st + L.cross_kv + (size_t)l * B * 2 * H * Ta * 64 * e;
-        RT_CALL(ln_step(lw[0], lw[1]));
+        if (!(tail && l == 0)) RT_CALL(ln_step(lw[0], lw[1]));
         {
             // q|k|v of this position -> slot[n / d][b][pos][n % d]
             wipa_gemm_desc g;
@@ -496,6 +518,15 @@ int enqueue_step(const wipa_model_cfg* cfg, const void* const* w, char* st, cons
     RT_CALL(ln_step(w[2], w[3]));
     float* logits = (float*)(st + L.logits);
     RT_CALL(gemm(ln, d, w[0], d, logits, L.ld_logits, B, cfg->n_vocab, d, dt, WIPA_F32, nullptr, 0, nullptr, stream));
+    if (tail) {
+        // greedy update + embedding of the chosen token + first LayerNorm of the NEXT position + position advance: one launch
+        const void* const* lw0 = w + WIPA_DEC_GLOBAL;
+        RT_CALL(wipa_greedy_step_embed(logits, L.ld_logits, B, cfg->n_vocab, mask_first, mask_always, tokens, L.ld_tok, pos, posd,
+                                       done_counter_of(st, L), n_init, eot, (float*)(st + L.sum_logprobs), (int32_t*)(st + L.not_done), w[0],
+                                       emb_dtype(cfg), emb_scale(cfg, w), (const float*)w[1], nctx, x_first, (const float*)lw0[0],
+                                       (const float*)lw0[1], ln, dt, d, 1e-5f, stream));
+        return WIPA_OK;
+    }
     RT_CALL(wipa_greedy_step(logits, L.ld_logits, B, cfg->n_vocab, mask_first, mask_always, tokens, L.ld_tok, pos, n_init,
                              eot, (float*)(st + L.sum_logprobs), (int32_t*)(st + L.not_done), stream));
     hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, pos, posd, d);
@@ -587,6 +618,8 @@ int decode_mode(const wipa_model_cfg* cfg, int B) {
     return m == 1 ? 1 : 2;
 }
 bool use_fused_step(const wipa_model_cfg* cfg, int B) { return !cfg->dec_cross_absorbed && decode_mode(cfg, B) == 1; }
+// whether the steps of this configuration end with the fused tail (and therefore need enqueue_step_head before the first one)
+bool step_needs_head(const wipa_model_cfg* cfg, int B) { return !use_fused_step(cfg, B) && tail_fused(); }
 
 int enqueue_decode_step(const wipa_model_cfg* cfg, const void* const* w, char* st, const wipa_dec_layout& L, int B, int n_init,
                         int eot, const float* mask_first, const float* mask_always, wipa_stream_t stream) {
@@ -868,6 +901,11 @@ extern "C" int wipa_decoder_run(const wipa_model_cfg* cfg, const void* const* w,
     char* st = (char*)state;
     hipStream_t s = (hipStream_t)stream;
     RT_CALL(init_before_capture(cfg));
+    if (n_steps == 0) return WIPA_OK;
+    // the first step's input rows (embedding + first LayerNorm of the token at the current position): every later step gets
+    // them from the previous step's last launch.  Outside the graph: once per call, whatever wrote the token (the greedy
+    // update, the prompt, a forced history)
+    if (step_needs_head(cfg, B)) RT_CALL(enqueue_step_head(cfg, w, st, L, B, stream));
     if (!use_graph || !graphs_allowed()) {
         for (int i = 0; i < n_steps; ++i)
             RT_CALL(enqueue_decode_step(cfg, w, st, L, B, n_init, eot, mask_first, mask_always, stream));
@@ -875,7 +913,7 @@ extern "C" int wipa_decoder_run(const wipa_model_cfg* cfg, const void* const* w,
     }
     WIPA_REQUIRE(s != nullptr, "wipa_decoder_run: graph capture needs a non-default stream");
     hipGraphExec_t exec = nullptr;
-    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * decode_mode(cfg, B) + 16 * cfg->dec_w_dtype + 64 * cfg->dec_cross_absorbed * (absorbed_block_fused() ? 2 : 1), cfg->weights_generation, 0);
+    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * decode_mode(cfg, B) + 16 * cfg->dec_w_dtype + 64 * cfg->dec_cross_absorbed * (absorbed_block_fused() ? 2 : 1) + 256 * (int)tail_fused(), cfg->weights_generation, 0);
     {
         std::lock_guard<std::mutex> lk(g_graph_mu);
         auto it = g_graphs.find(key);
@@ -912,14 +950,17 @@ extern "C" int wipa_decoder_prefill(const wipa_model_cfg* cfg, const void* const
     RT_CALL(state_fits("wipa_decoder_prefill", L, state_bytes));
     char* st = (char*)state;
     auto enqueue = [&]() -> int {
-        if (n_init == 1) return enqueue_decode_step(cfg, w, st, L, B, n_init, eot, mask_first, mask_always, stream);
+        if (n_init == 1) {  // a bare [sot] prompt: one ordinary step at position 0 (with its head when the step is tail-fused)
+            if (step_needs_head(cfg, B)) RT_CALL(enqueue_step_head(cfg, w, st, L, B, stream));
+            return enqueue_decode_step(cfg, w, st, L, B, n_init, eot, mask_first, mask_always, stream);
+        }
         return enqueue_prefill(cfg, w, st, L, B, n_init, eot, mask_first, mask_always, stream);
     };
     hipStream_t s = (hipStream_t)stream;
     RT_CALL(init_before_capture(cfg));
     if (!use_graph || s == nullptr || !graphs_allowed()) return enqueue();
     hipGraphExec_t exec = nullptr;
-    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * decode_mode(cfg, B) + 16 * cfg->dec_w_dtype + 64 * cfg->dec_cross_absorbed * (absorbed_block_fused() ? 2 : 1), cfg->weights_generation, 1);
+    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * decode_mode(cfg, B) + 16 * cfg->dec_w_dtype + 64 * cfg->dec_cross_absorbed * (absorbed_block_fused() ? 2 : 1) + 256 * (int)tail_fused(), cfg->weights_generation, 1);
     {
         std::lock_guard<std::mutex> lk(g_graph_mu);
         auto it = g_graphs.find(key);

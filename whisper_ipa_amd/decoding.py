@@ -67,10 +67,10 @@ class GreedyTokens:
 class DecoderState:
     """The caller-owned decode blob of wipa_decoder_* (tokens, position, logits, KV caches)."""
 
-    def __init__(self, model, B: int):
+    def __init__(self, model, B: int, pk=None):
         L = _lib.lib()
         self.model, self.B = model, B
-        pk = model.packed()
+        pk = pk or model.packed()
         self.layout = _lib.DecLayout()
         _lib.check(L.wipa_decoder_layout(C.byref(pk["cfg"]), B, C.byref(self.layout)), "wipa_decoder_layout")
         self.layout_key = tuple(getattr(self.layout, f) for f, _ in self.layout._fields_)
@@ -108,27 +108,34 @@ class DecoderState:
             pass
 
 
-def _layout_of(model, B: int) -> tuple:
-    """the blob layout the model's CURRENT configuration needs, as a comparable tuple"""
+def _layout_of(pk, B: int) -> tuple:
+    """the blob layout the packed configuration needs, as a comparable tuple"""
     lay = _lib.DecLayout()
-    _lib.check(_lib.lib().wipa_decoder_layout(C.byref(model.packed()["cfg"]), B, C.byref(lay)), "wipa_decoder_layout")
+    _lib.check(_lib.lib().wipa_decoder_layout(C.byref(pk["cfg"]), B, C.byref(lay)), "wipa_decoder_layout")
     return tuple(getattr(lay, f) for f, _ in lay._fields_)
 
 
-def _state_for(model, B: int) -> DecoderState:
+def _packed_for(model, B: int, new_tokens: Optional[int]):
+    """the weight tables + cfg for a decode of B clips x new_tokens positions: cross_attention="auto" picks the absorbed or
+    the cached form from the measured table (Whisper.use_absorbed)"""
+    return model.packed(absorbed=model.use_absorbed(B, new_tokens))
+
+
+def _state_for(model, B: int, pk=None) -> DecoderState:
     """one decode blob per (model, library stream); re-made when the batch, the device or the LAYOUT changes.  The layout
     follows the configuration (dtype, cached / absorbed cross-attention, fp8 tables): a bf16 model that decoded with the
     absorbed form holds ONE copy of the features where the cached form needs K and V of every layer (24 x the bytes at
     whisper-small), so e.g. quantize_weights() after a first decode must not find the old blob."""
+    pk = pk or model.packed()
     states = model.__dict__.setdefault("_dec_states", {})
-    sid = stream_id()
+    sid = (stream_id(), int(pk["cfg"].dec_cross_absorbed))  # one blob per library stream and cross-attention form
     st = states.get(sid)
-    if st is not None and (st.B != B or st.blob.device != model.device or st.layout_key != _layout_of(model, B)):
+    if st is not None and (st.B != B or st.blob.device != model.device or st.layout_key != _layout_of(pk, B)):
         stream().synchronize()
         st.release()
         st = None
     if st is None:
-        st = DecoderState(model, B)
+        st = DecoderState(model, B, pk)
         states[sid] = st
     return st
 
@@ -168,16 +175,16 @@ def greedy_launch(model, audio_features: torch.Tensor, initial_tokens: Sequence[
     stream and return without synchronising (EOT rows are latched on the device, so running
     past the end of a row is harmless).  Pair with greedy_collect()."""
     L = _lib.lib()
-    pk = model.packed()
     B = audio_features.shape[0]
     n_init = len(initial_tokens)
     max_new_tokens = min(max_new_tokens, model.dims.n_text_ctx - n_init)
+    pk = _packed_for(model, B, max_new_tokens)
     m_always = _mask(model, suppress_always)
     m_first = _mask(model, list(suppress_always) + list(suppress_first))
     init = (C.c_int32 * n_init)(*[int(t) for t in initial_tokens])
     total = (n_init - 1) + max_new_tokens
     with on_stream() as s:
-        st = _state_for(model, B)
+        st = _state_for(model, B, pk)
         feats = audio_features.to(device=model.device, dtype=model.dtype).contiguous()
         _lib.check(L.wipa_decoder_set_audio(C.byref(pk["cfg"]), pk["dec_tab"], ptr(feats), ptr(st.blob), st.blob.numel(), B, sptr(s)),
                    "wipa_decoder_set_audio")
@@ -207,13 +214,13 @@ def greedy_decode_tokens(model, audio_features: torch.Tensor, initial_tokens: Se
     """DecodingTask._main_loop for temperature 0, n_group 1 (see module docstring).
     ``audio_features`` [B, 1500, d] in the model dtype."""
     L = _lib.lib()
-    pk = model.packed()
     B = audio_features.shape[0]
     n_init = len(initial_tokens)
     if max_new_tokens is None:
         max_new_tokens = model.dims.n_text_ctx // 2
     max_new_tokens = min(max_new_tokens, model.dims.n_text_ctx - n_init)
-    st = _state_for(model, B)
+    pk = _packed_for(model, B, max_new_tokens)
+    st = _state_for(model, B, pk)
     m_always = _mask(model, suppress_always)
     m_first = _mask(model, list(suppress_always) + list(suppress_first))
     init = (C.c_int32 * n_init)(*[int(t) for t in initial_tokens])
@@ -262,12 +269,12 @@ def forced_decode_logits(model, audio_features: torch.Tensor, tokens: np.ndarray
     gives the logit error of a low-precision model at every step, independent of where its own greedy ids would part
     (DecodingTask._main_loop, transcribe_single.py:55)."""
     L = _lib.lib()
-    pk = model.packed()
     tokens = np.asarray(tokens)
     B, total_len = tokens.shape
     assert B == audio_features.shape[0] and 2 <= n_init < total_len <= model.dims.n_text_ctx
     n_steps = total_len - n_init
-    st = _state_for(model, B)
+    pk = _packed_for(model, B, n_steps)
+    st = _state_for(model, B, pk)
     m_always = _mask(model, suppress_always)
     m_first = _mask(model, list(suppress_always) + list(suppress_first))
     init = (C.c_int32 * n_init)(*[int(t) for t in tokens[0, :n_init]])

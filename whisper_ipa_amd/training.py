@@ -187,6 +187,8 @@ class DecoderTrainer:
         self._dw_slabs = None   # split-K partial weight gradients (wipa_gemm k_slices + wipa_sum_slabs)
         self._mm_slabs = None   # split-K partial outputs of the token-row GEMMs (_mm)
         self.feature_cache: Optional[FrozenFeatureCache] = None  # enable_feature_cache()
+        self._leaves = None     # autograd leaves over flat_p (leaves())
+        model._trainer = self   # Whisper.logits differentiates through this trainer under torch.enable_grad()
 
     def feature_cache_capacity_default(self) -> int:
         return FrozenFeatureCache.clips_that_fit(self.model)
@@ -339,21 +341,17 @@ class DecoderTrainer:
                                                  ptr(dvec), QK_SCALE, sptr(s)), "wipa_attention_bwd")
 
     # ---- forward + backward ------------------------------------------------------------
-    def loss_and_grads(self, audio_features: torch.Tensor, tokens: torch.Tensor, eot: int, group=None):
-        """features [B, 1500, d] f32 (encoder output, no gradient), tokens [B, T+1] int.
-        Fills self.flat_g (un-clipped, already divided by the global valid count and, under DP,
-        all-reduced).  Returns (loss, sum_ce, n_valid) as device scalars."""
+    def _forward(self, audio_features: torch.Tensor, tok_in: torch.Tensor):
+        """Teacher-forced decoder on ``tok_in`` [B, T] int32 (device, contiguous) and features [B, 1500, d]: returns the
+        zero-padded logits [ceil32(B*T), ceil32(V)] f32 and the saved activations the backward needs."""
         m, dm, L = self.model, self.model.dims, self.L
         P = self.p
-        B, T1 = tokens.shape
-        T = T1 - 1
+        B, T = tok_in.shape
         d, H, V, Ta = dm.n_text_state, dm.n_text_head, dm.n_vocab, dm.n_audio_ctx
         M, Mp = B * T, _ceil(B * T, 32)
         Vp = _ceil(V, 32)
         with on_stream() as s:
             dev = m.device
-            tok = tokens.to(device=dev, dtype=torch.int32).contiguous()
-            tok_in = tok[:, :-1].contiguous()
             feats = audio_features.to(device=dev, dtype=torch.float32).contiguous().view(B * Ta, d)
             # [d, ceil32(B*Ta)], shared by all layers; not needed when the weight-gradient GEMM reads feats K-major
             featsT = None if (B * Ta) % 32 == 0 else self._transpose(feats, B * Ta, d, _ceil(B * Ta, 32))
@@ -394,20 +392,24 @@ class DecoderTrainer:
             E = P("decoder.token_embedding.weight")
             logits = torch.zeros(Mp, Vp, dtype=torch.float32, device=dev)  # padding rows/cols stay zero
             self._gemm(hf, E, logits, M=M, N=V, K=d, lda=d, ldw=d, ldc=Vp)
-            row_buf = torch.empty(2 * M, dtype=torch.float32, device=dev)
-            stats = torch.empty(2, dtype=torch.float32, device=dev)
-            _lib.check(L.wipa_masked_ce(ptr(logits), Vp, ptr(tok), T1, B, T, V, eot, ptr(row_buf), ptr(stats), sptr(s)),
-                       "wipa_masked_ce")
-            sum_ce, n_valid = parallel.allreduce_loss_stats(stats[0], stats[1], group)
-            count = n_valid.reshape(1).contiguous()
-            loss = sum_ce / torch.clamp(n_valid, min=1.0)
+        ctx = dict(saved=saved, x_L=x_L, hf=hf, feats=feats, featsT=featsT, tok_in=tok_in, B=B, T=T)
+        return logits, ctx
 
-            # ------------------------------------------------------------ backward
+    def _backward(self, ctx: Dict, dlogits: torch.Tensor, group=None) -> None:
+        """Reverse pass from ``dlogits`` [ceil32(B*T), ceil32(V)] f32 (zero in the padding; consumed) into self.flat_g: the
+        gradient of every ``decoder.*`` tensor, tied embedding included.  Under DP every finished segment of the flat
+        buffer is all-reduced (SUM) asynchronously while the earlier blocks are still in their backward."""
+        m, dm, L = self.model, self.model.dims, self.L
+        P, G = self.p, self.g
+        saved, x_L, hf, feats, featsT, tok_in = ctx["saved"], ctx["x_L"], ctx["hf"], ctx["feats"], ctx["featsT"], ctx["tok_in"]
+        B, T = ctx["B"], ctx["T"]
+        d, H, V, Ta = dm.n_text_state, dm.n_text_head, dm.n_vocab, dm.n_audio_ctx
+        M, Mp = B * T, _ceil(B * T, 32)
+        Vp = _ceil(V, 32)
+        with on_stream() as s:
+            dev = m.device
             self.flat_g.zero_()
-            G = self.g
-            _lib.check(L.wipa_masked_ce_bwd(ptr(logits), Vp, ptr(tok), T1, B, T, V, ptr(row_buf[M:]), ptr(count), sptr(s)),
-                       "wipa_masked_ce_bwd")
-            dlogits = logits
+            E = P("decoder.token_embedding.weight")
             # logits = hf E^T : dhf = dlogits E ; dE = dlogits^T hf
             ET = self._transpose(E, V, d, Vp)  # [d, Vp]
             dhf = torch.empty(M, d, dtype=torch.float32, device=dev)
@@ -415,7 +417,7 @@ class DecoderTrainer:
             dlT = self._transpose(dlogits, M, V, Mp)  # [V, Mp]
             hfT = self._transpose(hf, M, d, Mp)
             self._gemm(dlT, hfT, G("decoder.token_embedding.weight"), M=V, N=d, K=Mp, lda=Mp, ldw=Mp, ldc=d)
-            del dlT, logits, dlogits
+            del dlT, dlogits
             dx = torch.empty(M, d, dtype=torch.float32, device=dev)
             self._ln_bwd(x_L, dhf, P("decoder.ln.weight"), dx, False, G("decoder.ln.weight"), G("decoder.ln.bias"), M, d)
             # DP: each finished gradient segment is all-reduced (SUM; every rank already divided by the GLOBAL
@@ -480,7 +482,49 @@ class DecoderTrainer:
                 reducer.wait()
                 e1.record(s)
                 self._ar_events = (e0, e1)
+
+    def loss_and_grads(self, audio_features: torch.Tensor, tokens: torch.Tensor, eot: int, group=None):
+        """features [B, 1500, d] f32 (encoder output, no gradient), tokens [B, T+1] int.
+        Fills self.flat_g (un-clipped, already divided by the global valid count and, under DP,
+        all-reduced).  Returns (loss, sum_ce, n_valid) as device scalars.  The fused path of the fine-tune step: masked CE and
+        its gradient run in place on the logits (wipa_masked_ce / _bwd), nothing of size [B*T, V] is kept twice."""
+        m, dm, L = self.model, self.model.dims, self.L
+        B, T1 = tokens.shape
+        T = T1 - 1
+        V = dm.n_vocab
+        M, Vp = B * T, _ceil(V, 32)
+        with on_stream() as s:
+            dev = m.device
+            tok = tokens.to(device=dev, dtype=torch.int32).contiguous()
+            tok_in = tok[:, :-1].contiguous()
+            logits, ctx = self._forward(audio_features, tok_in)
+            row_buf = torch.empty(2 * M, dtype=torch.float32, device=dev)
+            stats = torch.empty(2, dtype=torch.float32, device=dev)
+            _lib.check(L.wipa_masked_ce(ptr(logits), Vp, ptr(tok), T1, B, T, V, eot, ptr(row_buf), ptr(stats), sptr(s)),
+                       "wipa_masked_ce")
+            sum_ce, n_valid = parallel.allreduce_loss_stats(stats[0], stats[1], group)
+            count = n_valid.reshape(1).contiguous()
+            loss = sum_ce / torch.clamp(n_valid, min=1.0)
+            _lib.check(L.wipa_masked_ce_bwd(ptr(logits), Vp, ptr(tok), T1, B, T, V, ptr(row_buf[M:]), ptr(count), sptr(s)),
+                       "wipa_masked_ce_bwd")
+            self._backward(ctx, logits, group)
         return loss, sum_ce, n_valid
+
+    # ---- torch.autograd surface: Whisper.logits differentiable w.r.t. the decoder tensors (train_whisper_ipa.py:232,284) ----
+    def leaves(self) -> Dict[str, torch.Tensor]:
+        """name -> leaf tensor (requires_grad) that VIEWS the flat parameter buffer: what ``Whisper.logits`` differentiates
+        against under torch.enable_grad().  ``.grad`` is filled by ``loss.backward()``; apply_update() reads self.flat_g, so a
+        custom training loop copies / accumulates the leaves' gradients there (value_and_grad in scripts/train_whisper_ipa.py)."""
+        if self._leaves is None:
+            self._leaves = {n: self.p(n).detach().requires_grad_(True) for n in self.names}
+        return self._leaves
+
+    def differentiable_logits(self, tokens: torch.Tensor, audio_features: torch.Tensor) -> torch.Tensor:
+        """logits [B, T, V] f32 with a grad_fn: the HIP forward of loss_and_grads, its hand-written backward behind
+        torch.autograd.Function, so ANY torch-written loss on the logits gets exact decoder gradients."""
+        leaves = self.leaves()
+        return _DecoderLogits.apply(self, tokens, audio_features, *[leaves[n] for n in self.names])
+
 
     @property
     def last_allreduce_exposed_ms(self) -> float:
@@ -514,6 +558,36 @@ class DecoderTrainer:
         loss, _, _ = self.loss_and_grads(feats, tokens, eot, group)
         self.apply_update()
         return loss, self.grads()
+
+
+class _DecoderLogits(torch.autograd.Function):
+    """TextDecoder.__call__ of the fine-tune step as one autograd node: forward = DecoderTrainer._forward (libwipa kernels),
+    backward = DecoderTrainer._backward.  Gradients flow to the decoder tensors only (the encoder is frozen,
+    train_whisper_ipa.py:187; features and tokens get None)."""
+
+    @staticmethod
+    def forward(ctx, trainer, tokens, audio_features, *leaves):
+        B, T = tokens.shape
+        with on_stream():
+            tok_in = tokens.to(device=trainer.model.device, dtype=torch.int32).contiguous()
+        logits, saved = trainer._forward(audio_features, tok_in)
+        ctx.trainer, ctx.saved_acts, ctx.shape = trainer, saved, (B, T, logits.shape[0], logits.shape[1])
+        V = trainer.model.dims.n_vocab
+        return logits[: B * T].view(B, T, logits.shape[1])[:, :, :V]
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        tr = ctx.trainer
+        B, T, Mp, Vp = ctx.shape
+        V = tr.model.dims.n_vocab
+        with on_stream():
+            dl = torch.zeros(Mp, Vp, dtype=torch.float32, device=tr.model.device)
+            dl[: B * T].view(B, T, Vp)[:, :, :V].copy_(dlogits)
+        tr._backward(ctx.saved_acts, dl)
+        ctx.saved_acts = None
+        with on_stream():
+            grads = tuple(tr.g(n).clone() for n in tr.names)
+        return (None, None, None) + grads
 
 
 def _numel(shape) -> int:

@@ -129,11 +129,12 @@ class Whisper:
         per decoder layer and streamed every step, as mlx_whisper caches them.  "absorbed": Wk is absorbed into the query and
         Wv into the output, and every layer streams the encoder output xa itself -- half the bytes per step, no K/V cache, no
         projection GEMMs (csrc/cross_absorbed.hip); bf16 models with <= 16 heads and d in {384, 512, 768, 1024}, no fp8 tables.
-        "auto" (default): absorbed where it applies (WIPA_CROSS_ABSORB=0 turns that off).  Same mathematics, other bf16
-        rounding points.  Measured on MI355X, absorbed against cached: whisper-small, 64 clips: +5.8 % at
-        32 and 64 new tokens, +2.8 % at 128, -6.5 % at 224 (its extra launches per layer weigh most when every pass in flight
-        is decoding and the batch is small); 128 clips: +9.1 % at 64 tokens, +2.6 % at 224; whisper-medium, 256 clips: +5 % / +3.4 %.
-        Serving long outputs at small batch is the one case for cross_attention="cached".  The choice is
+        "auto" (default): per decode call, from (clips, new tokens) by the measured table (use_absorbed): absorbed where it
+        applies, except long outputs at a small batch (<= 64 clips with >= 192 new tokens -- the reference's own default
+        sample_len of 224 at the benchmark batch), where cached K / V is faster; WIPA_CROSS_ABSORB=0 turns absorbed off.
+        Same mathematics, other bf16 rounding points.  Measured on MI355X, absorbed against cached:
+        whisper-small, 64 clips: +5.5 % at 32, +6.0 % at 64, +3.8 % at 128, -4.6 % at 224 new tokens; 128 clips: +10.2 % / +3.0 % at
+        64 / 224; whisper-medium, 256 clips: +5.8 % / +4.0 %.  The choice is
         explicit here and in the CPU checker, and both settings are pinned by golden fixtures (tests/golden/wide_model.npz)."""
         if cross_attention not in ("auto", "absorbed", "cached"):
             raise _lib.WipaError(f"cross_attention must be 'auto', 'absorbed' or 'cached', got {cross_attention!r}")
@@ -153,6 +154,7 @@ class Whisper:
         self._enc_generation = 0  # bumped whenever an encoder tensor changes: FrozenFeatureCache entries are functions of it
         self._packed = None
         self._packed_tf = None
+        self._packed_abs = None
         self._enc_ws: Dict[int, torch.Tensor] = {}  # per library stream
         self._tf_ws: Dict[int, torch.Tensor] = {}
         self.encoder = _Part(self, "encoder")
@@ -286,42 +288,67 @@ class Whisper:
         """The weight tensors changed (load / update / dtype / optimiser step): drop the packed tables AND every decode-step
         graph captured against them -- a graph holds the device pointers of the fused q|k|v matrices that die with the old
         tables, and the table's host address alone (part of the graph key) can be reused by the next one."""
-        if self._packed is not None or getattr(self, "_dec_states", None):
+        if self._packed is not None or self._packed_abs is not None or getattr(self, "_dec_states", None):
             torch.cuda.synchronize(self.device)  # nothing may still be replaying a graph we are about to destroy
         for st in getattr(self, "_dec_states", {}).values():
             st.release()
         self._generation = (getattr(self, "_generation", 0) + 1) & 0x7FFFFFFF
         self._packed = None
         self._packed_tf = None
+        self._packed_abs = None
+
+    # "auto" by the measured table (profiles/r03_cached_vs_absorbed.txt, MI355X, 4 passes in flight; absorbed against cached):
+    # whisper-small 64 clips: +5.5 % at 32 new tokens, +6.0 % at 64, +3.8 % at 128, -4.6 % at 224; 128 clips: +10.2 % / +3.0 %
+    # at 64 / 224; whisper-medium 256 clips: +5.8 % / +4.0 %.  The one losing regime is long outputs at a small batch (every
+    # pass in flight sits in its decode loop and the absorbed step has two more launches per layer), and 224 = n_text_ctx // 2 is
+    # what the reference's callers get by default (scripts/transcribe_single.py:49-52 leaves sample_len unset).
+    AUTO_CACHED_MAX_BATCH = 64
+    AUTO_CACHED_MIN_NEW_TOKENS = 192
 
     @property
-    def cross_absorbed(self) -> bool:
-        """whether decode steps use the absorbed-projection cross-attention (see ``cross_attention`` in __init__)"""
+    def cross_absorbed_eligible(self) -> bool:
+        d = self.dims
+        return (self.dtype == torch.bfloat16 and not self._fp8 and d.n_text_head <= 16 and d.n_text_state in (384, 512, 768, 1024)
+                and d.n_text_state == d.n_audio_state)
+
+    def use_absorbed(self, batch: Optional[int] = None, new_tokens: Optional[int] = None) -> bool:
+        """whether a decode of ``batch`` clips x ``new_tokens`` positions uses the absorbed-projection cross-attention (see
+        ``cross_attention`` in __init__).  "absorbed" / "cached" force the form; "auto" takes absorbed where it applies EXCEPT
+        for long outputs at a small batch (<= 64 clips with >= 192 new tokens: the measured table above), where the cached
+        K / V form is faster.  Unknown sizes (None) count as short / large.  WIPA_CROSS_ABSORB=0 turns "auto" off."""
         import os
 
-        d = self.dims
-        eligible = (self.dtype == torch.bfloat16 and not self._fp8 and d.n_text_head <= 16 and d.n_text_state in (384, 512, 768, 1024)
-                    and d.n_text_state == d.n_audio_state)
+        eligible = self.cross_absorbed_eligible
         if self.cross_attention == "absorbed":
             if not eligible:
                 raise _lib.WipaError("cross_attention='absorbed' needs a bf16 model without fp8 tables, <= 16 heads, d in {384, 512, 768, 1024}")
             return True
-        if self.cross_attention == "cached":
+        if self.cross_attention == "cached" or not eligible or os.environ.get("WIPA_CROSS_ABSORB", "1") == "0":
             return False
-        return eligible and os.environ.get("WIPA_CROSS_ABSORB", "1") != "0"
+        long_small = (batch is not None and new_tokens is not None and batch <= self.AUTO_CACHED_MAX_BATCH
+                      and new_tokens >= self.AUTO_CACHED_MIN_NEW_TOKENS)
+        return not long_small
+
+    @property
+    def cross_absorbed(self) -> bool:
+        """the form a decode of unknown size takes (use_absorbed()); decoding.py asks use_absorbed(B, sample_len) per call"""
+        return self.use_absorbed()
 
     # ---- packing -------------------------------------------------------------------
-    def _cfg(self, fp8: bool = False) -> _lib.ModelCfg:
+    def _cfg(self, fp8: bool = False, absorbed: bool = False) -> _lib.ModelCfg:
         d = self.dims
         return _lib.ModelCfg(d.n_mels, d.n_audio_ctx, d.n_audio_state, d.n_audio_head, d.n_audio_layer, d.n_vocab,
                              d.n_text_ctx, d.n_text_state, d.n_text_head, d.n_text_layer, dt_code(self.dtype),
                              int(self.f32_split and self.dtype == torch.float32), _lib.WIPA_FP8_E4M3 if fp8 else 0,
-                             getattr(self, "_generation", 0), int(bool(self._fp8_enc)), int(self.cross_absorbed and not fp8))
+                             getattr(self, "_generation", 0), int(bool(self._fp8_enc)), int(bool(absorbed) and not fp8))
 
-    def packed(self, teacher_forced: bool = False):
+    def packed(self, teacher_forced: bool = False, absorbed: Optional[bool] = None):
         """(cfg, encoder table, decoder table); fused matrices are rebuilt after any update.  With fp8 weights the decoder
         table carries the e4m3 codes + scales of the decode-step matrices; ``teacher_forced=True`` gives the all-bf16 table
-        (dequantised values) that wipa_decoder_logits needs."""
+        (dequantised values) that wipa_decoder_logits needs.  ``absorbed`` (default: use_absorbed() of an unknown size) selects
+        the decode-step cross-attention form: both variants SHARE every weight tensor -- the absorbed one appends Wk^T per
+        layer to the decoder table and sets cfg.dec_cross_absorbed -- and both stay alive until the next weight change, so a
+        captured step graph never outlives the table it points into."""
         fp8 = bool(self._fp8) and not teacher_forced
         if teacher_forced and self._fp8:
             if self._packed_tf is None:
@@ -329,7 +356,21 @@ class Whisper:
             return self._packed_tf
         if self._packed is None:
             self._packed = self._pack(fp8)
-        return self._packed
+        if absorbed is None:
+            absorbed = self.use_absorbed()
+        if not absorbed or fp8:
+            return self._packed
+        if not self.cross_absorbed_eligible:
+            raise _lib.WipaError("packed(absorbed=True): the absorbed cross-attention does not apply to this model")
+        if self._packed_abs is None:
+            base, d = self._packed, self.dims
+            with on_stream():
+                wkT = [self._params[f"decoder.blocks.{i}.cross_attn.key.weight"].to(self.dtype).t().contiguous()
+                       for i in range(d.n_text_layer)]  # WIPA_DEC_ABSORBED_PER_LAYER: Wk^T per layer after the regular blocks
+            stream().synchronize()
+            dec = list(base["dec"]) + wkT
+            self._packed_abs = dict(cfg=self._cfg(False, True), enc=base["enc"], dec=dec, enc_tab=base["enc_tab"], dec_tab=ptr_table(dec))
+        return self._packed_abs
 
     def _pack(self, fp8: bool):
         P, T, d = self._params, self.dtype, self.dims
@@ -390,9 +431,6 @@ class Whisper:
                         enc.append(torch.cat([E[n][1] for n in names], 0).to(device=self.device, dtype=f32).contiguous())
                 assert len(enc) == _lib.ENC_GLOBAL + (_lib.ENC_PER_LAYER + _lib.ENC_FP8_PER_LAYER) * d.n_audio_layer
             assert len(dec) == _lib.DEC_GLOBAL + _lib.DEC_PER_LAYER * d.n_text_layer
-            if self.cross_absorbed and not fp8:  # absorbed cross-attention tail: Wk^T per layer (WIPA_DEC_ABSORBED_PER_LAYER)
-                for i in range(d.n_text_layer):
-                    dec.append(mat(P[f"decoder.blocks.{i}.cross_attn.key.weight"]).t().contiguous())
             if fp8:
                 # the decode-step matrices as e4m3 codes (rows concatenated like their bf16 counterparts) + per-row scales
                 F = self._fp8
@@ -416,7 +454,7 @@ class Whisper:
                 dec += tail
                 assert len(tail) == 1 + _lib.DEC_FP8_PER_LAYER * d.n_text_layer
         stream().synchronize()  # the tables are read from every library stream
-        return dict(cfg=self._cfg(fp8), enc=enc, dec=dec, enc_tab=ptr_table(enc), dec_tab=ptr_table(dec))
+        return dict(cfg=self._cfg(fp8, False), enc=enc, dec=dec, enc_tab=ptr_table(enc), dec_tab=ptr_table(dec))
 
     # ---- encoder -------------------------------------------------------------------
     def encode_padded(self, mel_padded: torch.Tensor, B: int) -> torch.Tensor:
@@ -451,7 +489,15 @@ class Whisper:
 
     # ---- teacher-forced decoder ----------------------------------------------------
     def logits(self, tokens: torch.Tensor, audio_features: torch.Tensor) -> torch.Tensor:
-        """tokens [B,T] int, features [B,1500,d] -> logits [B,T,V] f32 (train_whisper_ipa.py:232)."""
+        """tokens [B,T] int, features [B,1500,d] -> logits [B,T,V] f32 (train_whisper_ipa.py:232).
+
+        DIFFERENTIABLE w.r.t. the decoder tensors when a ``DecoderTrainer`` owns the model's decoder
+        parameters and torch's grad mode is on: the call then goes through ``training._DecoderLogits`` (HIP forward with
+        saved activations, hand-written HIP backward) and ``loss.backward()`` on ANY torch-written loss fills the ``.grad`` of
+        ``trainer.leaves()``.  Under ``torch.no_grad()`` -- inference, validation -- it is the forward-only C++ pass."""
+        tr = getattr(self, "_trainer", None)
+        if tr is not None and torch.is_grad_enabled() and self.dtype == torch.float32:
+            return tr.differentiable_logits(tokens, audio_features)
         L = _lib.lib()
         pk = self.packed(teacher_forced=True)
         B, T = tokens.shape
