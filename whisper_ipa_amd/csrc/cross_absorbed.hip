@@ -615,7 +615,10 @@ struct MergeCfg {
     static constexpr int CL = WIPA_MERGE_CL;  // clips per workgroup (1, 2, 4, 8 or 16)
 };
 
-template <int D>
+// SINGLE = the round-3 suspect re-built for the root-cause run (WIPA_MERGE_SINGLE=1, tests only): ONE thread computes the split
+// weights of the workgroup's clips into LDS and everybody reads them behind a workgroup barrier, instead of every lane
+// computing its own.  DESIGN.md section 8 records what the ISA and the determinism run showed.
+template <int D, bool SINGLE = false>
 __global__ __launch_bounds__(64 * MergeCfg<D>::NWM) void cross_merge_proj_kernel(
     const float* __restrict__ part_m, const float* __restrict__ part_l, const float* __restrict__ part_o, int n_splits,
     const __bf16* __restrict__ wv, const float* __restrict__ bv, __bf16* __restrict__ out, int64_t o_rs, int B) {
@@ -623,6 +626,7 @@ __global__ __launch_bounds__(64 * MergeCfg<D>::NWM) void cross_merge_proj_kernel
     static_assert(KQ % 32 == 0 && NWM * KQ == D, "width");
     constexpr int CL = MergeCfg<D>::CL;
     __shared__ __attribute__((aligned(16))) float red[NWM][CL][64 + 4];
+    __shared__ float ws_single[SINGLE ? CL : 1][4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int h = blockIdx.x, b0 = blockIdx.y * CL;
@@ -660,7 +664,29 @@ __global__ __launch_bounds__(64 * MergeCfg<D>::NWM) void cross_merge_proj_kernel
     // split weights exp(m_s - M) / L: every lane computes them for itself (no shared array, no single-thread section: see the
     // determinism test)
     float ws[4];
-    {
+    if constexpr (SINGLE) {
+        if (tid == 0) {
+            for (int cl = 0; cl < CL; ++cl) {
+                const int bq = min(b0 + cl, B - 1);
+                float mm[4], ll[4], M = NEG_BIG, Lsum = 0.f;
+                for (int s = 0; s < 4; ++s) {
+                    const int sc = min(s, n_splits - 1);
+                    mm[s] = part_m[((int64_t)bq * n_splits + sc) * 16 + h];
+                    ll[s] = part_l[((int64_t)bq * n_splits + sc) * 16 + h];
+                    if (s < n_splits) M = fmaxf(M, mm[s]);
+                }
+                for (int s = 0; s < 4; ++s) {
+                    mm[s] = s < n_splits ? __expf(mm[s] - M) : 0.f;
+                    Lsum += mm[s] * ll[s];
+                }
+                const float inv = 1.0f / Lsum;
+                for (int s = 0; s < 4; ++s) ws_single[cl][s] = mm[s] * inv;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ws[s] = ws_single[l15 & (CL - 1)][s];
+    } else {
         float M = NEG_BIG;
 #pragma unroll
         for (int s = 0; s < 4; ++s)
@@ -898,6 +924,12 @@ int launch_attn(const AbsParams& p_in, int B, hipStream_t s) {
 
 }  // namespace
 
+// the single-thread-section variant of the merge kernel (root-cause run of round 4; never the default)
+static bool merge_single() {
+    static const bool v = [] { const char* e = getenv("WIPA_MERGE_SINGLE"); return e && atoi(e) == 1; }();
+    return v;
+}
+
 // Frame splits per clip: FOUR, whatever the batch -- a clip's result must not depend on the batch it rides in (the partition
 // of the frames fixes the order of the softmax merges), and a workgroup streams the same 375 frames at the same per-CU rate
 // whether 1 or 256 clips are decoded; 64 clips x 4 splits are exactly one round on the 256 CUs (the kernel holds a CU: 104 KiB
@@ -1012,9 +1044,14 @@ extern "C" int wipa_cross_absorbed_attention(const void* q, int64_t q_row_stride
         if (stages & 1)                                                                                                                    \
             hipLaunchKernelGGL((cross_absorb_q_kernel<D>), gq, dim3(64), 0, s, (const __bf16*)q, q_row_stride, (const __bf16*)wkT, qp, B, H, k_scale); \
         if (stages & 2) rc = launch_attn<D>(p, B, s);                                                                                      \
-        if (rc == WIPA_OK && (stages & 4))                                                                                                 \
-            hipLaunchKernelGGL((cross_merge_proj_kernel<D>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o, S, (const __bf16*)wv, bv,        \
-                               (__bf16*)out, out_row_stride, B);                                                                           \
+        if (rc == WIPA_OK && (stages & 4)) {                                                                                               \
+            if (merge_single())                                                                                                            \
+                hipLaunchKernelGGL((cross_merge_proj_kernel<D, true>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o, S,  \
+                                   (const __bf16*)wv, bv, (__bf16*)out, out_row_stride, B);                                                \
+            else                                                                                                                           \
+                hipLaunchKernelGGL((cross_merge_proj_kernel<D>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o, S,        \
+                                   (const __bf16*)wv, bv, (__bf16*)out, out_row_stride, B);                                                \
+        }                                                                                                                                  \
     } while (0)
     if (d == 384) ABS_RUN(384);
     else if (d == 512) ABS_RUN(512);
