@@ -311,6 +311,14 @@ int wipa_cross_absorbed_attention(const void* q, int64_t q_row_stride, const voi
  * wkT / wv / bv / scratch as above.  c->x_out must not alias c->x_in. */
 int wipa_decode_cross_absorbed_block(const wipa_cross_block_desc* c, const void* wkT, const void* wv, const float* bv, void* scratch,
                                      size_t scratch_bytes, wipa_stream_t s);
+/* The same block with the cross-attention OUT projection inside its third launch (round 4; what the decode step runs): instead of
+ * c->out (may be NULL) the launch writes H split-K slabs slabs_out[h * slab_stride + b * d + n] = v_h[b] . Wo[n][h*64 .. h*64+63]
+ * (f32; slab 0 carries bo) -- MultiHeadAttention.out of the cross-attention as a per-head K split -- which the next
+ * wipa_add_slabs_layernorm(n_slabs = H <= 16) adds to the residual rows in head order.  wo [d, d] bf16 ([out][in]), bo [d] f32;
+ * slabs_out may be the buffer c->slabs points to. */
+int wipa_decode_cross_absorbed_block_out(const wipa_cross_block_desc* c, const void* wkT, const void* wv, const float* bv, const void* wo,
+                                         const float* bo, float* slabs_out, int64_t slab_stride, void* scratch, size_t scratch_bytes,
+                                         wipa_stream_t s);
 /* measurement aid: the streaming kernel of wipa_cross_absorbed_attention alone, on a scratch a full call has filled */
 int wipa_cross_absorbed_stream(const void* xa, void* scratch, size_t scratch_bytes, int B, int H, int d, int Tk, wipa_stream_t s);
 

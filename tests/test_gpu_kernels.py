@@ -999,3 +999,60 @@ def test_cross_attention_absorbed_is_deterministic_with_four_streams_in_flight()
         for i in range(4):
             assert torch.equal(outs[i], ref), (i, int((outs[i] != ref).sum()))
             assert torch.equal(scr[i][: nbytes - 1024], ref_scr[: nbytes - 1024]), i
+
+@pytest.mark.parametrize("B,H,n_slabs", [(64, 12, 2), (5, 6, 0), (19, 16, 4)])
+def test_absorbed_cross_block_with_the_out_projection_in_its_third_launch(B, H, n_slabs):
+    """Round 4: wipa_decode_cross_absorbed_block_out = the absorbed cross block whose merge launch also runs the cross-attention
+    OUT projection per head (H slabs, summed by the next LayerNorm).  Against the plain block + a float64 out projection of its
+    bf16 output: same x_out, and x + sum_h slab_h == x + out Wo^T + bo up to f32 summation order; wipa_add_slabs_layernorm over
+    the H slabs (the 16-slab form) == LayerNorm of that sum.  Ragged batches (not a multiple of the 4-clip merge tile or of the
+    16-clip prologue tile), 6 / 12 / 16 heads."""
+    import ctypes as C
+
+    from whisper_ipa_amd import _lib
+    from whisper_ipa_amd.runtime import on_stream, ptr, sptr
+
+    L = _lib.lib()
+    d, Tk = H * 64, 333
+    g = torch.Generator(device="cuda").manual_seed(B + H)
+    rn = lambda *sh, s=1.0: torch.randn(*sh, device="cuda", generator=g) * s
+    _lib.check(L.wipa_cross_absorbed_init(d))
+    xa = rn(B, Tk, d).bfloat16()
+    x_in, slabs_in = rn(B, d), rn(max(n_slabs, 1), B, d, s=0.3)
+    ln_w, ln_b = 1 + 0.1 * rn(d), 0.1 * rn(d)
+    wq, bq, wkT = rn(d, d, s=0.05).bfloat16(), rn(d, s=0.1), rn(d, d, s=0.05).bfloat16()
+    wv, bv, wo, bo = rn(d, d, s=0.05).bfloat16(), rn(d, s=0.1), rn(d, d, s=0.05).bfloat16(), rn(d, s=0.1)
+    nbytes = L.wipa_cross_absorbed_scratch_bytes(B, d, Tk)
+
+    def desc(x_out, out):
+        c = _lib.CrossBlockDesc()
+        c.x_in, c.x_out, c.slabs, c.bias_o, c.ln_w, c.ln_b = ptr(x_in), ptr(x_out), ptr(slabs_in), None, ptr(ln_w), ptr(ln_b)
+        c.wq, c.bq, c.kv, c.out = ptr(wq), ptr(bq), ptr(xa), (ptr(out) if out is not None else None)
+        c.slab_stride, c.n_slabs, c.B, c.d, c.H, c.Tk, c.dtype = B * d, n_slabs, B, d, H, Tk, _lib.WIPA_BF16
+        c.eps, c.qk_scale = 1e-5, 64 ** -0.25
+        return c
+
+    with on_stream() as s:
+        x1, x2 = torch.empty(B, d, device="cuda"), torch.empty(B, d, device="cuda")
+        out = torch.empty(B, d, device="cuda", dtype=torch.bfloat16)
+        scr = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        slabs_out = torch.full((H, B, d), float("nan"), device="cuda")
+        _lib.check(L.wipa_decode_cross_absorbed_block(C.byref(desc(x1, out)), ptr(wkT), ptr(wv), ptr(bv), ptr(scr), nbytes, sptr(s)))
+        _lib.check(L.wipa_decode_cross_absorbed_block_out(C.byref(desc(x2, None)), ptr(wkT), ptr(wv), ptr(bv), ptr(wo), ptr(bo), ptr(slabs_out),
+                                                          B * d, ptr(scr), nbytes, sptr(s)))
+        mw, mb = 1 + 0.1 * rn(d), 0.1 * rn(d)
+        y = torch.empty(B, d, device="cuda", dtype=torch.bfloat16)
+        x3 = x2.clone()
+        _lib.check(L.wipa_add_slabs_layernorm(ptr(x3), d, ptr(slabs_out), H, B * d, ptr(y), _lib.WIPA_BF16, d, ptr(mw), ptr(mb), B, d, 1e-5, sptr(s)))
+    torch.cuda.synchronize()
+    assert torch.equal(x1, x2) and torch.isfinite(slabs_out).all()
+    want = x1.double() + out.double() @ wo.double().T + bo.double()
+    got = x2.double() + slabs_out.double().sum(0)
+    assert float((got - want).abs().max()) < 2e-5 * float(want.abs().max())
+    # per-head slabs are what they say: slab h = v_h Wo[:, h]^T (+ bo in slab 0)
+    for h in (0, H - 1):
+        wh = out[:, h * 64:(h + 1) * 64].double() @ wo[:, h * 64:(h + 1) * 64].double().T + (bo.double() if h == 0 else 0)
+        assert float((slabs_out[h].double() - wh).abs().max()) < 1e-5 * float(wh.abs().max() + 1)
+    assert float((x3.double() - got).abs().max()) < 1e-5 * float(got.abs().max())  # the 16-slab LayerNorm left x + slabs in x
+    ref_y = torch.nn.functional.layer_norm(got.float(), (d,), mw, mb, 1e-5)
+    assert float((y.float() - ref_y).abs().max()) < 0.03  # bf16 output

@@ -128,6 +128,8 @@ SIGNATURES = {
                                               c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "wipa_cross_absorbed_stream": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_void_p]),
     "wipa_decode_cross_absorbed_block": (c_int, [_P(CrossBlockDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wipa_decode_cross_absorbed_block_out": (c_int, [_P(CrossBlockDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                                     c_void_p, c_size_t, c_void_p]),
     "wipa_greedy_step": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int,
                                  c_int, c_void_p, c_void_p, c_void_p]),
     "wipa_add_i32": (c_int, [c_void_p, C.c_int32, c_void_p]),

@@ -618,15 +618,26 @@ struct MergeCfg {
 // SINGLE = the round-3 suspect re-built for the root-cause run (WIPA_MERGE_SINGLE=1, tests only): ONE thread computes the split
 // weights of the workgroup's clips into LDS and everybody reads them behind a workgroup barrier, instead of every lane
 // computing its own.  DESIGN.md section 8 records what the ISA and the determinism run showed.
-template <int D, bool SINGLE = false>
+// OUTP (round 4): the cross-attention OUT projection of the head rides in the same launch.  The head's value vector
+// v_h[clip][64] (bf16, with bv: exactly what the plain kernel stores) stays in LDS and is multiplied by Wo[:, h*64 .. h*64+63]^T on
+// MFMA (48 column tiles over the waves, the fragments requested with the first loads of the kernel): slab_h[clip][0..d) in f32,
+// one slab per head at slabs_out + h * slab_stride (head 0 carries the out-projection bias).  The next LayerNorm sums x + the H
+// slabs in head order (deterministic; add_slabs_layernorm takes up to 16).  One launch instead of two per layer.
+template <int D, int SINGLE = 0, bool OUTP = false>
 __global__ __launch_bounds__(64 * MergeCfg<D>::NWM) void cross_merge_proj_kernel(
     const float* __restrict__ part_m, const float* __restrict__ part_l, const float* __restrict__ part_o, int n_splits,
-    const __bf16* __restrict__ wv, const float* __restrict__ bv, __bf16* __restrict__ out, int64_t o_rs, int B) {
+    const __bf16* __restrict__ wv, const float* __restrict__ bv, __bf16* __restrict__ out, int64_t o_rs, int B,
+    const __bf16* __restrict__ wo = nullptr, const float* __restrict__ bo = nullptr, float* __restrict__ slabs_out = nullptr,
+    int64_t slab_stride = 0) {
     constexpr int KQ = MergeCfg<D>::KQ, KS = MergeCfg<D>::KS, NWM = MergeCfg<D>::NWM;
     static_assert(KQ % 32 == 0 && NWM * KQ == D, "width");
     constexpr int CL = MergeCfg<D>::CL;
+    constexpr int NTO = D / 16;                       // column tiles of the out projection
+    constexpr int NTOW = (NTO + NWM - 1) / NWM;       // per wave (6 for d = 768)
     __shared__ __attribute__((aligned(16))) float red[NWM][CL][64 + 4];
-    __shared__ float ws_single[SINGLE ? CL : 1][4];
+    __shared__ float ws_single[SINGLE ? CL : 1][4];  // SINGLE: 1 = as the compiler builds it (SCALAR loads of the partials), 2 = the
+                                                     // same section with the index laundered through a vector register (VECTOR loads)
+    __shared__ __attribute__((aligned(16))) __bf16 vh[OUTP ? CL : 1][64 + 8];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int h = blockIdx.x, b0 = blockIdx.y * CL;
@@ -641,6 +652,17 @@ __global__ __launch_bounds__(64 * MergeCfg<D>::NWM) void cross_merge_proj_kernel
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
             wq[nt][ks] = *reinterpret_cast<const bf16x8*>(wv + (int64_t)(h * 64 + 16 * nt + l15) * D + w * KQ + 32 * ks + 8 * g);
+    // (OUTP) Wo fragments of this wave's column tiles: tile nt, k-step ks -> Wo[16 nt + l15][h*64 + 32 ks + 8 g ..]
+    bf16x8 wof[OUTP ? NTOW : 1][2];
+    if constexpr (OUTP) {
+#pragma unroll
+        for (int i = 0; i < NTOW; ++i) {
+            const int nt = min(w * NTOW + i, NTO - 1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                wof[i][ks] = *reinterpret_cast<const bf16x8*>(wo + (int64_t)(16 * nt + l15) * D + h * 64 + 32 * ks + 8 * g);
+        }
+    }
     // ... the split statistics of this lane's clip ...
     float pm[4], pl[4];
 #pragma unroll
@@ -666,8 +688,10 @@ __global__ __launch_bounds__(64 * MergeCfg<D>::NWM) void cross_merge_proj_kernel
     float ws[4];
     if constexpr (SINGLE) {
         if (tid == 0) {
+            int launder = 0;
+            if constexpr (SINGLE == 2) asm volatile("" : "+v"(launder));  // a value the compiler cannot prove uniform: global_load, not s_load
             for (int cl = 0; cl < CL; ++cl) {
-                const int bq = min(b0 + cl, B - 1);
+                const int bq = min(b0 + cl, B - 1) + launder;
                 float mm[4], ll[4], M = NEG_BIG, Lsum = 0.f;
                 for (int s = 0; s < 4; ++s) {
                     const int sc = min(s, n_splits - 1);
@@ -733,7 +757,32 @@ __global__ __launch_bounds__(64 * MergeCfg<D>::NWM) void cross_merge_proj_kernel
         float o = 0.f;
 #pragma unroll
         for (int v = 0; v < NWM; ++v) o += red[v][row][j];  // fixed order
-        if (b0 + row < B) out[(int64_t)(b0 + row) * o_rs + h * 64 + j] = (__bf16)(o + bv[h * 64 + j]);
+        const __bf16 val = (__bf16)(o + bv[h * 64 + j]);
+        if constexpr (OUTP) vh[row][j] = val;
+        else if (b0 + row < B) out[(int64_t)(b0 + row) * o_rs + h * 64 + j] = val;
+    }
+    if constexpr (OUTP) {
+        __syncthreads();
+        // A rows = clips (row l15 & (CL - 1): the tile's other rows repeat them, their results are dropped), k = the head's 64 values
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&vh[l15 & (CL - 1)][8 * g]);
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&vh[l15 & (CL - 1)][32 + 8 * g]);
+#pragma unroll
+        for (int i = 0; i < NTOW; ++i) {
+            const int nt = w * NTOW + i;
+            if (nt < NTO) {
+                f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wof[i][0], acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wof[i][1], acc2, 0, 0, 0);
+                // acc2[r] = slab_h[clip b0 + 4 g + r][16 nt + l15]: lane group 0 holds the CL real rows
+                if (4 * g < CL) {
+                    const float bias = (h == 0) ? bo[16 * nt + l15] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * g + r < CL && b0 + 4 * g + r < B)
+                            slabs_out[(int64_t)h * slab_stride + (int64_t)(b0 + 4 * g + r) * D + 16 * nt + l15] = acc2[r] + bias;
+                }
+            }
+        }
     }
 }
 
@@ -924,9 +973,9 @@ int launch_attn(const AbsParams& p_in, int B, hipStream_t s) {
 
 }  // namespace
 
-// the single-thread-section variant of the merge kernel (root-cause run of round 4; never the default)
-static bool merge_single() {
-    static const bool v = [] { const char* e = getenv("WIPA_MERGE_SINGLE"); return e && atoi(e) == 1; }();
+// the single-thread-section variants of the merge kernel (root-cause runs of round 4; never the default): 1 scalar loads, 2 vector loads
+static int merge_single() {
+    static const int v = [] { const char* e = getenv("WIPA_MERGE_SINGLE"); return e ? atoi(e) : 0; }();
     return v;
 }
 
@@ -1045,8 +1094,11 @@ extern "C" int wipa_cross_absorbed_attention(const void* q, int64_t q_row_stride
             hipLaunchKernelGGL((cross_absorb_q_kernel<D>), gq, dim3(64), 0, s, (const __bf16*)q, q_row_stride, (const __bf16*)wkT, qp, B, H, k_scale); \
         if (stages & 2) rc = launch_attn<D>(p, B, s);                                                                                      \
         if (rc == WIPA_OK && (stages & 4)) {                                                                                               \
-            if (merge_single())                                                                                                            \
-                hipLaunchKernelGGL((cross_merge_proj_kernel<D, true>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o, S,  \
+            if (merge_single() == 1)                                                                                                       \
+                hipLaunchKernelGGL((cross_merge_proj_kernel<D, 1>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o, S,     \
+                                   (const __bf16*)wv, bv, (__bf16*)out, out_row_stride, B);                                                \
+            else if (merge_single() == 2)                                                                                                  \
+                hipLaunchKernelGGL((cross_merge_proj_kernel<D, 2>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o, S,     \
                                    (const __bf16*)wv, bv, (__bf16*)out, out_row_stride, B);                                                \
             else                                                                                                                           \
                 hipLaunchKernelGGL((cross_merge_proj_kernel<D>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o, S,        \
@@ -1066,9 +1118,29 @@ extern "C" int wipa_cross_absorbed_attention(const void* q, int64_t q_row_stride
 // The whole absorbed cross block of a decode step in three launches: [slab sum + residual + cross_attn_ln + cross query + absorbed
 // query] -> streaming kernel -> [merge + value projection].  c->kv is the encoder output xa [B][Tk][d]; c->x_out must not alias
 // c->x_in (the caller swaps its two residual buffers afterwards, as with wipa_decode_cross_block).
+static int absorbed_block(const wipa_cross_block_desc* c, const void* wkT, const void* wv, const float* bv, const void* wo, const float* bo,
+                          float* slabs_out, int64_t slab_stride, void* scratch, size_t scratch_bytes, wipa_stream_t stream);
+
 extern "C" int wipa_decode_cross_absorbed_block(const wipa_cross_block_desc* c, const void* wkT, const void* wv, const float* bv, void* scratch,
                                                 size_t scratch_bytes, wipa_stream_t stream) {
-    WIPA_REQUIRE(c && c->x_in && c->x_out && c->ln_w && c->ln_b && c->wq && c->bq && c->kv && c->out && wkT && wv && bv && scratch,
+    WIPA_REQUIRE(c && c->out, "wipa_decode_cross_absorbed_block: null pointer");
+    return absorbed_block(c, wkT, wv, bv, nullptr, nullptr, nullptr, 0, scratch, scratch_bytes, stream);
+}
+
+// ... and with the cross-attention OUT projection in the third launch: instead of c->out, H split-K slabs
+// slabs_out[h * slab_stride + b * d + n] = v_h[b] . Wo[n][h*64 .. h*64+63] (+ bo[n] in slab 0), to be summed onto the residual rows
+// by the next wipa_add_slabs_layernorm(n_slabs = H).  slabs_out may be the buffer c->slabs points to (the prologue has read it).
+extern "C" int wipa_decode_cross_absorbed_block_out(const wipa_cross_block_desc* c, const void* wkT, const void* wv, const float* bv,
+                                                    const void* wo, const float* bo, float* slabs_out, int64_t slab_stride, void* scratch,
+                                                    size_t scratch_bytes, wipa_stream_t stream) {
+    WIPA_REQUIRE(c && wo && bo && slabs_out && slab_stride >= (int64_t)c->B * c->d && ((uintptr_t)wo % 16) == 0,
+                 "wipa_decode_cross_absorbed_block_out: null pointer / short slab stride");
+    return absorbed_block(c, wkT, wv, bv, wo, bo, slabs_out, slab_stride, scratch, scratch_bytes, stream);
+}
+
+static int absorbed_block(const wipa_cross_block_desc* c, const void* wkT, const void* wv, const float* bv, const void* wo, const float* bo,
+                          float* slabs_out, int64_t slab_stride, void* scratch, size_t scratch_bytes, wipa_stream_t stream) {
+    WIPA_REQUIRE(c && c->x_in && c->x_out && c->ln_w && c->ln_b && c->wq && c->bq && c->kv && (c->out || wo) && wkT && wv && bv && scratch,
                  "wipa_decode_cross_absorbed_block: null pointer");
     WIPA_REQUIRE(c->x_in != c->x_out, "wipa_decode_cross_absorbed_block: x_out must not alias x_in");
     const int B = c->B, H = c->H, d = c->d, Tk = c->Tk;
@@ -1103,7 +1175,10 @@ extern "C" int wipa_decode_cross_absorbed_block(const wipa_cross_block_desc* c, 
         if (cg == 8) hipLaunchKernelGGL((cross_absorb_prologue_kernel<D, 8>), gp, dim3(512), 0, s, q);                                     \
         else hipLaunchKernelGGL((cross_absorb_prologue_kernel<D, 16>), gp, dim3(512), 0, s, q);                                            \
         rc = launch_attn<D>(p, B, s);                                                                                                      \
-        if (rc == WIPA_OK)                                                                                                                 \
+        if (rc == WIPA_OK && wo)                                                                                                           \
+            hipLaunchKernelGGL((cross_merge_proj_kernel<D, 0, true>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o,  \
+                               S, (const __bf16*)wv, bv, (__bf16*)nullptr, (int64_t)d, B, (const __bf16*)wo, bo, slabs_out, slab_stride);  \
+        else if (rc == WIPA_OK)                                                                                                            \
             hipLaunchKernelGGL((cross_merge_proj_kernel<D>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o, S,             \
                                (const __bf16*)wv, bv, (__bf16*)c->out, (int64_t)d, B);                                                     \
     } while (0)

@@ -80,8 +80,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
 
 // Decode-step variant: ONE workgroup per row (few rows -> spread them over many CUs), fused with
 // the fixed-order sum of the split-K partial slabs of the preceding residual GEMM.
-constexpr int LN_MAX_SLABS = 4;
-template <typename TO>
+constexpr int LN_MAX_SLABS = 16;  // NS = 4 (the split-K residual GEMMs) or 16 (one slab per head from the fused out projections)
+template <typename TO, int NS = 4>
 __global__ __launch_bounds__(256) void add_slabs_layernorm_kernel(float* __restrict__ x, int64_t ldx,
                                                                    const float* __restrict__ slabs, int n_slabs,
                                                                    int64_t slab_stride, TO* __restrict__ y, int64_t ldy,
@@ -98,18 +98,18 @@ __global__ __launch_bounds__(256) void add_slabs_layernorm_kernel(float* __restr
         const int c = tid * 4 + 1024 * i;
         v[i] = ww[i] = bb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (c < D) {
-            // every load of the row (x, up to LN_MAX_SLABS slabs, w, b) is issued before the first use:
+            // every load of the row (x, up to NS slabs, w, b) is issued before the first use:
             // one memory round trip instead of one per slab
             v[i] = *reinterpret_cast<const f32x4*>(xr + c);
-            f32x4 sl[LN_MAX_SLABS];
+            f32x4 sl[NS];
 #pragma unroll
-            for (int s = 0; s < LN_MAX_SLABS; ++s)
+            for (int s = 0; s < NS; ++s)
                 sl[s] = (s < n_slabs) ? *reinterpret_cast<const f32x4*>(slabs + (int64_t)s * slab_stride + (int64_t)row * ldx + c)
                                       : f32x4{0.f, 0.f, 0.f, 0.f};
             ww[i] = *reinterpret_cast<const f32x4*>(w + c);
             bb[i] = *reinterpret_cast<const f32x4*>(b + c);
 #pragma unroll
-            for (int s = 0; s < LN_MAX_SLABS; ++s)
+            for (int s = 0; s < NS; ++s)
                 if (s < n_slabs) v[i] += sl[s];  // fixed order s = 0, 1, ...
             if (n_slabs > 0) *reinterpret_cast<f32x4*>(xr + c) = v[i];
             sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
@@ -656,14 +656,18 @@ extern "C" int wipa_add_slabs_layernorm(float* x, int64_t ldx, const float* slab
     WIPA_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && slab_stride % 4 == 0, "wipa_add_slabs_layernorm: strides must be multiples of 4");
     if (rows <= 0) return WIPA_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (y_dtype == WIPA_F32)
-        hipLaunchKernelGGL((add_slabs_layernorm_kernel<float>), dim3(rows), dim3(256), 0, s, x, ldx, slabs, n_slabs, slab_stride,
-                           (float*)y, ldy, w, b, D, eps);
-    else if (y_dtype == WIPA_BF16)
-        hipLaunchKernelGGL((add_slabs_layernorm_kernel<__bf16>), dim3(rows), dim3(256), 0, s, x, ldx, slabs, n_slabs, slab_stride,
-                           (__bf16*)y, ldy, w, b, D, eps);
-    else
-        WIPA_REQUIRE(false, "wipa_add_slabs_layernorm: bad dtype %d", y_dtype);
+    WIPA_REQUIRE(y_dtype == WIPA_F32 || y_dtype == WIPA_BF16, "wipa_add_slabs_layernorm: bad dtype %d", y_dtype);
+#define LN_SLABS(TO, NS)                                                                                                          \
+    hipLaunchKernelGGL((add_slabs_layernorm_kernel<TO, NS>), dim3(rows), dim3(256), 0, s, x, ldx, slabs, n_slabs, slab_stride, (TO*)y, \
+                       ldy, w, b, D, eps)
+    if (y_dtype == WIPA_F32) {
+        if (n_slabs <= 4) LN_SLABS(float, 4);
+        else LN_SLABS(float, 16);
+    } else {
+        if (n_slabs <= 4) LN_SLABS(__bf16, 4);
+        else LN_SLABS(__bf16, 16);
+    }
+#undef LN_SLABS
     WIPA_LAUNCH_CHECK();
     return WIPA_OK;
 }

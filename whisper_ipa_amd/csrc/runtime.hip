@@ -376,6 +376,11 @@ bool absorbed_block_fused() {
     return !(e && atoi(e) == 0);
 }
 
+// WIPA_ABS_MERGE_OUT=0 keeps the cross-attention out projection of the absorbed block as its own split-K GEMM (A/B runs)
+bool absorbed_merge_out() {
+    const char* e = getenv("WIPA_ABS_MERGE_OUT");
+    return !(e && atoi(e) == 0);
+}
 // WIPA_DECODE_TAIL=0 keeps the separate greedy_step / advance_pos / embed / first-LayerNorm launches (A/B runs, part of the graph
 // key); default: ONE launch, wipa_greedy_step_embed, ends a step and prepares the next one's input rows
 bool tail_fused() {
@@ -441,6 +446,7 @@ int enqueue_step(const wipa_model_cfg* cfg, const void* const* w, char* st, cons
         const void* const* lw = w + WIPA_DEC_GLOBAL + WIPA_DEC_PER_LAYER * l;
         char* skv = st + L.self_kv + (size_t)l * 3 * B * nctx * d * e;  // [3][B][nctx][d]
         char* ckv = st + L.cross_kv + (size_t)l * B * 2 * H * Ta * 64 * e;
+        bool cross_out_done = false;
         if (!(tail && l == 0)) RT_CALL(ln_step(lw[0], lw[1]));
         {
             // q|k|v of this position -> slot[n / d][b][pos][n % d]
@@ -488,10 +494,20 @@ int enqueue_step(const wipa_model_cfg* cfg, const void* const* w, char* st, cons
             c.ln_w = (const float*)lw[6]; c.ln_b = (const float*)lw[7]; c.wq = lw[8]; c.bq = (const float*)lw[9];
             c.kv = st + L.cross_kv; c.out = ao; c.slab_stride = slab_stride;
             c.n_slabs = pend; c.B = B; c.d = d; c.H = H; c.Tk = Ta; c.dtype = dt; c.eps = 1e-5f; c.qk_scale = QK_SCALE;
-            RT_CALL(wipa_decode_cross_absorbed_block(&c, wkT, (const char*)lw[10] + (size_t)d * d * e, (const float*)lw[11] + d,
-                                                     sc + S.absorbed, S.total - S.absorbed, stream));
-            pend = 0;
-            std::swap(x, x_other);
+            if (absorbed_merge_out()) {
+                // ... and the cross-attention OUT projection rides in the third launch: one slab per head, summed by the mlp LayerNorm
+                RT_CALL(wipa_decode_cross_absorbed_block_out(&c, wkT, (const char*)lw[10] + (size_t)d * d * e, (const float*)lw[11] + d,
+                                                             lw[12], (const float*)lw[13], slabs, slab_stride, sc + S.absorbed,
+                                                             S.total - S.absorbed, stream));
+                pend = H;
+                std::swap(x, x_other);
+                cross_out_done = true;
+            } else {
+                RT_CALL(wipa_decode_cross_absorbed_block(&c, wkT, (const char*)lw[10] + (size_t)d * d * e, (const float*)lw[11] + d,
+                                                         sc + S.absorbed, S.total - S.absorbed, stream));
+                pend = 0;
+                std::swap(x, x_other);
+            }
         } else {
             RT_CALL(ln_step(lw[6], lw[7]));
             {
@@ -510,7 +526,7 @@ int enqueue_step(const wipa_model_cfg* cfg, const void* const* w, char* st, cons
                 RT_CALL(wipa_decode_cross_attn(q, ckv, ao, B, H, Ta, dt, stream));
             }
         }
-        RT_CALL(residual_gemm(ao, d, lw[12], lw[13]));
+        if (!cross_out_done) RT_CALL(residual_gemm(ao, d, lw[12], lw[13]));
         RT_CALL(ln_step(lw[14], lw[15]));
         RT_CALL(gemm(ln, d, lw[16], d, hb, 4 * d, B, 4 * d, d, dt, dt, (const float*)lw[17], 1, nullptr, stream));
         RT_CALL(residual_gemm(hb, 4 * d, lw[18], lw[19]));
@@ -913,7 +929,7 @@ extern "C" int wipa_decoder_run(const wipa_model_cfg* cfg, const void* const* w,
     }
     WIPA_REQUIRE(s != nullptr, "wipa_decoder_run: graph capture needs a non-default stream");
     hipGraphExec_t exec = nullptr;
-    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * decode_mode(cfg, B) + 16 * cfg->dec_w_dtype + 64 * cfg->dec_cross_absorbed * (absorbed_block_fused() ? 2 : 1) + 256 * (int)tail_fused(), cfg->weights_generation, 0);
+    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * decode_mode(cfg, B) + 16 * cfg->dec_w_dtype + 64 * cfg->dec_cross_absorbed * (absorbed_block_fused() ? 2 : 1) + 256 * (int)tail_fused() + 512 * (int)absorbed_merge_out(), cfg->weights_generation, 0);
     {
         std::lock_guard<std::mutex> lk(g_graph_mu);
         auto it = g_graphs.find(key);
@@ -960,7 +976,7 @@ extern "C" int wipa_decoder_prefill(const wipa_model_cfg* cfg, const void* const
     RT_CALL(init_before_capture(cfg));
     if (!use_graph || s == nullptr || !graphs_allowed()) return enqueue();
     hipGraphExec_t exec = nullptr;
-    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * decode_mode(cfg, B) + 16 * cfg->dec_w_dtype + 64 * cfg->dec_cross_absorbed * (absorbed_block_fused() ? 2 : 1) + 256 * (int)tail_fused(), cfg->weights_generation, 1);
+    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * decode_mode(cfg, B) + 16 * cfg->dec_w_dtype + 64 * cfg->dec_cross_absorbed * (absorbed_block_fused() ? 2 : 1) + 256 * (int)tail_fused() + 512 * (int)absorbed_merge_out(), cfg->weights_generation, 1);
     {
         std::lock_guard<std::mutex> lk(g_graph_mu);
         auto it = g_graphs.find(key);
