@@ -276,8 +276,12 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_mfma_kernel(AttnParams p) {
 // K11 decode-step cross-attention
 // =============================================================================
 // WPH = waves per (b,h): 4 (the workgroup's waves split the keys; long caches, e.g. 1500 cross keys) or
-// 1 (every wave owns one head and walks all its keys; short self-attention caches: no LDS merge, 4x fewer workgroups)
-template <typename T, int WPH>
+// 1 (every wave owns one head and walks all its keys; short self-attention caches: no LDS merge, 4x fewer workgroups).
+// NT: non-temporal loads (a cache read exactly once per step: the cached cross K / V); off for the growing self-attention cache,
+// which the next step reads again.  Round 4: the self-attention of a decode step takes WPH = 4 with NT off once the cache can
+// exceed 32 keys -- a wave of the one-wave form walks 32 keys per dependent round trip (7 of them at 224 keys: 6.6 us at 32
+// keys, 9.9 us at 64, growing), four waves take 128 per round trip.
+template <typename T, int WPH, bool NT = (WPH == 4)>
 __global__ __launch_bounds__(256) void decode_attn_kernel(AttnParams p) {
     constexpr int EPL = Vec16<T>::EPL;  // elements per 16-byte load
     constexpr int LPK = 64 / EPL;       // lanes per key row (64 dims)
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(AttnParams p) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int t = min(t0 + u * G + g, Tk - 1);
-            if constexpr (WPH == 4) {  // cross-attention: 3.5 GB per step read exactly once -> non-temporal (nt) loads
+            if constexpr (NT) {  // cross-attention: 3.5 GB per step read exactly once -> non-temporal (nt) loads
                 typedef decltype(kv_[u].v) VT;
                 kv_[u].v = __builtin_nontemporal_load(reinterpret_cast<const VT*>(Kb + (int64_t)t * k_rs));
                 vv_[u].v = __builtin_nontemporal_load(reinterpret_cast<const VT*>(Vb + (int64_t)t * v_rs));
@@ -519,6 +523,10 @@ constexpr int FA_TILE = 64 * FA_ROWB;       // 8 KiB
 constexpr float LOG2E = 1.4426950408889634f;
 
 // blockDim.x / 64 = 4 or 8 waves: 128 or 256 queries share every K / V^T tile (8 waves halve the L2->LDS fill per FLOP).
+// PK: the softmax's scale-and-shift as packed f32 math (v_pk_fma_f32 / v_pk_add_f32, two scores per instruction; the form since
+// round 1) or as one v_fma_f32 per score (WIPA_FLASH_PK=0: MI355X_MICROARCH.md prices packed f32 VALU beside MFMAs above two
+// plain ones in a one-wave-per-SIMD stream; measured here with two waves per SIMD).
+template <bool PK>
 __global__ __launch_bounds__(512) void flash_enc_bf16_kernel(const __bf16* __restrict__ qk, int64_t ldqk,
                                                              const __bf16* __restrict__ vt, int64_t ldvt,
                                                              __bf16* __restrict__ out, int64_t ldo, int H, int T) {
@@ -616,19 +624,38 @@ __global__ __launch_bounds__(512) void flash_enc_bf16_kernel(const __bf16* __res
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m, mx * LOG2E);  // every tile holds at least one real key, so m_new is finite
         // two scores per VALU slot (v_pk_fma_f32 / v_pk_add_f32); only the exponentials stay scalar
-        f32x2 psum2 = {0.f, 0.f};
-        const f32x2 l2e = {LOG2E, LOG2E}, mneg = {-m_new, -m_new};
+        float psum;
+        if constexpr (PK) {
+            f32x2 psum2 = {0.f, 0.f};
+            const f32x2 l2e = {LOG2E, LOG2E}, mneg = {-m_new, -m_new};
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int i = 0; i < 16; i += 2) {
-                const f32x2 x = __builtin_elementwise_fma(f32x2{S[u][i], S[u][i + 1]}, l2e, mneg);  // masked: exp2(-1e30) = 0
-                const f32x2 pv = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
-                S[u][i] = pv.x;
-                S[u][i + 1] = pv.y;
-                psum2 += pv;
-            }
-        const float psum = psum2.x + psum2.y;
+                for (int i = 0; i < 16; i += 2) {
+                    const f32x2 x = __builtin_elementwise_fma(f32x2{S[u][i], S[u][i + 1]}, l2e, mneg);  // masked: exp2(-1e30) = 0
+                    const f32x2 pv = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+                    S[u][i] = pv.x;
+                    S[u][i + 1] = pv.y;
+                    psum2 += pv;
+                }
+            psum = psum2.x + psum2.y;
+        } else {
+            float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    float x0, x1;  // asm: keeps -O3 from SLP-packing the pair back into v_pk_fma_f32
+                    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(x0) : "v"(S[u][i]), "v"(LOG2E), "v"(-m_new));
+                    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(x1) : "v"(S[u][i + 1]), "v"(LOG2E), "v"(-m_new));
+                    const float p0 = __builtin_amdgcn_exp2f(x0), p1 = __builtin_amdgcn_exp2f(x1);
+                    S[u][i] = p0;
+                    S[u][i + 1] = p1;
+                    asm("v_add_f32 %0, %1, %2" : "=v"(ps0) : "v"(ps0), "v"(p0));
+                    asm("v_add_f32 %0, %1, %2" : "=v"(ps1) : "v"(ps1), "v"(p1));
+                }
+            psum = ps0 + ps1;
+        }
         if (__any(m_new > m)) {  // wave-uniform: the running max rarely moves after the first tiles
             const float alpha = __builtin_amdgcn_exp2f(m - m_new);
             l *= alpha;
@@ -1042,8 +1069,13 @@ extern "C" int wipa_flash_attn_enc_bf16(const void* qk, int64_t ldqk, const void
     static const int q128 = [] { const char* e = getenv("WIPA_FLASH_Q128"); return e ? atoi(e) : 0; }();
     const int nw = (T > 256 && !q128) ? 8 : 4;
     dim3 grid((T + nw * 32 - 1) / (nw * 32), H, B);
-    hipLaunchKernelGGL(flash_enc_bf16_kernel, grid, dim3(nw * 64), 0, (hipStream_t)stream, (const __bf16*)qk, ldqk,
-                       (const __bf16*)vt, ldvt, (__bf16*)out, ldo, H, T);
+    static const int pk = [] { const char* e = getenv("WIPA_FLASH_PK"); return e ? atoi(e) : 1; }();
+    if (pk)
+        hipLaunchKernelGGL(flash_enc_bf16_kernel<true>, grid, dim3(nw * 64), 0, (hipStream_t)stream, (const __bf16*)qk, ldqk,
+                           (const __bf16*)vt, ldvt, (__bf16*)out, ldo, H, T);
+    else
+        hipLaunchKernelGGL(flash_enc_bf16_kernel<false>, grid, dim3(nw * 64), 0, (hipStream_t)stream, (const __bf16*)qk, ldqk,
+                           (const __bf16*)vt, ldvt, (__bf16*)out, ldo, H, T);
     WIPA_LAUNCH_CHECK();
     return WIPA_OK;
 }
@@ -1094,9 +1126,17 @@ extern "C" int wipa_decode_attn(const wipa_attn_desc* d, wipa_stream_t stream) {
                  "wipa_decode_attn: strides must keep 16-byte alignment");
     AttnParams p;
     fill_attn_params(d, p);
-    // short caches (the growing self-attention cache, <= n_text_ctx keys): one wave per head; long ones: 4 waves
+    // short caches (the growing self-attention cache, <= n_text_ctx keys): default-policy loads, and four waves per head
+    // (WIPA_SELF_ATTN_WAVES=1: the one-wave-per-head form of rounds 1-3); long ones (cached cross K / V): 4 waves, nt loads
     const bool short_cache = d->Tk + (d->tk_dev ? 448 : 0) <= 512;
-    if (short_cache) {
+    static const int self_waves = [] { const char* e = getenv("WIPA_SELF_ATTN_WAVES"); return e ? atoi(e) : 4; }();
+    if (short_cache && self_waves == 4) {
+        dim3 grid(d->H, d->B);
+        if (d->dtype == WIPA_F32)
+            hipLaunchKernelGGL((decode_attn_kernel<float, 4, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else
+            hipLaunchKernelGGL((decode_attn_kernel<__bf16, 4, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    } else if (short_cache) {
         dim3 grid((d->H + 3) / 4, d->B);
         if (d->dtype == WIPA_F32)
             hipLaunchKernelGGL((decode_attn_kernel<float, 1>), grid, dim3(256), 0, (hipStream_t)stream, p);

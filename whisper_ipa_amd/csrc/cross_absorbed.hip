@@ -635,12 +635,18 @@ __global__ __launch_bounds__(64 * MergeCfg<D>::NWM) void cross_merge_proj_kernel
     constexpr int NTO = D / 16;                       // column tiles of the out projection
     constexpr int NTOW = (NTO + NWM - 1) / NWM;       // per wave (6 for d = 768)
     __shared__ __attribute__((aligned(16))) float red[NWM][CL][64 + 4];
+    __shared__ float dbg_ml[SINGLE == 5 ? CL : 1][8];
     __shared__ float ws_single[SINGLE ? CL : 1][4];  // SINGLE: 1 = as the compiler builds it (SCALAR loads of the partials), 2 = the
                                                      // same section with the index laundered through a vector register (VECTOR loads)
     __shared__ __attribute__((aligned(16))) __bf16 vh[OUTP ? CL : 1][64 + 8];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int h = blockIdx.x, b0 = blockIdx.y * CL;
+    if constexpr (SINGLE == 7) {  // poison WITHOUT a barrier: wave 1 marks the weight words at the very start of the kernel; thread 0
+                                  // overwrites them microseconds later (it waits for memory first).  A NaN in the output = a reader
+                                  // that saw the words as they were BEFORE thread 0's write, i.e. a read that overtook the write.
+        if (tid >= 64 && tid < 64 + CL * 4) ws_single[(tid - 64) >> 2][tid & 3] = __builtin_nanf("");
+    }
     // this lane's clip (A rows): only CL of the tile's 16 rows are distinct clips -- the others repeat them (same addresses, one
     // fetch) and their results are dropped; rows past B are clamped the same way
     const int bc = min(b0 + (l15 & (CL - 1)), B - 1);
@@ -687,9 +693,14 @@ __global__ __launch_bounds__(64 * MergeCfg<D>::NWM) void cross_merge_proj_kernel
     // determinism test)
     float ws[4];
     if constexpr (SINGLE) {
+        if constexpr (SINGLE == 3) {  // poison run: a DIFFERENT wave fills the weights with NaN first; a NaN in the output = a read that
+                                      // overtook thread 0's write
+            if (tid >= 64 && tid < 64 + CL * 4) ws_single[(tid - 64) >> 2][tid & 3] = __builtin_nanf("");
+            __syncthreads();
+        }
         if (tid == 0) {
             int launder = 0;
-            if constexpr (SINGLE == 2) asm volatile("" : "+v"(launder));  // a value the compiler cannot prove uniform: global_load, not s_load
+            if constexpr (SINGLE >= 2) asm volatile("" : "+v"(launder));  // a value the compiler cannot prove uniform: global_load, not s_load
             for (int cl = 0; cl < CL; ++cl) {
                 const int bq = min(b0 + cl, B - 1) + launder;
                 float mm[4], ll[4], M = NEG_BIG, Lsum = 0.f;
@@ -707,9 +718,31 @@ __global__ __launch_bounds__(64 * MergeCfg<D>::NWM) void cross_merge_proj_kernel
                 for (int s = 0; s < 4; ++s) ws_single[cl][s] = mm[s] * inv;
             }
         }
-        __syncthreads();
+        if constexpr (SINGLE == 5) {  // dump run: thread 0 also records the 16 + 16 statistics it loaded
+            if (tid == 0) {
+                for (int cl = 0; cl < CL; ++cl)
+                    for (int s = 0; s < 4; ++s) {
+                        const int bq = min(b0 + cl, B - 1);
+                        dbg_ml[cl][s] = part_m[((int64_t)bq * n_splits + min(s, n_splits - 1)) * 16 + h];
+                        dbg_ml[cl][4 + s] = part_l[((int64_t)bq * n_splits + min(s, n_splits - 1)) * 16 + h];
+                    }
+            }
+        }
+        if constexpr (SINGLE == 4) {  // an explicit full drain + raw barrier instead of __syncthreads()
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else {
+            __syncthreads();
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) ws[s] = ws_single[l15 & (CL - 1)][s];
+        if constexpr (SINGLE == 6) {
+            // the FULL kernel, plus: the weights as EVERY wave's lanes (l15 = clip, lane group 0) got them go to the never-read rows of
+            // the padded heads in part_o (head 12 + wave / 2 of split 0, floats [wave & 1][h][4])
+            if (g == 0 && l15 < CL && b0 + l15 < B) {
+                float* dbg = const_cast<float*>(part_o) + (((int64_t)(b0 + l15) * n_splits + 0) * 16 + 12 + (w >> 1)) * D + (w & 1) * 64 + h * 4;
+                for (int s = 0; s < 4; ++s) dbg[s] = ws[s];
+            }
+        }
     } else {
         float M = NEG_BIG;
 #pragma unroll
@@ -724,6 +757,29 @@ __global__ __launch_bounds__(64 * MergeCfg<D>::NWM) void cross_merge_proj_kernel
         const float inv = 1.0f / Lsum;
 #pragma unroll
         for (int s = 0; s < 4; ++s) ws[s] *= inv;
+    }
+    if constexpr (SINGLE == 5) {
+        // out rows b0 .. b0+3, columns h*64 ..: per clip 32 floats = [ws as lane (wave 3, l15 = cl) read it: 4][ws_single re-read by
+        // thread 0: 4][m: 4][l: 4][zeros]; the kernel then stops (no projection)
+        float* o32 = reinterpret_cast<float*>(out);
+        if (w == 3 && g == 0 && l15 < CL && b0 + l15 < B) {
+            float* dst = o32 + ((int64_t)(b0 + l15) * o_rs + h * 64) / 2;
+            for (int s = 0; s < 4; ++s) dst[s] = ws[s];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int cl = 0; cl < CL; ++cl) {
+                if (b0 + cl >= B) break;
+                float* dst = o32 + ((int64_t)(b0 + cl) * o_rs + h * 64) / 2;
+                for (int s = 0; s < 4; ++s) {
+                    dst[4 + s] = ws_single[cl][s];
+                    dst[8 + s] = dbg_ml[cl][s];
+                    dst[12 + s] = dbg_ml[cl][4 + s];
+                }
+                for (int s = 16; s < 32; ++s) dst[s] = 0.f;
+            }
+        }
+        return;
     }
     f32x4 acc[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -1100,6 +1156,21 @@ extern "C" int wipa_cross_absorbed_attention(const void* q, int64_t q_row_stride
             else if (merge_single() == 2)                                                                                                  \
                 hipLaunchKernelGGL((cross_merge_proj_kernel<D, 2>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o, S,     \
                                    (const __bf16*)wv, bv, (__bf16*)out, out_row_stride, B);                                                \
+            else if (merge_single() == 3)                                                                                                  \
+                hipLaunchKernelGGL((cross_merge_proj_kernel<D, 3>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o, S,     \
+                                   (const __bf16*)wv, bv, (__bf16*)out, out_row_stride, B);                                                \
+            else if (merge_single() == 4)                                                                                                  \
+                hipLaunchKernelGGL((cross_merge_proj_kernel<D, 4>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o, S,     \
+                                   (const __bf16*)wv, bv, (__bf16*)out, out_row_stride, B);                                                \
+            else if (merge_single() == 7)                                                                                                  \
+                hipLaunchKernelGGL((cross_merge_proj_kernel<D, 7>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o, S,     \
+                                   (const __bf16*)wv, bv, (__bf16*)out, out_row_stride, B);                                                \
+            else if (merge_single() == 6)                                                                                                  \
+                hipLaunchKernelGGL((cross_merge_proj_kernel<D, 6>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o, S,     \
+                                   (const __bf16*)wv, bv, (__bf16*)out, out_row_stride, B);                                                \
+            else if (merge_single() == 5)                                                                                                  \
+                hipLaunchKernelGGL((cross_merge_proj_kernel<D, 5>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o, S,     \
+                                   (const __bf16*)wv, bv, (__bf16*)out, out_row_stride, B);                                                \
             else                                                                                                                           \
                 hipLaunchKernelGGL((cross_merge_proj_kernel<D>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o, S,        \
                                    (const __bf16*)wv, bv, (__bf16*)out, out_row_stride, B);                                                \
@@ -1167,7 +1238,9 @@ static int absorbed_block(const wipa_cross_block_desc* c, const void* wkT, const
     p.Tk = Tk; p.n_splits = S; p.H = H;
     const int tiles = (Tk + FT - 1) / FT;
     p.tiles_per_split = (tiles + S - 1) / S;
-    static const int cg = [] { const char* e = getenv("WIPA_ABS_PROLOGUE_CLIPS"); return e ? atoi(e) : 16; }();  // A/B: 8 or 16
+    // clips per prologue workgroup: 8 (default since round 4: H x B / 8 = 96 workgroups at 64 clips; a lone decode step 1.304 vs
+    // 1.338 ms, the pipelined pass unchanged) or 16 (WIPA_ABS_PROLOGUE_CLIPS=16: every MFMA row a clip, 48 workgroups)
+    static const int cg = [] { const char* e = getenv("WIPA_ABS_PROLOGUE_CLIPS"); return e ? atoi(e) : 8; }();
     const dim3 gp(H, cg == 8 ? (B + 7) / 8 : (B + 15) / 16), gm(H, (B + WIPA_MERGE_CL - 1) / WIPA_MERGE_CL);
     int rc = WIPA_OK;
 #define ABS_BLOCK(D)                                                                                                                       \

@@ -445,13 +445,15 @@ __global__ __launch_bounds__(GS_THREADS) void greedy_tail_kernel(TailParams q) {
     __shared__ int s_i[GS_THREADS / 64];
     __shared__ float s_sum[GS_THREADS / 64];
     __shared__ float s_red[4];
-    __shared__ int s_next;
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int p = *q.pos;
     const int V = q.V;
+    // `next` is computed by EVERY thread from values all of them hold (no single-thread section that hands a value to the
+    // workgroup through LDS: the pattern whose merge-kernel instance misbehaved); thread 0 alone writes
+    int next;
     if (p + 1 < q.n_init) {  // prompt walk: the token is already in place (uniform branch: p is the same for every thread)
-        if (tid == 0) s_next = q.tokens[(int64_t)b * q.ld_tok + p + 1];
+        next = q.tokens[(int64_t)b * q.ld_tok + p + 1];
     } else {
         const float* mask = (p + 1 == q.n_init) ? q.mask_first : q.mask_always;
         const float* row = q.logits + (int64_t)b * q.ldl;
@@ -493,32 +495,24 @@ __global__ __launch_bounds__(GS_THREADS) void greedy_tail_kernel(TailParams q) {
         se = wave_reduce_sum(se);
         if (lane == 0) s_sum[wave] = se;
         __syncthreads();
+        const int prev = q.tokens[(int64_t)b * q.ld_tok + p];
+        next = (prev == q.eot) ? q.eot : bm.i;
         if (tid == 0) {
             float tot = 0.f;
 #pragma unroll
             for (int w = 0; w < GS_THREADS / 64; ++w) tot += s_sum[w];
-            const int prev = q.tokens[(int64_t)b * q.ld_tok + p];
-            int next = bm.i;
-            if (prev == q.eot) {
-                next = q.eot;
-            } else {
-                q.sum_logprobs[b] += -logf(tot);
-            }
+            if (prev != q.eot) q.sum_logprobs[b] += -logf(tot);
             q.tokens[(int64_t)b * q.ld_tok + p + 1] = next;
             if (next != q.eot) atomicAdd(q.not_done, 1);
-            s_next = next;
         }
     }
-    __syncthreads();
-    const int next = s_next;
     // the next step's input row: embedding of the chosen token at position p + 1, then the first block's LayerNorm
     row_embed_layernorm<TO>(tid, next, min(p + 1, q.n_ctx - 1), q.emb, q.emb_dtype, q.emb_scale, q.pos_emb, q.x + (int64_t)b * q.D, q.ln_w,
                             q.ln_b, (TO*)q.y + (int64_t)b * q.D, q.D, q.eps, s_red);
     // position advance by the LAST workgroup: every thread of every workgroup read *pos at its start and has used it before
     // its workgroup's barrier above, i.e. before its counter increment -- no workgroup can still see the old position late
     if (tid == 0) {
-        __threadfence();
-        const int arrived = atomicAdd(q.done_counter, 1);
+        const int arrived = atomicAdd(q.done_counter, 1);  // counts arrivals only: what the step wrote reaches the next launch at the kernel boundary
         if (arrived == (int)gridDim.x - 1) {
             *q.done_counter = 0;
             *q.pos = p + 1;

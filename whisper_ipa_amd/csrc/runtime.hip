@@ -376,10 +376,14 @@ bool absorbed_block_fused() {
     return !(e && atoi(e) == 0);
 }
 
-// WIPA_ABS_MERGE_OUT=0 keeps the cross-attention out projection of the absorbed block as its own split-K GEMM (A/B runs)
+// WIPA_ABS_MERGE_OUT=1 folds the cross-attention out projection of the absorbed block into its merge launch (one slab per head,
+// wipa_decode_cross_absorbed_block_out).  Built, parity-tested and NOT the default: measured r04 (whisper-small, 64 clips, MI355X)
+// the fused launch takes 17.0 us where merge 10.5 + out-projection GEMM 4.9 take 15.4 -- its 192 workgroups pull the head's
+// Wo slice (98 KB) on top of the Wv slice through the same per-CU load path and write 12 slabs instead of 2 -- decode step
+// 1.338 vs 1.306 ms, pipelined pass 78.2 vs 75.0 ms.  A launch in a replayed graph costs ~1.6 us; 98 KB more per workgroup costs 2.
 bool absorbed_merge_out() {
     const char* e = getenv("WIPA_ABS_MERGE_OUT");
-    return !(e && atoi(e) == 0);
+    return e && atoi(e) == 1;
 }
 // WIPA_DECODE_TAIL=0 keeps the separate greedy_step / advance_pos / embed / first-LayerNorm launches (A/B runs, part of the graph
 // key); default: ONE launch, wipa_greedy_step_embed, ends a step and prepares the next one's input rows
