@@ -1,6 +1,8 @@
 #!/bin/bash
 # Round-4 measurement pass on the GPU box (run through gpurun from the repo root), in two calls to stay inside one call's limit:
-#   bash tools/r04_gpu_profile.sh a     # default bench, kernel traces, counters of the dominant kernel / encoder GEMMs / log-mel  (a1: the first half only)
+#   bash tools/r04_gpu_profile.sh a1    # default bench, kernel traces, counters of the dominant kernels
+#   bash tools/r04_gpu_profile.sh a2    # encoder GEMM counters, log-mel, cached-K/V comparison runs
+#   bash tools/r04_gpu_profile.sh a3    # cached vs absorbed over output lengths and batch sizes (tools/r04_cross_sweep.sh)
 #   bash tools/r04_gpu_profile.sh b     # fine-tune step, sizing runs
 # Everything lands under gpurun_out/r04/; tools/r04_summaries.py turns it into the committed summaries under profiles/.
 set -o pipefail
@@ -9,7 +11,13 @@ OUT=$ROOT/gpurun_out/r04
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B="python3 $ROOT/bench.py --no-cpu-baseline --no-finetune"
-if [ "$1" = "a" ] || [ "$1" = "a1" ]; then
+if [ "$1" = "a3" ]; then
+echo "== cached vs absorbed over output lengths and batch sizes"
+bash $ROOT/tools/r04_cross_sweep.sh || exit 1
+echo "== done a3"; exit 0
+fi
+if [ "$1" = "a" ] || [ "$1" = "a1" ] || [ "$1" = "a2" ]; then
+if [ "$1" != "a2" ]; then
 echo "== default bench"; python3 $ROOT/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err || exit 1
 echo "== kernel trace of the default bench command"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o bench -- python3 $ROOT/bench.py --no-cpu-baseline --no-finetune --steps 6 > $OUT/kt.log 2>&1 || exit 1
@@ -24,6 +32,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_x1 -- 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_x2 -- python3 $ROOT/tools/pmc_cross_absorbed.py > $OUT/pmc_x2.log 2>&1 || exit 1
 python3 $ROOT/tools/pmc_cross_absorbed.py > $OUT/pmc_x_timing.log 2>&1 || exit 1
 if [ "$1" = "a1" ]; then echo "== done a1"; cat $OUT/bench_default.json; exit 0; fi
+fi
 echo "== counters: encoder GEMMs"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/pmc_g1 -- python3 $ROOT/tools/pmc_gemm.py > $OUT/pmc_g1.log 2>&1 || exit 1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d $OUT/pmc_g2 -- python3 $ROOT/tools/pmc_gemm.py > $OUT/pmc_g2.log 2>&1 || exit 1
@@ -40,9 +49,11 @@ $B --cross-attention cached > $OUT/bench_cached.json 2> /dev/null || exit 1
 $B --cross-attention cached --new-tokens 224 --steps 6 > $OUT/bench_cached_n224.json 2> /dev/null || exit 1
 $B --new-tokens 224 --steps 6 > $OUT/size_small_n224.json 2> /dev/null || exit 1   # cross_attention=auto: picks cached K / V here (64 clips, >= 192 new tokens)
 $B --cross-attention absorbed --new-tokens 224 --steps 6 > $OUT/size_small_n224_absorbed.json 2> /dev/null || exit 1
+if [ "$1" = "a" ]; then
 echo "== cached vs absorbed over output lengths and batch sizes"
 bash $ROOT/tools/r04_cross_sweep.sh || exit 1
-echo "== done a"; cat $OUT/bench_default.json
+fi
+echo "== done $1"
 else
 echo "== fine-tune step"
 python3 $ROOT/bench.py --mode train --steps 5 --warmup 1 > $OUT/train_exact.json 2> $OUT/train_exact.err || exit 1
