@@ -398,7 +398,7 @@ def roofline_cross_attn(model, B: int, iters: int = 48):
     # quoted when it was collected for exactly this launch shape.
     traffic = None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_cross_block.json" if fused else "r01_pmc_cross_attn.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_cross_block.json" if fused else "r01_pmc_cross_attn.json")))
         if pm.get("algorithmic_bytes_per_launch") == bytes_alg:
             traffic = pm["hbm_bytes_per_launch"]
     except Exception:
@@ -478,7 +478,7 @@ def roofline_cross_absorbed(model, B: int, st, iters: int = 48):
     achieved = bytes_alg / (ms * 1e-3) / 1e9
     traffic = None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_cross_absorbed.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_cross_absorbed.json")))
         if pm.get("algorithmic_bytes_per_launch") == bytes_alg:
             traffic = pm["hbm_bytes_per_launch"]
     except Exception:
@@ -497,7 +497,7 @@ def roofline_cross_absorbed(model, B: int, st, iters: int = 48):
                               "GB/s": round(kv_bytes / (ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(kv_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
 
 
-def roofline_mfma(model, audio, pmc_file: str = "r03_pmc_encoder_gemm.json"):
+def roofline_mfma(model, audio, pmc_file: str = "r04_pmc_encoder_gemm.json"):
     """The MFMA-bound kernel set: every GEMM / conv-as-GEMM of one encoder pass plus the cross-K/V projection.
     Algorithmic FLOPs per clip are SURVEY.md App. B's (whisper-small: 261.2 + 42.5 GFLOP); the time is the sum of HIP-event
     spans around each GEMM launch of a real pass on the library stream (wipa_profile_begin / wipa_profile_end)."""

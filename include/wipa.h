@@ -148,8 +148,9 @@ enum {
     WIPA_GEMM_SKINNY_LN = 7, /* ... with the LayerNorm prologue */
     WIPA_GEMM_KMAJOR = 8,    /* a_trans / w_trans operands (128 x 128 kernel) */
     WIPA_GEMM_SPLIT_K = 9,   /* calls with k_slices > 1 (counted in addition to their kernel family) */
-    WIPA_GEMM_TILE_FP8 = 10, /* fp8 x fp8 on v_mfma_scale_f32_16x16x128_f8f6f4 (in_dtype = WIPA_FP8_E4M3) */
-    WIPA_GEMM_DISPATCH_CLASSES = 11
+    WIPA_GEMM_TILE_FP8 = 10, /* fp8 x fp8 on v_mfma_scale_f32_16x16x128_f8f6f4 (in_dtype = WIPA_FP8_E4M3): every such call */
+    WIPA_GEMM_TILE_FP8_384 = 11, /* ... those of them that took the 384 x 256 tile (counted in addition) */
+    WIPA_GEMM_DISPATCH_CLASSES = 12
 };
 int wipa_gemm_dispatch_counts(int64_t* out, int n, int reset);
 

@@ -1056,3 +1056,65 @@ def test_absorbed_cross_block_with_the_out_projection_in_its_third_launch(B, H, 
     assert float((x3.double() - got).abs().max()) < 1e-5 * float(got.abs().max())  # the 16-slab LayerNorm left x + slabs in x
     ref_y = torch.nn.functional.layer_norm(got.float(), (d,), mw, mb, 1e-5)
     assert float((y.float() - ref_y).abs().max()) < 0.03  # bf16 output
+
+def test_gemm_fp8_384x256_tile_in_a_subprocess():
+    """Round 4: gemm_fp8_384_kernel (fp8 x fp8 on the 384 x 256 tile; WIPA_GEMM_FP8_TILE=384 forces it, read once per process).
+    EXACT on small integers with asymmetric operands (a row <-> column swap, a wrong k-group or LDS chunk would show), ragged
+    M / N around the 384-row and 256-column tile edges, several K-steps; then random operands with per-row scales through bias /
+    column scale / GELU / f32 residual / bf16 output against float64 on the dequantised operands; and the same calls give the
+    256 x 256 kernel's bits when the products are exact."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import torch
+from whisper_ipa_amd import ops
+g = torch.Generator().manual_seed(5)
+for M, N, K in ((800, 300, 256), (768, 512, 128), (1153, 70, 640), (385, 257, 384)):
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    W = torch.randint(-3, 4, (N, K), generator=g).float()
+    A[:, 0] = (torch.arange(M) % 5 - 2).float()
+    W[:, 1] = (torch.arange(N) % 7 - 3).float()
+    A[7, :] = (torch.arange(K) % 4).float()
+    a_codes = A.to(torch.float8_e4m3fn).view(torch.uint8).cuda()
+    w_codes = W.to(torch.float8_e4m3fn).view(torch.uint8).cuda()
+    out = torch.full((M, N), 9.0, device="cuda")
+    ops.gemm_fp8(a_codes, torch.ones(M, device="cuda"), w_codes, torch.ones(N, device="cuda"), out)
+    torch.cuda.synchronize()
+    ref = A.double() @ W.double().T
+    assert torch.equal(out.cpu().double(), ref), (M, N, K, float((out.cpu().double() - ref).abs().max()))
+counts = ops.gemm_dispatch_counts(reset=True)
+assert counts["tile_fp8_384"] == 4 and counts["tile_fp8"] == 4, counts
+
+def e4m3(x):
+    from whisper_ipa_amd.whisper import quantize_fp8_e4m3, dequantize_fp8_e4m3
+    c, s = quantize_fp8_e4m3(x)
+    return c, s, dequantize_fp8_e4m3(c, s)
+
+worst = 0.0
+for (M, N, K, act, resid, odt) in [(1000, 768, 768, 0, True, torch.float32), (900, 1536, 768, 0, False, torch.bfloat16),
+                                   (1200, 3072, 768, 1, False, torch.bfloat16), (770, 1280, 5120, 0, True, torch.float32)]:
+    g = torch.Generator().manual_seed(M + N)
+    a_codes, a_scale, A = e4m3(torch.randn(M, K, generator=g) * torch.rand(M, 1, generator=g) * 3)
+    w_codes, w_scale, W = e4m3(torch.randn(N, K, generator=g) * 0.05)
+    bias = torch.randn(N, generator=g) * 0.1
+    res = torch.randn(M, N, generator=g)
+    out = (res.clone() if resid else torch.zeros(M, N)).to(odt).cuda()
+    ops.gemm_fp8(a_codes.cuda(), a_scale.cuda(), w_codes.cuda(), w_scale.cuda(), out, bias=bias.cuda(), act=act,
+                 residual=out if resid else None, col_scale_n=N if not act else 0, col_scale=0.35)
+    torch.cuda.synchronize()
+    ref = A.double() @ W.double().T + bias.double()
+    ref = torch.nn.functional.gelu(ref) if act else ref * 0.35
+    if resid:
+        ref = ref + res.double()
+    err = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
+    assert err < (2e-5 if odt == torch.float32 else 6e-3), (M, N, K, err)
+    worst = max(worst, err)
+assert ops.gemm_dispatch_counts(reset=True)["tile_fp8_384"] == 4
+print("OK", worst)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WIPA_GEMM_FP8_TILE="384", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:] + r.stdout[-500:]

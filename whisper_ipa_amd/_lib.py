@@ -17,7 +17,7 @@ WIPA_F32, WIPA_BF16, WIPA_FP8_E4M3 = 0, 1, 2
 ENC_GLOBAL, ENC_PER_LAYER = 7, 14
 DEC_GLOBAL, DEC_PER_LAYER, DEC_FP8_PER_LAYER = 4, 20, 6
 GEMM_DISPATCH = ("tile128", "tile256", "tile384", "tile384n", "tile256p", "skinny", "skinny_fp8", "skinny_ln", "kmajor", "split_k",
-                 "tile_fp8")
+                 "tile_fp8", "tile_fp8_384")
 ENC_FP8_PER_LAYER = 8
 DEC_ABSORBED_PER_LAYER = 1
 

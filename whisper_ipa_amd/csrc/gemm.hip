@@ -1642,6 +1642,130 @@ __global__ __launch_bounds__(512) void gemm_nt384n_kernel(GemmParams p) {  // 38
     gemm_nt384_body<T, OutT, ACT, SPLIT, 2>(p);
 }
 
+// fp8 x fp8 on the 384 x 256 tile (round 4): gemm_fp8_256_kernel's arithmetic -- one
+// v_mfma_scale_f32_16x16x128_f8f6f4 per 16 x 16 output tile and 128-byte K-step, a fragment = two ds_read_b128 -- in
+// gemm_nt384_body's geometry (8 waves 2 x 4, 192 x 64 per wave, 192 accumulators, (256 + 384) x 128 B = 80 KiB per stage):
+// 1/307 staged byte per FLOP instead of 1/256, and N = 1280 / 5120 grids quantise as for the bf16 kernel.  ACT: bias + GELU on
+// the MFMA layout before the transposing epilogue (compiled without its GELU path, like the bf16 instantiation).
+template <typename OutT, bool ACT>
+__global__ __launch_bounds__(512) void gemm_fp8_384_kernel(GemmParams p) {
+    typedef X384<4> X;
+    constexpr int MT = X::MT, XW_TILE = X::W_TILE, XSTAGE = X::STAGE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][W tile 256 rows | A tile 384 rows]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nblocks = p.tiles_m * p.tiles_n;
+    int id;
+    {
+        const int bid = blockIdx.x;
+        const int q = nblocks >> 3, r = nblocks & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int group_size = GROUP_M * p.tiles_n;
+    const int group = id / group_size;
+    const int first_m = group * GROUP_M;
+    const int gm = min(p.tiles_m - first_m, GROUP_M);
+    const int in_group = id - group * group_size;
+    const int tile_m = first_m + in_group % gm;
+    const int tile_n = in_group / gm;
+    const int m0 = tile_m * XBM, n0 = tile_n * X::BN;
+
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (int64_t)n0 * p.ldw_b), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)m0 * p.lda_b), 0, 0x7fffffff, 0x00020000);
+    int oW[4], oA[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int row = 64 * i + 8 * wave + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        if (i < 4) oW[i] = (min(n0 + row, p.N - 1) - n0) * (int)p.ldw_b + c * 16;
+        oA[i] = (min(m0 + row, p.M - 1) - m0) * (int)p.lda_b + c * 16;
+    }
+    auto stage = [&](int kt, int buf) {
+        const int kb = kt * ROWB;
+        char* base = smem + buf * XSTAGE + wave * (8 * ROWB);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)(base + i * 64 * ROWB), 16, oW[i], kb, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(base + XW_TILE + i * 64 * ROWB), 16, oA[i], kb, 0, 0);
+    };
+    f32x4 acc[4][MT];  // [n tile i][m tile j]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15;
+    const int fsw = (lane >> 1) & 7;
+    const int fq = lane >> 4;
+    const int nk = p.K / ROWB;  // one byte per element
+    const int c0 = ((2 * fq) ^ fsw) << 4, c1 = ((2 * fq + 1) ^ fsw) << 4;
+    auto frag = [&](const char* row) {
+        const v4i32 lo = *reinterpret_cast<const v4i32*>(row + c0);
+        const v4i32 hi = *reinterpret_cast<const v4i32*>(row + c1);
+        return v8i32{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        const char* wb = smem + (kt & 1) * XSTAGE + (wn * 64 + frow) * ROWB;
+        const char* ab = smem + (kt & 1) * XSTAGE + XW_TILE + (wm * (16 * MT) + frow) * ROWB;
+        v8i32 fw[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fw[i] = frag(wb + i * 16 * ROWB);
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const v8i32 fx = frag(ab + j * 16 * ROWB);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fw[i], fx, acc[i][j], 0, 0, 0, 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // dequantisation: acc[i][j][e] is C[m = m0 + wm*192 + 16 j + frow][n = n0 + wn*64 + 16 i + 4 fq + e]
+    {
+        f32x4 ws[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + 16 * i + 4 * fq;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ws[i][e] = p.w_scale[min(n + e, p.N - 1)];
+        }
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const float as = p.a_scale[min(m0 + wm * (16 * MT) + 16 * j + frow, p.M - 1)];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] *= ws[i] * as;
+        }
+    }
+    int64_t coff_dev = p.c_offset;
+    if (p.c_offset_dev) coff_dev += *p.c_offset_dev;
+    // the dispatcher sends only stage_ok outputs here (and an activation only with a plain column bias and no column scale)
+    if constexpr (ACT) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + 16 * i + 4 * fq;
+            float b4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b4[e] = (p.bias && n + e < p.N) ? p.bias[n + e] : 0.f;
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                const f32x2 g0 = gelu_erf2(f32x2{acc[i][j][0] + b4[0], acc[i][j][1] + b4[1]});
+                const f32x2 g1 = gelu_erf2(f32x2{acc[i][j][2] + b4[2], acc[i][j][3] + b4[3]});
+                acc[i][j] = f32x4{g0.x, g0.y, g1.x, g1.y};
+                __builtin_amdgcn_sched_barrier(0);  // one tile at a time (see gemm_nt384_body)
+            }
+        }
+        p.bias = nullptr;
+    }
+    epilogue_staged<OutT, MT, 0, MT, false, !ACT>(p, acc, smem + wave * 4096, m0 + wm * (16 * MT), n0 + wn * 64, coff_dev, lane);
+}
+
 template <typename T, typename OutT>
 int launch384(GemmParams p, hipStream_t s) {
     typedef X384<4> X;
@@ -1718,6 +1842,17 @@ int launch_fp8_256(GemmParams p, hipStream_t s) {
     return WIPA_OK;
 }
 
+template <typename OutT>
+int launch_fp8_384(GemmParams p, hipStream_t s) {
+    typedef X384<4> X;
+    p.tiles_m = (p.M + XBM - 1) / XBM;
+    p.tiles_n = (p.N + X::BN - 1) / X::BN;
+    if (p.act == 1) hipLaunchKernelGGL((gemm_fp8_384_kernel<OutT, true>), dim3(p.tiles_m * p.tiles_n), dim3(512), X::SMEM, s, p);
+    else hipLaunchKernelGGL((gemm_fp8_384_kernel<OutT, false>), dim3(p.tiles_m * p.tiles_n), dim3(512), X::SMEM, s, p);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
 constexpr int SMEM_BYTES = 4 * TILE_BYTES;  // 64 KiB
 
 // Raise the dynamic-LDS limit of every instantiation once, outside any stream capture.
@@ -1780,6 +1915,14 @@ int init_attrs() {
                               reinterpret_cast<const void*>(&gemm_fp8_256_kernel<float>)};
         for (const void* f : f8k) {
             const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LSMEM);
+            if (e != hipSuccess) err = e;
+        }
+        const void* f8w[4] = {reinterpret_cast<const void*>(&gemm_fp8_384_kernel<__bf16, false>),
+                              reinterpret_cast<const void*>(&gemm_fp8_384_kernel<float, false>),
+                              reinterpret_cast<const void*>(&gemm_fp8_384_kernel<__bf16, true>),
+                              reinterpret_cast<const void*>(&gemm_fp8_384_kernel<float, true>)};
+        for (const void* f : f8w) {
+            const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, X384<4>::SMEM);
             if (e != hipSuccess) err = e;
         }
         const void* lnk[9] = {reinterpret_cast<const void*>(&gemm_skinny_ln_kernel<__bf16, __bf16, 1>),
@@ -1878,6 +2021,19 @@ static int gemm_fp8(const wipa_gemm_desc* d, wipa_stream_t stream) {
     const int rc = init_attrs();
     if (rc != WIPA_OK) return rc;
     count_dispatch(WIPA_GEMM_TILE_FP8);
+    // 384 x 256 tile (round 4) under the bf16 kernels' rule: big row counts, a staged epilogue, an activation only with a plain
+    // column bias, and a grid that fills the 256 CUs at least 0.95 x as well as the 256 x 256 one.  WIPA_GEMM_FP8_TILE=256 / 384 forces.
+    static const int force_f8 = [] { const char* e = getenv("WIPA_GEMM_FP8_TILE"); return e ? atoi(e) : 0; }();
+    const bool act384_ok = d->act == 0 || (!d->bias_along_m && d->col_scale_n == 0);
+    bool use384 = false;
+    if (p.stage_ok && act384_ok && force_f8 != 256 && d->M >= 2 * XBM) {
+        auto fill = [](int64_t tiles) { const int64_t rounds = (tiles + 255) / 256; return (double)tiles / (double)(rounds * 256); };
+        const double e256 = fill((int64_t)((d->M + LBM - 1) / LBM) * ((d->N + LBN - 1) / LBN));
+        const double e384 = fill((int64_t)((d->M + XBM - 1) / XBM) * ((d->N + LBN - 1) / LBN));
+        use384 = force_f8 == 384 || e384 >= 0.95 * e256;
+    }
+    if (use384) count_dispatch(WIPA_GEMM_TILE_FP8_384);
+    if (use384) return d->out_dtype == WIPA_BF16 ? launch_fp8_384<__bf16>(p, (hipStream_t)stream) : launch_fp8_384<float>(p, (hipStream_t)stream);
     return d->out_dtype == WIPA_BF16 ? launch_fp8_256<__bf16>(p, (hipStream_t)stream) : launch_fp8_256<float>(p, (hipStream_t)stream);
 }
 

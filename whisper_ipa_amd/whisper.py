@@ -133,8 +133,8 @@ class Whisper:
         applies, except long outputs at a small batch (<= 64 clips with >= 192 new tokens -- the reference's own default
         sample_len of 224 at the benchmark batch), where cached K / V is faster; WIPA_CROSS_ABSORB=0 turns absorbed off.
         Same mathematics, other bf16 rounding points.  Measured on MI355X, absorbed against cached:
-        whisper-small, 64 clips: +5.5 % at 32, +6.0 % at 64, +3.8 % at 128, -4.6 % at 224 new tokens; 128 clips: +10.2 % / +3.0 % at
-        64 / 224; whisper-medium, 256 clips: +5.8 % / +4.0 %.  The choice is
+        whisper-small, 64 clips: +5.3 % at 32, +7.0 % at 64, +4.5 % at 128, -3.1 % at 224 new tokens; 128 clips: +8.5 % / +3.6 % at
+        64 / 224; whisper-medium, 256 clips: +1.1 % at 224 (profiles/r04_cached_vs_absorbed.txt).  The choice is
         explicit here and in the CPU checker, and both settings are pinned by golden fixtures (tests/golden/wide_model.npz)."""
         if cross_attention not in ("auto", "absorbed", "cached"):
             raise _lib.WipaError(f"cross_attention must be 'auto', 'absorbed' or 'cached', got {cross_attention!r}")
@@ -297,9 +297,9 @@ class Whisper:
         self._packed_tf = None
         self._packed_abs = None
 
-    # "auto" by the measured table (profiles/r03_cached_vs_absorbed.txt, MI355X, 4 passes in flight; absorbed against cached):
-    # whisper-small 64 clips: +5.5 % at 32 new tokens, +6.0 % at 64, +3.8 % at 128, -4.6 % at 224; 128 clips: +10.2 % / +3.0 %
-    # at 64 / 224; whisper-medium 256 clips: +5.8 % / +4.0 %.  The one losing regime is long outputs at a small batch (every
+    # "auto" by the measured table (profiles/r04_cached_vs_absorbed.txt, MI355X, 4 passes in flight; absorbed against cached):
+    # whisper-small 64 clips: +5.3 % at 32 new tokens, +7.0 % at 64, +4.5 % at 128, -3.1 % at 224; 128 clips: +8.5 % / +3.6 %
+    # at 64 / 224; whisper-medium 256 clips: +1.1 % at 224 (r03: +5.8 % at 64).  The one losing regime is long outputs at a small batch (every
     # pass in flight sits in its decode loop and the absorbed step has two more launches per layer), and 224 = n_text_ctx // 2 is
     # what the reference's callers get by default (scripts/transcribe_single.py:49-52 leaves sample_len unset).
     AUTO_CACHED_MAX_BATCH = 64
