@@ -2021,8 +2021,11 @@ static int gemm_fp8(const wipa_gemm_desc* d, wipa_stream_t stream) {
     const int rc = init_attrs();
     if (rc != WIPA_OK) return rc;
     count_dispatch(WIPA_GEMM_TILE_FP8);
-    // 384 x 256 tile (round 4) under the bf16 kernels' rule: big row counts, a staged epilogue, an activation only with a plain
-    // column bias, and a grid that fills the 256 CUs at least 0.95 x as well as the 256 x 256 one.  WIPA_GEMM_FP8_TILE=256 / 384 forces.
+    // 384 x 256 tile (round 4): big row counts, a staged epilogue, an activation only with a plain column bias, a grid that fills
+    // the 256 CUs at least 0.95 x as well as the 256 x 256 one, and a LONG contraction -- measured on the whisper-large-v3 shapes
+    // at M = 96 000 (profiles/r04_fp8_tile_ab.txt): K = 5120 1 554 -> 1 644 TF/s, but K = 1280 1 498 -> 1 475 (q|k) and
+    // 1 362 -> 1 336 (mlp1 + GELU): ten K-steps do not pay for the longer prologue and the 192-accumulator epilogue.
+    // WIPA_GEMM_FP8_TILE=256 / 384 forces.
     static const int force_f8 = [] { const char* e = getenv("WIPA_GEMM_FP8_TILE"); return e ? atoi(e) : 0; }();
     const bool act384_ok = d->act == 0 || (!d->bias_along_m && d->col_scale_n == 0);
     bool use384 = false;
@@ -2030,7 +2033,7 @@ static int gemm_fp8(const wipa_gemm_desc* d, wipa_stream_t stream) {
         auto fill = [](int64_t tiles) { const int64_t rounds = (tiles + 255) / 256; return (double)tiles / (double)(rounds * 256); };
         const double e256 = fill((int64_t)((d->M + LBM - 1) / LBM) * ((d->N + LBN - 1) / LBN));
         const double e384 = fill((int64_t)((d->M + XBM - 1) / XBM) * ((d->N + LBN - 1) / LBN));
-        use384 = force_f8 == 384 || e384 >= 0.95 * e256;
+        use384 = force_f8 == 384 || (e384 >= 0.95 * e256 && d->K >= 2048);
     }
     if (use384) count_dispatch(WIPA_GEMM_TILE_FP8_384);
     if (use384) return d->out_dtype == WIPA_BF16 ? launch_fp8_384<__bf16>(p, (hipStream_t)stream) : launch_fp8_384<float>(p, (hipStream_t)stream);
