@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Root-cause aid (round 4): the merge kernel's single-thread weight section (WIPA_MERGE_SINGLE=1 scalar loads / 2 vector loads)
+"""Root-cause aid (round 4; needs a library built with WIPA_EXTRA_HIPCC_FLAGS=-DWIPA_MERGE_VARIANTS): the merge kernel's single-thread weight section (WIPA_MERGE_SINGLE=1 scalar loads / 2 vector loads)
 under four streams in flight.  On a mismatch, say WHAT differs: the split partials the streaming kernel wrote (producer side) or
 only the merge output, which (clip, head) blocks, and what the wrong values look like.
 usage: WIPA_MERGE_SINGLE=1 python tools/merge_single_diag.py"""

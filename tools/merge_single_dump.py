@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Root-cause aid (round 4), WIPA_MERGE_SINGLE=5: the merge kernel's single-thread section DUMPS, per (head, clip): the split weights
+"""Root-cause aid (round 4; needs a library built with WIPA_EXTRA_HIPCC_FLAGS=-DWIPA_MERGE_VARIANTS), WIPA_MERGE_SINGLE=5: the merge kernel's single-thread section DUMPS, per (head, clip): the split weights
 as a lane of another wave read them from LDS, the same LDS words re-read by thread 0, and the (m, l) statistics thread 0 loaded.
 The host recomputes the weights from the statistics the STREAMING kernel left in the scratch and says which stage is off."""
 import os

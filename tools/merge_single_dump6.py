@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Root-cause aid (round 4), WIPA_MERGE_SINGLE=6: the FULL merge kernel with the single-thread section; every wave also stores the
+"""Root-cause aid (round 4; needs a library built with WIPA_EXTRA_HIPCC_FLAGS=-DWIPA_MERGE_VARIANTS), WIPA_MERGE_SINGLE=6: the FULL merge kernel with the single-thread section; every wave also stores the
 split weights it read from LDS into never-read scratch rows.  For every launch whose output differs from the all-lanes kernel's
 bits (DIAG_BASE, made by tools/merge_single_diag.py with WIPA_MERGE_SINGLE=0), say whether the weights of the differing
 (clip, head) workgroups were right in every wave."""

@@ -1,5 +1,7 @@
 #!/bin/bash
-# root-cause runs of the merge kernel's single-thread section (round 4); each python process is bounded
+# root-cause runs of the merge kernel's single-thread section (round 4); each python process is bounded.
+# Needs the diagnostic build: WIPA_EXTRA_HIPCC_FLAGS=-DWIPA_MERGE_VARIANTS python -c "import __graft_entry__ as g; g.build(force=True)"
+# (the shipped library has the every-lane kernel only and ignores WIPA_MERGE_SINGLE).
 O=gpurun_out/r4_rootcause; mkdir -p $O
 WIPA_MERGE_SINGLE=0 DIAG_SAVE=$O/base.pt timeout -k 10 120 python tools/merge_single_diag.py > $O/v0.log 2>&1
 for v in 2 3 4; do

@@ -1029,8 +1029,8 @@ int launch_attn(const AbsParams& p_in, int B, hipStream_t s) {
 
 }  // namespace
 
-// the single-thread-section variants of the merge kernel (root-cause runs of round 4; never the default): 1 scalar loads, 2 vector loads
-static int merge_single() {
+// the single-thread-section variants of the merge kernel (root-cause runs of round 4; -DWIPA_MERGE_VARIANTS builds only)
+[[maybe_unused]] static int merge_single() {
     static const int v = [] { const char* e = getenv("WIPA_MERGE_SINGLE"); return e ? atoi(e) : 0; }();
     return v;
 }
@@ -1144,36 +1144,28 @@ extern "C" int wipa_cross_absorbed_attention(const void* q, int64_t q_row_stride
     int rc = WIPA_OK;
     const char* st_env = getenv("WIPA_ABS_STAGES");  // debugging: bit 0 absorb-q, bit 1 stream, bit 2 merge (default all)
     const int stages = st_env ? atoi(st_env) : 7;
+    // The root-cause variants of the merge kernel exist only in a build with -DWIPA_MERGE_VARIANTS
+    // (WIPA_EXTRA_HIPCC_FLAGS=-DWIPA_MERGE_VARIANTS python -c "import __graft_entry__ as g; g.build(force=True)"); WIPA_MERGE_SINGLE=1..7
+    // then selects one.  The shipped library has the every-lane kernel only.
+#ifdef WIPA_MERGE_VARIANTS
+#define ABS_MERGE_ONE(D, V)                                                                                                                \
+    if (merge_single() == V)                                                                                                               \
+        hipLaunchKernelGGL((cross_merge_proj_kernel<D, V>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o, S,             \
+                           (const __bf16*)wv, bv, (__bf16*)out, out_row_stride, B);                                                        \
+    else
+#define ABS_MERGE_VARIANTS(D) ABS_MERGE_ONE(D, 1) ABS_MERGE_ONE(D, 2) ABS_MERGE_ONE(D, 3) ABS_MERGE_ONE(D, 4) ABS_MERGE_ONE(D, 5) ABS_MERGE_ONE(D, 6) ABS_MERGE_ONE(D, 7)
+#else
+#define ABS_MERGE_VARIANTS(D)
+#endif
 #define ABS_RUN(D)                                                                                                                         \
     do {                                                                                                                                   \
         if (stages & 1)                                                                                                                    \
             hipLaunchKernelGGL((cross_absorb_q_kernel<D>), gq, dim3(64), 0, s, (const __bf16*)q, q_row_stride, (const __bf16*)wkT, qp, B, H, k_scale); \
         if (stages & 2) rc = launch_attn<D>(p, B, s);                                                                                      \
         if (rc == WIPA_OK && (stages & 4)) {                                                                                               \
-            if (merge_single() == 1)                                                                                                       \
-                hipLaunchKernelGGL((cross_merge_proj_kernel<D, 1>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o, S,     \
-                                   (const __bf16*)wv, bv, (__bf16*)out, out_row_stride, B);                                                \
-            else if (merge_single() == 2)                                                                                                  \
-                hipLaunchKernelGGL((cross_merge_proj_kernel<D, 2>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o, S,     \
-                                   (const __bf16*)wv, bv, (__bf16*)out, out_row_stride, B);                                                \
-            else if (merge_single() == 3)                                                                                                  \
-                hipLaunchKernelGGL((cross_merge_proj_kernel<D, 3>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o, S,     \
-                                   (const __bf16*)wv, bv, (__bf16*)out, out_row_stride, B);                                                \
-            else if (merge_single() == 4)                                                                                                  \
-                hipLaunchKernelGGL((cross_merge_proj_kernel<D, 4>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o, S,     \
-                                   (const __bf16*)wv, bv, (__bf16*)out, out_row_stride, B);                                                \
-            else if (merge_single() == 7)                                                                                                  \
-                hipLaunchKernelGGL((cross_merge_proj_kernel<D, 7>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o, S,     \
-                                   (const __bf16*)wv, bv, (__bf16*)out, out_row_stride, B);                                                \
-            else if (merge_single() == 6)                                                                                                  \
-                hipLaunchKernelGGL((cross_merge_proj_kernel<D, 6>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o, S,     \
-                                   (const __bf16*)wv, bv, (__bf16*)out, out_row_stride, B);                                                \
-            else if (merge_single() == 5)                                                                                                  \
-                hipLaunchKernelGGL((cross_merge_proj_kernel<D, 5>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o, S,     \
-                                   (const __bf16*)wv, bv, (__bf16*)out, out_row_stride, B);                                                \
-            else                                                                                                                           \
-                hipLaunchKernelGGL((cross_merge_proj_kernel<D>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o, S,        \
-                                   (const __bf16*)wv, bv, (__bf16*)out, out_row_stride, B);                                                \
+            ABS_MERGE_VARIANTS(D)                                                                                                          \
+            hipLaunchKernelGGL((cross_merge_proj_kernel<D>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o, S,            \
+                               (const __bf16*)wv, bv, (__bf16*)out, out_row_stride, B);                                                    \
         }                                                                                                                                  \
     } while (0)
     if (d == 384) ABS_RUN(384);
@@ -1181,6 +1173,7 @@ extern "C" int wipa_cross_absorbed_attention(const void* q, int64_t q_row_stride
     else if (d == 768) ABS_RUN(768);
     else ABS_RUN(1024);
 #undef ABS_RUN
+#undef ABS_MERGE_VARIANTS
     if (rc != WIPA_OK) return rc;
     WIPA_LAUNCH_CHECK();
     return WIPA_OK;
