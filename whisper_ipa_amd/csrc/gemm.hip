@@ -623,14 +623,22 @@ __global__ __launch_bounds__(512) void gemm_wide_persistent_kernel(GemmParams p)
     const int frow = lane & 15, fq = lane >> 4;
     const int n_tiles = (p.N + 15) / 16;
     const int stride = gridDim.x * 8;
-    // the FIRST tile's weight fragments are requested before the activations are staged: the weight stream (HBM) starts at
-    // once instead of after the 98 KB copy from L2 and its barrier (round 4: ~3 us of a 30 us launch)
+    // Weight fragments travel in HALF tiles (k-steps 0 .. KS/2-1 and KS/2 .. KS-1, 12 KiB per wave each): while one half is spent
+    // on the MFMAs the other -- or the first half of the wave's NEXT tile -- is in flight, so the stream never stops between a
+    // tile's arithmetic, its epilogue and the next tile's first load (round 4; before, all KS loads of a tile were issued, waited
+    // for and spent, then the next tile started: two dependent rounds per wave).  The first tile's halves are requested BEFORE
+    // the activations are staged: the weight stream (HBM) starts at once instead of after the 98 KB copy from L2 and its barrier.
+    constexpr int KH = KS / 2;
+    static_assert(KS % 2 == 0, "even k-step count");
     const int tile0 = blockIdx.x * 8 + wave;
-    Frag fw[KS];
+    Frag fa[KH], fb[KH];
+    auto wptr = [&](int tile) { return p.W + (int64_t)min(min(tile, n_tiles - 1) * 16 + frow, p.N - 1) * p.ldw_b + fq * 16; };
     {
-        const char* wp0 = p.W + (int64_t)min(min(tile0, n_tiles - 1) * 16 + frow, p.N - 1) * p.ldw_b + fq * 16;
+        const char* wp0 = wptr(tile0);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) fw[ks] = *reinterpret_cast<const Frag*>(wp0 + ks * 64);
+        for (int ks = 0; ks < KH; ++ks) fa[ks] = *reinterpret_cast<const Frag*>(wp0 + ks * 64);
+#pragma unroll
+        for (int ks = 0; ks < KH; ++ks) fb[ks] = *reinterpret_cast<const Frag*>(wp0 + (KH + ks) * 64);
     }
     // activations -> LDS (rows past M repeat the last row; their results are dropped by the epilogue's row test)
     for (int c = tid; c < 64 * (K / 8); c += 512) {
@@ -644,23 +652,39 @@ __global__ __launch_bounds__(512) void gemm_wide_persistent_kernel(GemmParams p)
     __syncthreads();
     for (int tile = tile0; tile < n_tiles; tile += stride) {
         const int n0 = tile * 16;
-        if (tile != tile0) {
-            const char* wp = p.W + (int64_t)min(n0 + frow, p.N - 1) * p.ldw_b + fq * 16;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) fw[ks] = *reinterpret_cast<const Frag*>(wp + ks * 64);
-        }
+        const bool more = tile + stride < n_tiles;
+        const char* wpn = wptr(tile + stride);
         const EpiCol cc = epi_col(p, n0 + 4 * fq);
         f32x4 acc[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
+        for (int ks = 0; ks < KH; ++ks) {
             Frag fx[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) fx[j] = *reinterpret_cast<const Frag*>(sa + (16 * j + frow) * LROW + 32 * ks + 8 * fq);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) Mma<__bf16>::run(fw[ks], fx[j], acc[j]);
+            for (int j = 0; j < 4; ++j) Mma<__bf16>::run(fa[ks], fx[j], acc[j]);
             // keep the LDS reads of the later k-steps where they are: hoisted over the whole unrolled loop they need 384 registers
             if ((ks & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
+        if (more) {  // first half of the next tile: in flight under this tile's second half and its epilogue
+#pragma unroll
+            for (int ks = 0; ks < KH; ++ks) fa[ks] = *reinterpret_cast<const Frag*>(wpn + ks * 64);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < KH; ++ks) {
+            Frag fx[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fx[j] = *reinterpret_cast<const Frag*>(sa + (16 * j + frow) * LROW + 32 * (KH + ks) + 8 * fq);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Mma<__bf16>::run(fb[ks], fx[j], acc[j]);
+            if ((ks & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) {
+#pragma unroll
+            for (int ks = 0; ks < KH; ++ks) fb[ks] = *reinterpret_cast<const Frag*>(wpn + (KH + ks) * 64);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) epilogue4<OutT>(p, acc[j], epi_row(p, 16 * j + frow, coff_dev), cc, vec);
     }
