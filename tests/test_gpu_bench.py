@@ -42,6 +42,11 @@ def test_bench_single_rank_contract_and_rooflines():
     # the default: absorbed-projection cross-attention (no cross-K/V GEMMs, the streaming kernel is the roofline kernel, half the
     # cross bytes per step)
     assert out["config"]["cross_attention"] == "absorbed"
+    # honest labels: the workload string names a cross-K/V projection only when one runs, says how many clips are
+    # in flight, and the latency figure (one pass at a time) sits next to the throughput figure
+    assert "cross-K/V projection" not in out["config"]["workload"] and "absorbed" in out["config"]["workload"]
+    assert out["config"]["clips_in_flight_per_gpu"] == 2 * 8 and "2 such passes (16 clips) in flight" in out["config"]["workload"]
+    assert 0 < out["value_single_in_flight"] and abs(out["value_single_in_flight"] - 8 * 30.0 / (out["ms_per_pass_single_in_flight"] * 1e-3)) < 1.0
     assert out["roofline_mfma"]["gemm_launches"] == 2 + 5 * 4
     assert "cross_absorbed_v2_kernel" in out["roofline"]["kernel"] and out["roofline"]["layer_call"]["avg_ms"] > out["roofline"]["avg_launch_ms"]
     assert out["decode_step"]["bytes_per_step"] > out["decode_step"]["cross_kv_bytes"] > 0
@@ -49,6 +54,10 @@ def test_bench_single_rank_contract_and_rooflines():
     # the cross bytes, and the same accounting when the absorbed line is read in cached-K/V terms
     ck = _run(["--steps", "3", "--warmup", "1", "--model", "tiny", "--batch", "8", "--pipeline", "2", "--no-cpu-baseline", "--cross-attention", "cached"])
     assert ck["config"]["cross_attention"] == "cached" and ck["passes_identical"] is True
+    assert "+ cross-K/V projection" in ck["config"]["workload"]
+    # cross_attention="auto" decides from (clips, new tokens): long outputs at a small batch take the cached form
+    long_ = _run(["--steps", "2", "--warmup", "1", "--model", "tiny", "--batch", "8", "--pipeline", "2", "--no-cpu-baseline", "--new-tokens", "200"])
+    assert long_["config"]["cross_attention"] == "cached" and long_["passes_identical"] is True
     assert ck["roofline_mfma"]["gemm_launches"] == 2 + 5 * 4 + 4
     assert "decode_cross_block" in ck["roofline"]["kernel"]
     assert out["decode_step"]["cross_kv_bytes"] * 2 == ck["decode_step"]["cross_kv_bytes"]
