@@ -453,7 +453,8 @@ def roofline_cross_absorbed(model, B: int, st, iters: int = 48):
                                                        ptr(scratch), nbytes, B, H, dd, Ta, 64 ** -0.25, sptr(s)), "wipa_cross_absorbed_attention")
 
         def stream_only(i):
-            _lib.check(L.wipa_cross_absorbed_stream(ptr(xas[(i // per_buf) % n_buf]), ptr(scratch), nbytes, B, H, dd, Ta, sptr(s)), "wipa_cross_absorbed_stream")
+            _lib.check(L.wipa_cross_absorbed_stream(ptr(xas[(i // per_buf) % n_buf]), ptr(scratch), nbytes, B, H, dd, Ta, model.cross_splits, sptr(s)),
+                       "wipa_cross_absorbed_stream")
 
         times = {}
         for name, fn in (("stream", stream_only), ("layer_call", full)):
@@ -471,14 +472,14 @@ def roofline_cross_absorbed(model, B: int, st, iters: int = 48):
             ev1.record(s)
             ev1.synchronize()
             times[name] = ev0.elapsed_time(ev1) / iters
-    S = L.wipa_cross_absorbed_splits(B, Ta)
+    S = L.wipa_cross_absorbed_splits(model.cross_splits, Ta)  # the streaming launch of the decode steps this run timed
     xa_bytes = B * Ta * dd * 2
     bytes_alg = xa_bytes + B * 16 * dd * 2 + B * S * (H * dd + 32) * 4  # xa once + absorbed queries in + split partials (H head rows, m, l) out
     ms = times["stream"]
     achieved = bytes_alg / (ms * 1e-3) / 1e9
     traffic = None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_cross_absorbed.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_cross_absorbed.json" if S == 4 else f"r04_pmc_cross_absorbed_s{S}.json")))
         if pm.get("algorithmic_bytes_per_launch") == bytes_alg:
             traffic = pm["hbm_bytes_per_launch"]
     except Exception:
@@ -985,6 +986,10 @@ def main():
     ap.add_argument("--cross-attention", default="auto", choices=["auto", "cached", "absorbed"],
                     help="decode-step cross-attention: the encoder output with absorbed key / value projections (what auto picks for "
                          "bf16 models of <= 16 heads) or mlx_whisper's projected K / V caches (Whisper(cross_attention=...))")
+    ap.add_argument("--cross-splits", type=int, default=None, choices=[0, 1, 2, 3, 4],
+                    help="absorbed cross-attention: frame splits per clip of the decode step's streaming launch "
+                         "(Whisper(cross_splits=...)).  Default: 2 (half-chip launches: the library's setting for several passes in "
+                         "flight) when --pipeline >= 2, else 0 = the library default 4 (shortest lone step)")
     ap.add_argument("--activations", default="bf16", choices=["bf16", "fp8"],
                     help="with --weights fp8: fp8 also runs the encoder's q|k, value, mlp1, mlp2 projections fp8 x fp8 on the "
                          "block-scaled fp8 MFMA (LayerNorm / GELU outputs quantised per row) -- configs[4] '(CDNA4 fp8 MFMA)'")
@@ -1016,6 +1021,9 @@ def main():
     log("weights generated")
     model = Whisper(dims, dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32, f32_split=(args.f32 == "split"),
                     cross_attention=args.cross_attention)
+    if args.cross_splits is None:
+        args.cross_splits = 2 if args.pipeline >= 2 else 0
+    model.cross_splits = args.cross_splits
     model.load_weights(W)
     del W
     if args.activations == "fp8" and args.weights != "fp8":
@@ -1088,7 +1096,11 @@ def main():
                        "workload": f"whisper-{args.model} {args.dtype}{' (fp8 e4m3 weights)' if args.weights == 'fp8' else ''} batched inference, batch={B}x30s synthetic clips per GPU, "
                                    f"log-mel + encoder{'' if absorbed_run else ' + cross-K/V projection'} + {NEW_TOKENS} greedy KV-cached decode steps"
                                    f" ({'cross-attention on the encoder output, key / value projections absorbed' if absorbed_run else 'cross-attention on cached K / V'});"
-                                   f" {args.pipeline} such passes ({args.pipeline * B} clips) in flight per GPU",
+                                   f" {args.pipeline} such passes ({args.pipeline * B} clips) in flight per GPU"
+                                   + (f"; streaming launch in {model.cross_splits} frame splits per clip (Whisper.cross_splits: the setting for several "
+                                      f"passes in flight; 4 = the lone-decode default, timed below as *_default_splits)"
+                                      if absorbed_run and model.cross_splits not in (0, 4) else ""),
+                       "cross_frame_splits": (model.cross_splits or 4) if absorbed_run else None,
                        "clips_per_gpu": B, "clips_in_flight_per_gpu": args.pipeline * B, "new_tokens": NEW_TOKENS, "streams_per_gpu": args.streams,
                        "passes_in_flight": args.pipeline, "decode_group": args.decode_group,
                        "encoder_cus": args.encoder_cus, "decoder_cus": args.decoder_cus,
@@ -1112,6 +1124,22 @@ def main():
             out["roofline"] = roofline_cross_attn(model, audio_chunks[0].shape[0])
         if args.streams == 1 and args.decode_split == 1:
             out["decode_step"] = decode_step_roofline(model, audio_chunks[0].shape[0])
+            if absorbed_run and model.cross_splits not in (0, 4):
+                # the same two latency figures in the library's DEFAULT setting (4 frame splits: what a caller with one pass at a
+                # time runs); the bench setting trades them for throughput with several passes in flight
+                keep = model.cross_splits
+                model.cross_splits = 0
+                one_pass(model, audio_chunks, setup)  # captures the step graph of this setting
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                one_pass(model, audio_chunks, setup)
+                ms1 = (time.perf_counter() - t2) * 1e3
+                dflt = decode_step_roofline(model, audio_chunks[0].shape[0])
+                out["default_splits"] = {"cross_frame_splits": 4, "ms_per_pass_single_in_flight": round(ms1, 2),
+                                         "value_single_in_flight": round(world * B * 30.0 / (ms1 * 1e-3), 1),
+                                         "decode_step_ms": dflt["ms_per_step"], "decode_step_frac": dflt["frac"]}
+                model.cross_splits = keep
+                one_pass(model, audio_chunks, setup)  # back to the timed setting: the parity legs below check what was timed
             if args.dtype == "bf16" and args.batch <= 128:
                 out["roofline_mfma"] = roofline_mfma(model, audio_chunks[0])
         log("roofline microbenches done")

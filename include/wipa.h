@@ -284,6 +284,8 @@ typedef struct wipa_cross_block_desc {
     int64_t slab_stride;
     int32_t n_slabs, B, d, H, Tk, dtype;
     float eps, qk_scale;
+    int32_t cross_splits; /* wipa_decode_cross_absorbed_block[_out] only: frame splits per clip of the streaming launch, 1..4; 0 = the
+                           * default (4).  wipa_decode_cross_block ignores it. */
 } wipa_cross_block_desc;
 int wipa_decode_cross_block(const wipa_cross_block_desc* d, wipa_stream_t s);
 
@@ -297,9 +299,15 @@ int wipa_decode_cross_block(const wipa_cross_block_desc* d, wipa_stream_t s);
  * q   [B rows, row stride q_row_stride] bf16: the cross query, already multiplied by 64^-0.25 (and with its bias);
  * wkT [d, d] bf16 = Wk^T ([in][out]);  xa [B, Tk, d] bf16;  wv [d, d] bf16 ([out][in]), bv [d] f32;
  * out [B rows, row stride out_row_stride] bf16;  k_scale = 64^-0.25 (the key side's share of the score scale);
- * scratch: wipa_cross_absorbed_scratch_bytes(B, d, Tk) bytes, 16-byte aligned.  wipa_cross_absorbed_init(d) raises the
- * kernel's LDS limit (call it once outside any stream capture). */
-int wipa_cross_absorbed_splits(int B, int Tk);
+ * scratch: wipa_cross_absorbed_scratch_bytes(B, d, Tk) bytes, 16-byte aligned (sized for the largest split count).
+ * wipa_cross_absorbed_init(d) raises the kernel's LDS limit (call it once outside any stream capture).
+ * Frame splits: the streaming launch has n_splits x B workgroups, each holding a CU for Tk / n_splits frames of one clip, and the
+ * merge adds the split partials in split order -- so the count is part of the result's rounding and NEVER depends on B.  4 (the
+ * default; want = 0) fills the 256 CUs at 64 clips and gives a lone decode step its shortest launch; 2 leaves half the chip to
+ * the other passes in flight (round 4, whisper-small, 64 clips, 4 passes in flight: 72.3 against 75.3 ms per pass, a lone step
+ * 1.35 against 1.25 ms; 3: 73.5 ms / 1.26 ms) -- the caller who pipelines passes chooses (wipa_model_cfg.dec_cross_splits).
+ * wipa_cross_absorbed_splits(want, Tk) = the count a launch uses: want clamped to 1..4 and to >= two 32-frame tiles per split. */
+int wipa_cross_absorbed_splits(int want, int Tk);
 size_t wipa_cross_absorbed_scratch_bytes(int B, int d, int Tk);
 int wipa_cross_absorbed_init(int d);
 int wipa_cross_absorbed_attention(const void* q, int64_t q_row_stride, const void* wkT, const void* xa, const void* wv, const float* bv,
@@ -321,7 +329,8 @@ int wipa_decode_cross_absorbed_block_out(const wipa_cross_block_desc* c, const v
                                          const float* bo, float* slabs_out, int64_t slab_stride, void* scratch, size_t scratch_bytes,
                                          wipa_stream_t s);
 /* measurement aid: the streaming kernel of wipa_cross_absorbed_attention alone, on a scratch a full call has filled */
-int wipa_cross_absorbed_stream(const void* xa, void* scratch, size_t scratch_bytes, int B, int H, int d, int Tk, wipa_stream_t s);
+int wipa_cross_absorbed_stream(const void* xa, void* scratch, size_t scratch_bytes, int B, int H, int d, int Tk, int n_splits,
+                               wipa_stream_t s);
 
 /* ------------------------------------------------------------------ K13 greedy step
  * GreedyDecoder.update + SuppressBlank + SuppressTokens of mlx_whisper.decoding
@@ -397,6 +406,10 @@ typedef struct wipa_model_cfg {
                                  * [B, n_audio_ctx, d], wipa_decoder_set_audio runs no projection, and the decoder table carries one
                                  * more entry per layer after the regular blocks: Wk^T [d, d] (WIPA_DEC_ABSORBED_PER_LAYER).  0 =
                                  * cached K / V (every other configuration). */
+    int32_t dec_cross_splits; /* dec_cross_absorbed = 1: frame splits per clip of the decode step's streaming launch
+                               * (wipa_cross_block_desc.cross_splits): 0 = default (4: shortest lone step), 2 = half-chip launches
+                               * for callers that keep several passes in flight on one GPU.  Part of the step graph's key; the
+                               * prompt prefill (wipa_cross_absorbed_attention) always uses the default. */
 } wipa_model_cfg;
 
 /* Encoder weight table (const void* [WIPA_ENC_GLOBAL + WIPA_ENC_PER_LAYER * n_layer]):

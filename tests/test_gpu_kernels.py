@@ -1057,6 +1057,70 @@ def test_absorbed_cross_block_with_the_out_projection_in_its_third_launch(B, H, 
     ref_y = torch.nn.functional.layer_norm(got.float(), (d,), mw, mb, 1e-5)
     assert float((y.float() - ref_y).abs().max()) < 0.03  # bf16 output
 
+@pytest.mark.parametrize("H,Tk", [(12, 1500), (6, 333), (16, 100)])
+def test_absorbed_cross_block_frame_splits_are_a_property_of_the_call(H, Tk):
+    """Round 4: wipa_cross_block_desc.cross_splits (wipa_model_cfg.dec_cross_splits) = 1..4 frame splits per clip of the streaming
+    launch (2 = half-chip launches for pipelined passes).  Every count gives the float64 attention of the kernel's own bf16
+    absorbed queries within the same bound as the default; the prologue (x_out) does not move; 0 means 4; the count a call uses
+    is wipa_cross_absorbed_splits(want, Tk) (short inputs: >= two 32-frame tiles per split); and for a given count a clip's
+    result does not depend on the batch it rides in (64 clips == the same clips 5 at a time, bit for bit)."""
+    import ctypes as C
+
+    from whisper_ipa_amd import _lib
+    from whisper_ipa_amd.runtime import on_stream, ptr, sptr
+
+    L = _lib.lib()
+    B, d = 64, H * 64
+    g = torch.Generator(device="cuda").manual_seed(H + Tk)
+    rn = lambda *sh, s=1.0: torch.randn(*sh, device="cuda", generator=g) * s
+    _lib.check(L.wipa_cross_absorbed_init(d))
+    xa = rn(B, Tk, d).bfloat16()
+    x_in, slabs_in = rn(B, d), rn(2, B, d, s=0.3)
+    ln_w, ln_b = 1 + 0.1 * rn(d), 0.1 * rn(d)
+    wq, bq, wkT = rn(d, d, s=0.05).bfloat16(), rn(d, s=0.1), rn(d, d, s=0.05).bfloat16()
+    wv, bv = rn(d, d, s=0.05).bfloat16(), rn(d, s=0.1)
+    tiles = (Tk + 31) // 32
+    for want in range(0, 5):
+        assert L.wipa_cross_absorbed_splits(want, Tk) == max(1, min(want or 4, tiles // 2))
+
+    def run(splits, lo, hi):
+        n = hi - lo
+        nbytes = L.wipa_cross_absorbed_scratch_bytes(n, d, Tk)
+        c = _lib.CrossBlockDesc()
+        x_out = torch.empty(n, d, device="cuda")
+        out = torch.empty(n, d, device="cuda", dtype=torch.bfloat16)
+        scr = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+        xi, sl, xs = x_in[lo:hi].contiguous(), slabs_in[:, lo:hi].contiguous(), xa[lo:hi].contiguous()
+        c.x_in, c.x_out, c.slabs, c.bias_o, c.ln_w, c.ln_b = ptr(xi), ptr(x_out), ptr(sl), None, ptr(ln_w), ptr(ln_b)
+        c.wq, c.bq, c.kv, c.out = ptr(wq), ptr(bq), ptr(xs), ptr(out)
+        c.slab_stride, c.n_slabs, c.B, c.d, c.H, c.Tk, c.dtype = n * d, 2, n, d, H, Tk, _lib.WIPA_BF16
+        c.eps, c.qk_scale, c.cross_splits = 1e-5, 64 ** -0.25, splits
+        with on_stream() as s:
+            _lib.check(L.wipa_decode_cross_absorbed_block(C.byref(c), ptr(wkT), ptr(wv), ptr(bv), ptr(scr), nbytes, sptr(s)))
+        torch.cuda.synchronize()
+        qp = scr[: n * 16 * d * 2].view(torch.bfloat16).view(n, 16, d)[:, :H]  # the absorbed queries the streaming launch read
+        return x_out, out, qp.clone()
+
+    x4, o4, qp4 = run(4, 0, B)
+    x0, o0, _ = run(0, 0, B)
+    assert torch.equal(x0, x4) and torch.equal(o0, o4)
+    # float64 reference from the kernel's own bf16 absorbed queries: softmax(qp xa^T) xa Wv_h^T + bv
+    sc = torch.einsum("bhd,btd->bht", qp4.double(), xa.double())
+    pv = torch.einsum("bht,btd->bhd", torch.softmax(sc, -1), xa.double())
+    ref = torch.einsum("bhd,hed->bhe", pv, wv.double().view(H, 64, d)).reshape(B, d) + bv.double()
+    bound = 0.02 * float(ref.abs().max())
+    assert float((o4.double() - ref).abs().max()) < bound
+    for splits in (1, 2, 3):
+        xs_, os_, qps = run(splits, 0, B)
+        assert torch.equal(xs_, x4) and torch.equal(qps, qp4)
+        assert float((os_.double() - ref).abs().max()) < bound, splits
+        for lo in (0, 5, 59):  # the same clips, 5 at a time: bit-identical
+            _, part, _ = run(splits, lo, lo + 5)
+            assert torch.equal(part, os_[lo:lo + 5]), (splits, lo)
+    c = _lib.CrossBlockDesc()
+    c.cross_splits = 5
+    assert L.wipa_decode_cross_absorbed_block(C.byref(c), None, None, None, None, 0, None) != 0
+
 def test_gemm_fp8_384x256_tile_in_a_subprocess():
     """Round 4: gemm_fp8_384_kernel (fp8 x fp8 on the 384 x 256 tile; WIPA_GEMM_FP8_TILE=384 forces it, read once per process).
     EXACT on small integers with asymmetric operands (a row <-> column swap, a wrong k-group or LDS chunk would show), ragged

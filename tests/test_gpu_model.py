@@ -331,6 +331,57 @@ def test_absorbed_cross_block_fused_prologue_equals_separate_launches(small2, mo
     assert diff < 0.03 * spread, (diff, spread)
 
 
+def test_cross_splits_is_a_model_setting_that_keeps_graph_eager_and_batch_invariance(small2):
+    """Round 4: Whisper.cross_splits -> wipa_model_cfg.dec_cross_splits: the frame splits of the decode step's streaming launch
+    (2 = half-chip launches for several passes in flight).  For every count: the step graph is re-captured under its own key and
+    replays what the eager step computes, bit for bit; a clip's ids and logits do not depend on the batch it rides in; the
+    logits along a fixed history stay within a small fraction of their spread of the default's (only the order of the softmax
+    merges moves); 0 and 4 are the same setting; the setting survives a weight reload; and the runtime refuses counts outside
+    0..4 or a count on the cached form."""
+    import ctypes as C
+
+    from whisper_ipa_amd import _lib
+    from whisper_ipa_amd.decoding import forced_decode_logits, greedy_decode_tokens
+
+    W, mels, xa = small2
+    sp = R.SpecialTokens.multilingual()
+    always, first = R.suppress_lists(sp)
+    init = list(sp.sot_sequence_including_notimestamps(0))
+    m = _model(SMALL2, W, torch.bfloat16, cross_attention="absorbed")
+    feats = xa.cuda().to(torch.bfloat16)
+    base = greedy_decode_tokens(m, feats, init, always, first, sp.eot, max_new_tokens=12, stop_on_eot=False)
+    t4, _ = forced_decode_logits(m, feats, base.tokens, 4, always, first, sp.eot, use_graph=True)
+    traces = {}
+    for n in (0, 1, 2, 3, 4):
+        m.cross_splits = n
+        assert m.packed(absorbed=True)["cfg"].dec_cross_splits == n
+        tg, _ = forced_decode_logits(m, feats, base.tokens, 4, always, first, sp.eot, use_graph=True)
+        te, _ = forced_decode_logits(m, feats, base.tokens, 4, always, first, sp.eot, use_graph=False)
+        assert torch.equal(tg, te), n
+        one, _ = forced_decode_logits(m, feats[1:2].contiguous(), base.tokens[1:2], 4, always, first, sp.eot, use_graph=True)
+        assert torch.equal(one[0], tg[1]), n  # clip 1 alone == clip 1 in the batch
+        traces[n] = tg.float().cpu()
+    assert torch.equal(traces[0], traces[4]) and torch.equal(traces[4], t4.float().cpu())
+    fin = torch.isfinite(traces[4])
+    spread = traces[4][fin].std().item()
+    for n in (1, 2, 3):
+        diff = (traces[n] - traces[4])[fin].abs().max().item()
+        print(f"\ncross_splits {n} vs 4: max logit difference {diff:.4f} = {diff / spread:.4f} of the logit std")
+        assert diff < 0.03 * spread, (n, diff, spread)
+    m.cross_splits = 2
+    m.load_weights(W)  # repacks: the setting is the model's, not the packed table's
+    assert m.packed(absorbed=True)["cfg"].dec_cross_splits == 2
+    with pytest.raises(_lib.WipaError):
+        m.cross_splits = 5
+    pk = m.packed(absorbed=True)
+    bad = type(pk["cfg"]).from_buffer_copy(pk["cfg"])
+    bad.dec_cross_splits = 7
+    assert _lib.lib().wipa_decoder_layout(C.byref(bad), 4, C.byref(_lib.DecLayout())) != 0
+    cached = type(pk["cfg"]).from_buffer_copy(m.packed(absorbed=False)["cfg"])
+    cached.dec_cross_splits = 2
+    assert _lib.lib().wipa_decoder_layout(C.byref(cached), 4, C.byref(_lib.DecLayout())) != 0
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("mode", ["0", "1", "2"])
 def test_decode_never_reads_unwritten_state(micro, monkeypatch, dtype, mode):

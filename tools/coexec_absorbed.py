@@ -41,7 +41,7 @@ kv = (torch.randn(4, B, 2 * H, Tk, 64, device="cuda", generator=g) * 0.5).to(tor
 def stream_abs(n):
     s = sptr(runtime.stream())
     for i in range(n):
-        _lib.check(L.wipa_cross_absorbed_stream(ptr(xas[i % 4]), ptr(scratch), nbytes, B, H, d, Tk, s))
+        _lib.check(L.wipa_cross_absorbed_stream(ptr(xas[i % 4]), ptr(scratch), nbytes, B, H, d, Tk, 0, s))
 
 
 def cross_cached(n):

@@ -51,4 +51,4 @@ with on_stream() as s:
         us = e0.elapsed_time(e1) / 48 * 1e3
         xa_bytes = B * Tk * d * 2
         print(f"B={B} absorbed cross-attention, {'cold (rotating xa)' if rotate else 'hot (one xa)'}: {us:.2f} us per layer call (3 launches) -> "
-              f"{xa_bytes / us / 1e6:.2f} TB/s of xa; splits {L.wipa_cross_absorbed_splits(B, Tk)}", flush=True)
+              f"{xa_bytes / us / 1e6:.2f} TB/s of xa; splits {L.wipa_cross_absorbed_splits(0, Tk)}", flush=True)

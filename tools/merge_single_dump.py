@@ -24,7 +24,7 @@ wkT = (torch.randn(d, d, device="cuda", generator=g) * 0.05).bfloat16()
 wv = (torch.randn(d, d, device="cuda", generator=g) * 0.05).bfloat16()
 bv = torch.randn(d, device="cuda", generator=g) * 0.1
 nbytes = L.wipa_cross_absorbed_scratch_bytes(B, d, Tk)
-S = L.wipa_cross_absorbed_splits(B, Tk)
+S = L.wipa_cross_absorbed_splits(0, Tk)
 st = torch.cuda.Stream()
 out = torch.zeros(B, d, device="cuda", dtype=torch.bfloat16)
 scr = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")

@@ -20,6 +20,7 @@ from whisper_ipa_amd.runtime import on_stream, ptr, sptr  # noqa: E402
 B, H, Tk = 64, 12, 1500
 NBUF = int(os.environ.get("NBUF", "4"))
 PER_BUF = int(os.environ.get("PER_BUF", "12"))
+SPLITS = int(os.environ.get("SPLITS", "0"))  # frame splits per clip of the streaming launch: 0 = the default (4); 2 = bench.py's pipelined setting
 d = H * 64
 L = _lib.lib()
 _lib.check(L.wipa_cross_absorbed_init(d))
@@ -38,12 +39,12 @@ with on_stream() as s:
                                                64 ** -0.25, sptr(s)))
 
     def launch(i):
-        _lib.check(L.wipa_cross_absorbed_stream(ptr(xas[(i // PER_BUF) % NBUF]), ptr(scratch), nbytes, B, H, d, Tk, sptr(s)))
+        _lib.check(L.wipa_cross_absorbed_stream(ptr(xas[(i // PER_BUF) % NBUF]), ptr(scratch), nbytes, B, H, d, Tk, SPLITS, sptr(s)))
 
     for i in range(48):
         launch(i)
     s.synchronize()
-    S = L.wipa_cross_absorbed_splits(B, Tk)
+    S = L.wipa_cross_absorbed_splits(SPLITS, Tk)
     xa_bytes = B * Tk * d * 2
     alg = xa_bytes + B * 16 * d * 2 + B * S * (H * d + 32) * 4
     print("xa bytes per launch:", xa_bytes, " algorithmic bytes per launch (xa once + absorbed queries in + split partials out):", alg)

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Turn gpurun_out/r04/ (tools/r04_gpu_profile.sh a | b) into the committed summaries under profiles/.  usage: tools/r04_summaries.py"""
+"""Turn gpurun_out/r04/ (tools/r04_gpu_profile.sh a | b) into the committed summaries under profiles/.  usage: tools/r04_summaries.py
+R04_SRC=r04s8 R04_SPLITS=2 tools/r04_summaries.py: the same from gpurun_out/r04s8/ (tools/r04_run8.sh: the streaming kernel at 2 frame
+splits -> profiles/r04_pmc_cross_absorbed_s2.json)."""
 import collections
 import csv
 import glob
@@ -9,7 +11,8 @@ import re
 import shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "r04")
+SRC = os.path.join(ROOT, "gpurun_out", os.environ.get("R04_SRC", "r04"))
+SPLITS = int(os.environ.get("R04_SPLITS", "4"))
 DST = os.path.join(ROOT, "profiles")
 
 
@@ -73,8 +76,8 @@ if have("pmc_x1"):
     d1, d2 = trace_us("pmc_x1", "cross_absorbed_v2"), trace_us("pmc_x2", "cross_absorbed_v2")
     out = {"kernel": "cross_absorbed_v2_kernel<768> (decode-step cross-attention of one layer on the encoder output itself: scores with the key "
                      "projection absorbed into the query, P x xa with the value projection applied after the merge)",
-           "shape": "whisper-small, B=64, H=12, Tk=1500, bf16, 4 frame splits: 48 launches: 12 consecutive (the layers of a step) per encoder output, 4 encoder outputs in turn",
-           "command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 tools/pmc_cross_absorbed.py ; same with --pmc WRITE_SIZE (separate passes)",
+           "shape": "whisper-small, B=64, H=12, Tk=1500, bf16, " + str(SPLITS) + " frame splits: 48 launches: 12 consecutive (the layers of a step) per encoder output, 4 encoder outputs in turn",
+           "command": ("" if SPLITS == 4 else f"SPLITS={SPLITS} ") + "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 tools/pmc_cross_absorbed.py ; same with --pmc WRITE_SIZE (separate passes)",
            "FETCH_SIZE_KB_per_launch": round(x.get("FETCH_SIZE", 0), 2), "WRITE_SIZE_KB_per_launch": round(x.get("WRITE_SIZE", 0), 2),
            "launches_counted": n_launch,
            "correction": "gfx950: FETCH_SIZE counts a wide coalesced 16 B/lane stream at exactly 1/2 of its bytes (MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE is exact",
@@ -83,7 +86,7 @@ if have("pmc_x1"):
            "avg_us_under_counters": [round(sum(d1) / max(len(d1), 1), 2), round(sum(d2) / max(len(d2), 1), 2)],
            "avg_us_event_timed_no_counters": ev}
     out["ratio_traffic_over_algorithmic"] = round(out["hbm_bytes_per_launch"] / alg, 4)
-    json.dump(out, open(os.path.join(DST, "r04_pmc_cross_absorbed.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(DST, "r04_pmc_cross_absorbed.json" if SPLITS == 4 else f"r04_pmc_cross_absorbed_s{SPLITS}.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 # ---- the dominant kernel of the default step: fused cross block on the cached K / V

@@ -59,7 +59,7 @@ class CrossBlockDesc(C.Structure):
         ("wq", c_void_p), ("bq", c_void_p), ("kv", c_void_p), ("out", c_void_p),
         ("slab_stride", c_int64),
         ("n_slabs", C.c_int32), ("B", C.c_int32), ("d", C.c_int32), ("H", C.c_int32), ("Tk", C.c_int32), ("dtype", C.c_int32),
-        ("eps", c_float), ("qk_scale", c_float),
+        ("eps", c_float), ("qk_scale", c_float), ("cross_splits", C.c_int32),
     ]
 
 
@@ -80,7 +80,7 @@ class ModelCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n_mels", "n_audio_ctx", "n_audio_state", "n_audio_head", "n_audio_layer",
         "n_vocab", "n_text_ctx", "n_text_state", "n_text_head", "n_text_layer", "dtype", "f32_split", "dec_w_dtype", "weights_generation",
-        "enc_act_fp8", "dec_cross_absorbed")]
+        "enc_act_fp8", "dec_cross_absorbed", "dec_cross_splits")]
 
 
 class DecLayout(C.Structure):
@@ -126,7 +126,7 @@ SIGNATURES = {
     "wipa_cross_absorbed_init": (c_int, [c_int]),
     "wipa_cross_absorbed_attention": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_size_t,
                                               c_int, c_int, c_int, c_int, c_float, c_void_p]),
-    "wipa_cross_absorbed_stream": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_void_p]),
+    "wipa_cross_absorbed_stream": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "wipa_decode_cross_absorbed_block": (c_int, [_P(CrossBlockDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wipa_decode_cross_absorbed_block_out": (c_int, [_P(CrossBlockDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                                      c_void_p, c_size_t, c_void_p]),

@@ -1035,21 +1035,26 @@ int launch_attn(const AbsParams& p_in, int B, hipStream_t s) {
     return v;
 }
 
-// Frame splits per clip: FOUR, whatever the batch -- a clip's result must not depend on the batch it rides in (the partition
-// of the frames fixes the order of the softmax merges), and a workgroup streams the same 375 frames at the same per-CU rate
-// whether 1 or 256 clips are decoded; 64 clips x 4 splits are exactly one round on the 256 CUs (the kernel holds a CU: 104 KiB
-// of LDS).  Short inputs: at least two 32-frame tiles per split.
-extern "C" int wipa_cross_absorbed_splits(int B, int Tk) {
-    (void)B;
+// Frame splits per clip: a clip's result must not depend on the batch it rides in (the partition of the frames fixes the order of
+// the softmax merges), so the count is a property of the CALL, never of B.  FOUR by default: a workgroup streams 375 frames at the
+// same per-CU rate whether 1 or 256 clips are decoded, and 64 clips x 4 splits are exactly one round on the 256 CUs (the kernel
+// holds a CU: 104 KiB of LDS).  Fewer splits = fewer, longer workgroups: measured r04 (whisper-small, 64 clips; lone launch /
+// lone step / pass with 4 passes in flight): 4: 32.4 us / 1.253 ms / 75.3 ms; 3: 32.7 / 1.261 / 73.5 (192 CUs already reach the
+// HBM-side limit of this access path); 2: 40.4 / 1.352 / 72.3 (128 CUs run at their own 34 GB/s each, and the streaming kernels
+// of two passes run side by side instead of queueing for the whole chip); 1: 66.1 / 1.674 / 72.1.  Short inputs: at least two
+// 32-frame tiles per split.  WIPA_ABS_SPLITS overrides the DEFAULT (want = 0) for A/B runs.
+extern "C" int wipa_cross_absorbed_splits(int want, int Tk) {
     const int tiles = (Tk + FT - 1) / FT;
-    int s = 4;
+    static const int dflt = [] { const char* e = getenv("WIPA_ABS_SPLITS"); const int v = e ? atoi(e) : 4; return (v >= 1 && v <= 4) ? v : 4; }();
+    int s = (want >= 1 && want <= 4) ? want : dflt;
     if (s > tiles / 2) s = tiles / 2;
     return s < 1 ? 1 : s;
 }
 
+// sized for four splits whatever a call uses: one state blob serves every dec_cross_splits
 extern "C" size_t wipa_cross_absorbed_scratch_bytes(int B, int d, int Tk) {
-    const size_t S = (size_t)wipa_cross_absorbed_splits(B, Tk);
-    return (size_t)B * 16 * d * 2 + (size_t)B * S * 16 * (2 + (size_t)d) * 4 + 1024;
+    (void)Tk;
+    return (size_t)B * 16 * d * 2 + (size_t)B * 4 * 16 * (2 + (size_t)d) * 4 + 1024;
 }
 
 extern "C" int wipa_cross_absorbed_init(int d) {
@@ -1086,14 +1091,15 @@ extern "C" int wipa_cross_absorbed_init(int d) {
 
 // the streaming kernel alone on a scratch whose Qp a wipa_cross_absorbed_attention call has filled (measurement aid: bench.py
 // times the dominant kernel of the decode step by itself)
-extern "C" int wipa_cross_absorbed_stream(const void* xa, void* scratch, size_t scratch_bytes, int B, int H, int d, int Tk,
+extern "C" int wipa_cross_absorbed_stream(const void* xa, void* scratch, size_t scratch_bytes, int B, int H, int d, int Tk, int n_splits,
                                           wipa_stream_t stream) {
-    WIPA_REQUIRE(xa && scratch && B > 0 && H >= 1 && H <= 16 && d == H * 64 && (d == 384 || d == 512 || d == 768 || d == 1024) && Tk >= 1,
+    WIPA_REQUIRE(xa && scratch && B > 0 && H >= 1 && H <= 16 && d == H * 64 && (d == 384 || d == 512 || d == 768 || d == 1024) && Tk >= 1 &&
+                     n_splits >= 0 && n_splits <= 4,
                  "wipa_cross_absorbed_stream: bad arguments");
     WIPA_REQUIRE(scratch_bytes >= wipa_cross_absorbed_scratch_bytes(B, d, Tk), "wipa_cross_absorbed_stream: scratch too small");
     const int rc0 = wipa_cross_absorbed_init(d);
     if (rc0 != WIPA_OK) return rc0;
-    const int S = wipa_cross_absorbed_splits(B, Tk);
+    const int S = wipa_cross_absorbed_splits(n_splits, Tk);
     char* sc = (char*)scratch;
     AbsParams p = {};
     p.qp = (const __bf16*)sc; p.xa = (const __bf16*)xa;
@@ -1129,7 +1135,7 @@ extern "C" int wipa_cross_absorbed_attention(const void* q, int64_t q_row_stride
         const int rc0 = wipa_cross_absorbed_init(d);  // once per width
         if (rc0 != WIPA_OK) return rc0;
     }
-    const int S = wipa_cross_absorbed_splits(B, Tk);
+    const int S = wipa_cross_absorbed_splits(0, Tk);
     char* sc = (char*)scratch;
     __bf16* qp = (__bf16*)sc;
     float* part_m = (float*)(sc + (size_t)B * 16 * d * 2);
@@ -1209,13 +1215,15 @@ static int absorbed_block(const wipa_cross_block_desc* c, const void* wkT, const
     WIPA_REQUIRE(c->x_in != c->x_out, "wipa_decode_cross_absorbed_block: x_out must not alias x_in");
     const int B = c->B, H = c->H, d = c->d, Tk = c->Tk;
     WIPA_REQUIRE(c->dtype == WIPA_BF16 && B > 0 && B <= 65535 * 16 && H >= 1 && H <= 16 && d == H * 64 &&
-                     (d == 384 || d == 512 || d == 768 || d == 1024) && Tk >= 1 && c->n_slabs >= 0 && c->n_slabs <= 4 && !c->bias_o,
-                 "wipa_decode_cross_absorbed_block: bf16, <= 16 heads of 64, d in {384, 512, 768, 1024}, <= 4 slabs, no separate bias");
+                     (d == 384 || d == 512 || d == 768 || d == 1024) && Tk >= 1 && c->n_slabs >= 0 && c->n_slabs <= 4 && !c->bias_o &&
+                     c->cross_splits >= 0 && c->cross_splits <= 4,
+                 "wipa_decode_cross_absorbed_block: bf16, <= 16 heads of 64, d in {384, 512, 768, 1024}, <= 4 slabs, no separate bias, "
+                 "cross_splits 0..4");
     WIPA_REQUIRE(c->n_slabs == 0 || c->slabs, "wipa_decode_cross_absorbed_block: slabs missing");
     WIPA_REQUIRE((int64_t)Tk * d * 2 < ((int64_t)1 << 31), "wipa_decode_cross_absorbed_block: clip too long for 32-bit tile offsets");
     WIPA_REQUIRE(scratch_bytes >= wipa_cross_absorbed_scratch_bytes(B, d, Tk), "wipa_decode_cross_absorbed_block: scratch too small");
     hipStream_t s = (hipStream_t)stream;
-    const int S = wipa_cross_absorbed_splits(B, Tk);
+    const int S = wipa_cross_absorbed_splits(c->cross_splits, Tk);
     char* sc = (char*)scratch;
     __bf16* qp = (__bf16*)sc;
     float* part_m = (float*)(sc + (size_t)B * 16 * d * 2);

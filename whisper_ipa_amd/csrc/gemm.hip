@@ -977,7 +977,8 @@ int launch_skinny_cfg(const GemmParams& p, hipStream_t s) {
 template <typename OutT, int KS>
 int launch_wide_persistent_ks(const GemmParams& p, hipStream_t s) {
     const size_t lds = (size_t)64 * (KS * 32 + 8) * 2;
-    hipLaunchKernelGGL((gemm_wide_persistent_kernel<OutT, KS>), dim3(256), dim3(512), lds, s, p);
+    static const int wide_grid = [] { const char* e = getenv("WIPA_WIDE_GRID"); const int v = e ? atoi(e) : 256; return (v >= 32 && v <= 256) ? v : 256; }();  // A/B: 128 = half-chip launches
+    hipLaunchKernelGGL((gemm_wide_persistent_kernel<OutT, KS>), dim3(wide_grid), dim3(512), lds, s, p);
     WIPA_LAUNCH_CHECK();
     return WIPA_OK;
 }

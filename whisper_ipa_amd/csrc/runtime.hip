@@ -79,6 +79,8 @@ int cfg_check(const wipa_model_cfg* c) {
                       (c->n_text_state == 384 || c->n_text_state == 512 || c->n_text_state == 768 || c->n_text_state == 1024)),
                  "cfg.dec_cross_absorbed %d: absorbed cross-attention needs a bf16 model without fp8 decoder tables, <= 16 heads, d in "
                  "{384, 512, 768, 1024}", c->dec_cross_absorbed);
+    WIPA_REQUIRE(c->dec_cross_splits >= 0 && c->dec_cross_splits <= 4 && (c->dec_cross_splits == 0 || c->dec_cross_absorbed == 1),
+                 "cfg.dec_cross_splits %d: 0 (default) or 1..4 frame splits, with dec_cross_absorbed = 1 only", c->dec_cross_splits);
     WIPA_REQUIRE(c->enc_act_fp8 == 0 || (c->enc_act_fp8 == 1 && c->dtype == WIPA_BF16 && c->n_audio_state % 128 == 0),
                  "cfg.enc_act_fp8 %d: fp8 encoder activations need a bf16 model whose width is a multiple of 128", c->enc_act_fp8);
     return WIPA_OK;
@@ -498,6 +500,7 @@ int enqueue_step(const wipa_model_cfg* cfg, const void* const* w, char* st, cons
             c.ln_w = (const float*)lw[6]; c.ln_b = (const float*)lw[7]; c.wq = lw[8]; c.bq = (const float*)lw[9];
             c.kv = st + L.cross_kv; c.out = ao; c.slab_stride = slab_stride;
             c.n_slabs = pend; c.B = B; c.d = d; c.H = H; c.Tk = Ta; c.dtype = dt; c.eps = 1e-5f; c.qk_scale = QK_SCALE;
+            c.cross_splits = cfg->dec_cross_splits;
             if (absorbed_merge_out()) {
                 // ... and the cross-attention OUT projection rides in the third launch: one slab per head, summed by the mlp LayerNorm
                 RT_CALL(wipa_decode_cross_absorbed_block_out(&c, wkT, (const char*)lw[10] + (size_t)d * d * e, (const float*)lw[11] + d,
@@ -933,7 +936,7 @@ extern "C" int wipa_decoder_run(const wipa_model_cfg* cfg, const void* const* w,
     }
     WIPA_REQUIRE(s != nullptr, "wipa_decoder_run: graph capture needs a non-default stream");
     hipGraphExec_t exec = nullptr;
-    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * decode_mode(cfg, B) + 16 * cfg->dec_w_dtype + 64 * cfg->dec_cross_absorbed * (absorbed_block_fused() ? 2 : 1) + 256 * (int)tail_fused() + 512 * (int)absorbed_merge_out(), cfg->weights_generation, 0);
+    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * decode_mode(cfg, B) + 16 * cfg->dec_w_dtype + 64 * cfg->dec_cross_absorbed * (absorbed_block_fused() ? 2 : 1) + 256 * (int)tail_fused() + 512 * (int)absorbed_merge_out() + 1024 * cfg->dec_cross_splits, cfg->weights_generation, 0);
     {
         std::lock_guard<std::mutex> lk(g_graph_mu);
         auto it = g_graphs.find(key);
@@ -980,7 +983,7 @@ extern "C" int wipa_decoder_prefill(const wipa_model_cfg* cfg, const void* const
     RT_CALL(init_before_capture(cfg));
     if (!use_graph || s == nullptr || !graphs_allowed()) return enqueue();
     hipGraphExec_t exec = nullptr;
-    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * decode_mode(cfg, B) + 16 * cfg->dec_w_dtype + 64 * cfg->dec_cross_absorbed * (absorbed_block_fused() ? 2 : 1) + 256 * (int)tail_fused() + 512 * (int)absorbed_merge_out(), cfg->weights_generation, 1);
+    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * decode_mode(cfg, B) + 16 * cfg->dec_w_dtype + 64 * cfg->dec_cross_absorbed * (absorbed_block_fused() ? 2 : 1) + 256 * (int)tail_fused() + 512 * (int)absorbed_merge_out() + 1024 * cfg->dec_cross_splits, cfg->weights_generation, 1);
     {
         std::lock_guard<std::mutex> lk(g_graph_mu);
         auto it = g_graphs.find(key);

@@ -117,7 +117,7 @@ class _Part:
 
 class Whisper:
     def __init__(self, dims: ModelDimensions, dtype: torch.dtype = torch.float32, f32_split: bool = False,
-                 sinusoid_rounding: str = "f32", cross_attention: str = "auto"):
+                 sinusoid_rounding: str = "f32", cross_attention: str = "auto", cross_splits: int = 0):
         """``f32_split`` (float32 models only): let the large GEMMs and the encoder attention take every f32 product as
         split-bf16 MFMA terms (about twice as fast, ~5e-6 relative error per dot product).  Off by default: the reference
         computes in true float32 (train_whisper_ipa.py:505, transcribe_single.py:13).
@@ -135,7 +135,17 @@ class Whisper:
         Same mathematics, other bf16 rounding points.  Measured on MI355X, absorbed against cached:
         whisper-small, 64 clips: +5.3 % at 32, +7.0 % at 64, +4.5 % at 128, -3.1 % at 224 new tokens; 128 clips: +8.5 % / +3.6 % at
         64 / 224; whisper-medium, 256 clips: +1.1 % at 224 (profiles/r04_cached_vs_absorbed.txt).  The choice is
-        explicit here and in the CPU checker, and both settings are pinned by golden fixtures (tests/golden/wide_model.npz)."""
+        explicit here and in the CPU checker, and both settings are pinned by golden fixtures (tests/golden/wide_model.npz).
+        ``cross_splits`` (absorbed form only; also an attribute that may be changed between decodes): frame splits per clip of the
+        decode step's streaming launch.  0 = the library default, 4: the shortest launch for a decode that has the GPU to itself
+        (one clip: 4 workgroups of 375 frames).  2 = half-chip launches for callers that keep SEVERAL passes in flight on one
+        GPU (bench.py's pipelined passes): the streaming kernels of two passes run side by side instead of queueing for all 256
+        CUs -- measured on MI355X, whisper-small, 64 clips, 4 passes in flight: 72.3 against 75.3 ms per pass, while a lone
+        decode step costs 1.35 against 1.25 ms (3: 73.5 ms / 1.26 ms; profiles/r04_stream_splits_ab.txt).  The count never
+        depends on the batch; it moves the order of the softmax merges, i.e. bf16-level rounding like any other kernel choice."""
+        if cross_splits not in (0, 1, 2, 3, 4):
+            raise _lib.WipaError(f"cross_splits must be 0 (default) or 1..4, got {cross_splits!r}")
+        self._cross_splits = int(cross_splits)
         if cross_attention not in ("auto", "absorbed", "cached"):
             raise _lib.WipaError(f"cross_attention must be 'auto', 'absorbed' or 'cached', got {cross_attention!r}")
         self.cross_attention = cross_attention
@@ -330,6 +340,18 @@ class Whisper:
         return not long_small
 
     @property
+    def cross_splits(self) -> int:
+        return self._cross_splits
+
+    @cross_splits.setter
+    def cross_splits(self, n: int):
+        if n not in (0, 1, 2, 3, 4):
+            raise _lib.WipaError(f"cross_splits must be 0 (default) or 1..4, got {n!r}")
+        self._cross_splits = int(n)
+        if self._packed_abs is not None:
+            self._packed_abs["cfg"].dec_cross_splits = self._cross_splits  # part of the step graph's key: the next decode re-captures
+
+    @property
     def cross_absorbed(self) -> bool:
         """the form a decode of unknown size takes (use_absorbed()); decoding.py asks use_absorbed(B, sample_len) per call"""
         return self.use_absorbed()
@@ -340,7 +362,8 @@ class Whisper:
         return _lib.ModelCfg(d.n_mels, d.n_audio_ctx, d.n_audio_state, d.n_audio_head, d.n_audio_layer, d.n_vocab,
                              d.n_text_ctx, d.n_text_state, d.n_text_head, d.n_text_layer, dt_code(self.dtype),
                              int(self.f32_split and self.dtype == torch.float32), _lib.WIPA_FP8_E4M3 if fp8 else 0,
-                             getattr(self, "_generation", 0), int(bool(self._fp8_enc)), int(bool(absorbed) and not fp8))
+                             getattr(self, "_generation", 0), int(bool(self._fp8_enc)), int(bool(absorbed) and not fp8),
+                             self._cross_splits if (absorbed and not fp8) else 0)
 
     def packed(self, teacher_forced: bool = False, absorbed: Optional[bool] = None):
         """(cfg, encoder table, decoder table); fused matrices are rebuilt after any update.  With fp8 weights the decoder
