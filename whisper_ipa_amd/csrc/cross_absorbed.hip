@@ -1038,7 +1038,7 @@ int launch_attn(const AbsParams& p_in, int B, hipStream_t s) {
 // Frame splits per clip: a clip's result must not depend on the batch it rides in (the partition of the frames fixes the order of
 // the softmax merges), so the count is a property of the CALL, never of B.  FOUR by default: a workgroup streams 375 frames at the
 // same per-CU rate whether 1 or 256 clips are decoded, and 64 clips x 4 splits are exactly one round on the 256 CUs (the kernel
-// holds a CU: 104 KiB of LDS).  Fewer splits = fewer, longer workgroups: measured r04 (whisper-small, 64 clips; lone launch /
+// holds a CU: 145 KiB of LDS).  Fewer splits = fewer, longer workgroups: measured r04 (whisper-small, 64 clips; lone launch /
 // lone step / pass with 4 passes in flight): 4: 32.4 us / 1.253 ms / 75.3 ms; 3: 32.7 / 1.261 / 73.5 (192 CUs already reach the
 // HBM-side limit of this access path); 2: 40.4 / 1.352 / 72.3 (128 CUs run at their own 34 GB/s each, and the streaming kernels
 // of two passes run side by side instead of queueing for the whole chip); 1: 66.1 / 1.674 / 72.1.  Short inputs: at least two
