@@ -472,7 +472,33 @@ def roofline_cross_absorbed(model, B: int, st, iters: int = 48):
             ev1.record(s)
             ev1.synchronize()
             times[name] = ev0.elapsed_time(ev1) / iters
-    S = L.wipa_cross_absorbed_splits(model.cross_splits, Ta)  # the streaming launch of the decode steps this run timed
+        S = L.wipa_cross_absorbed_splits(model.cross_splits, Ta)  # the streaming launch of the decode steps this run timed
+        pair_ms = None
+        if S * B <= 128:
+            # a launch of <= 128 workgroups is MEANT to share the chip with another pass's launch: the same launches on two HIP
+            # streams at once (separate scratch, the same encoder outputs), aggregate bytes over the wall time of both
+            s2 = torch.cuda.Stream()
+            scratch2 = scratch.clone()
+            s.synchronize()
+            graphs = []
+            for st_, sc_ in ((s, scratch), (s2, scratch2)):
+                g_ = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_, stream=st_):
+                    for i in range(iters):
+                        _lib.check(L.wipa_cross_absorbed_stream(ptr(xas[(i // per_buf) % n_buf]), ptr(sc_), nbytes, B, H, dd, Ta, model.cross_splits,
+                                                                st_.cuda_stream), "wipa_cross_absorbed_stream")
+                graphs.append((st_, g_))
+            for rep in range(2):
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record(s)
+                s2.wait_event(ev0)
+                for st_, g_ in graphs:
+                    with torch.cuda.stream(st_):
+                        g_.replay()
+                s.wait_stream(s2)
+                ev1.record(s)
+                ev1.synchronize()
+            pair_ms = ev0.elapsed_time(ev1) / iters  # wall time per PAIR of launches
     xa_bytes = B * Ta * dd * 2
     bytes_alg = xa_bytes + B * 16 * dd * 2 + B * S * (H * dd + 32) * 4  # xa once + absorbed queries in + split partials (H head rows, m, l) out
     ms = times["stream"]
@@ -490,7 +516,12 @@ def roofline_cross_absorbed(model, B: int, st, iters: int = 48):
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": bytes_alg, "avg_launch_ms": round(ms, 5),
             "launch_order": f"{per_buf} consecutive launches (the layers of one decode step) per encoder output, {n_buf} encoder outputs (passes in flight) in turn",
-            "frame_splits": S,
+            "frame_splits": S, "workgroups": S * B,
+            **({"two_launches_side_by_side": {
+                "what": f"the launch holds {S * B} of the 256 CUs by design (half-chip launches for several passes in flight): the same launches on "
+                        "two HIP streams at once, aggregate algorithmic bytes over the wall time",
+                "avg_pair_ms": round(pair_ms, 5), "achieved": round(2 * bytes_alg / (pair_ms * 1e-3) / 1e9, 1),
+                "frac": round(2 * bytes_alg / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}} if pair_ms else {}),
             "layer_call": {"what": "absorb-q + streaming + merge / value projection (3 launches: what replaces the cached-K/V cross "
                                    "block's streaming loop)", "avg_ms": round(times["layer_call"], 5)},
             "kv_equivalent": {"what": "the cached K / V bytes this launch stands for (SURVEY.md 8d: 55.3 MB per clip and step over 12 "
@@ -1135,9 +1166,12 @@ def main():
                 one_pass(model, audio_chunks, setup)
                 ms1 = (time.perf_counter() - t2) * 1e3
                 dflt = decode_step_roofline(model, audio_chunks[0].shape[0])
+                rf4 = roofline_cross_attn(model, audio_chunks[0].shape[0])
                 out["default_splits"] = {"cross_frame_splits": 4, "ms_per_pass_single_in_flight": round(ms1, 2),
                                          "value_single_in_flight": round(world * B * 30.0 / (ms1 * 1e-3), 1),
-                                         "decode_step_ms": dflt["ms_per_step"], "decode_step_frac": dflt["frac"]}
+                                         "decode_step_ms": dflt["ms_per_step"], "decode_step_frac": dflt["frac"],
+                                         "streaming_launch": {k: rf4[k] for k in ("workgroups", "avg_launch_ms", "achieved", "frac", "traffic",
+                                                                                  "algorithmic_bytes_per_launch")}}
                 model.cross_splits = keep
                 one_pass(model, audio_chunks, setup)  # back to the timed setting: the parity legs below check what was timed
             if args.dtype == "bf16" and args.batch <= 128:

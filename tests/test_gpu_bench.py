@@ -50,6 +50,15 @@ def test_bench_single_rank_contract_and_rooflines():
     assert out["roofline_mfma"]["gemm_launches"] == 2 + 5 * 4
     assert "cross_absorbed_v2_kernel" in out["roofline"]["kernel"] and out["roofline"]["layer_call"]["avg_ms"] > out["roofline"]["avg_launch_ms"]
     assert out["decode_step"]["bytes_per_step"] > out["decode_step"]["cross_kv_bytes"] > 0
+    # several passes in flight: the streaming launch runs in 2 frame splits per clip (Whisper.cross_splits), the line says so, times
+    # two such launches side by side, and carries the latencies of the library's default setting (4 splits) beside its own
+    assert out["config"]["cross_frame_splits"] == 2 and "2 frame splits" in out["config"]["workload"]
+    assert out["roofline"]["frame_splits"] == 2 and out["roofline"]["workgroups"] == 16 and out["roofline"]["two_launches_side_by_side"]["achieved"] > 0
+    ds = out["default_splits"]
+    assert ds["cross_frame_splits"] == 4 and ds["decode_step_ms"] > 0 and ds["ms_per_pass_single_in_flight"] > 0
+    assert ds["streaming_launch"]["workgroups"] == 32 and ds["streaming_launch"]["frac"] > 0
+    one = _run(["--steps", "2", "--warmup", "1", "--model", "tiny", "--batch", "8", "--pipeline", "1", "--no-cpu-baseline"])
+    assert one["config"]["cross_frame_splits"] == 4 and "default_splits" not in one and "frame splits" not in one["config"]["workload"]
     # mlx_whisper's projected K / V caches (opt-in): four more GEMM launches, the fused cross block as the roofline kernel, twice
     # the cross bytes, and the same accounting when the absorbed line is read in cached-K/V terms
     ck = _run(["--steps", "3", "--warmup", "1", "--model", "tiny", "--batch", "8", "--pipeline", "2", "--no-cpu-baseline", "--cross-attention", "cached"])

@@ -210,7 +210,8 @@ for i, (label, pat) in enumerate(cases):
     if all(have(f) and os.path.getsize(os.path.join(SRC, f)) > 0 for f in files):
         c, a = (json.loads(open(os.path.join(SRC, f)).read().strip().splitlines()[-1]) for f in files)
         rows.append((label, c["ms_per_step"], c["value"], a["ms_per_step"], a["value"]))
-if rows:
+# (sessions 5-6 data, 4 frame splits; R04_CROSS_TABLE=1 rewrites the table -- a later bench_default.json is a 2-split run from another box)
+if rows and os.environ.get("R04_CROSS_TABLE") == "1":
     with open(os.path.join(DST, "r04_cached_vs_absorbed.txt"), "w") as f:
         f.write("# bench.py --no-cpu-baseline --no-finetune --cross-attention {cached,absorbed} [...]   (MI355X, round 4; tools/r04_gpu_profile.sh, tools/r04_cross_sweep.sh)\n")
         f.write(f"# {'workload':66s} {'cached ms':>10s} {'audio-s/s':>10s} {'absorbed ms':>12s} {'audio-s/s':>10s} {'absorbed vs cached':>19s}\n")
