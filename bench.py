@@ -477,16 +477,16 @@ def roofline_cross_absorbed(model, B: int, st, iters: int = 48):
         if S * B <= 128:
             # a launch of <= 128 workgroups is MEANT to share the chip with another pass's launch: the same launches on two HIP
             # streams at once (separate scratch, the same encoder outputs), aggregate bytes over the wall time of both
-            s2 = torch.cuda.Stream()
+            s2 = stream(1)  # library stream 1 = where the second pass in flight decodes (its own hardware queue, like in the timed run)
             scratch2 = scratch.clone()
             s.synchronize()
             graphs = []
             for st_, sc_ in ((s, scratch), (s2, scratch2)):
                 g_ = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g_, stream=st_):
-                    for i in range(iters):
-                        _lib.check(L.wipa_cross_absorbed_stream(ptr(xas[(i // per_buf) % n_buf]), ptr(sc_), nbytes, B, H, dd, Ta, model.cross_splits,
-                                                                st_.cuda_stream), "wipa_cross_absorbed_stream")
+                    for i in range(iters):  # the second stream two encoder outputs behind the first: nothing shared at any time
+                        _lib.check(L.wipa_cross_absorbed_stream(ptr(xas[(i // per_buf + (2 if st_ is s2 else 0)) % n_buf]), ptr(sc_), nbytes, B, H, dd, Ta,
+                                                                model.cross_splits, st_.cuda_stream), "wipa_cross_absorbed_stream")
                 graphs.append((st_, g_))
             for rep in range(2):
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
