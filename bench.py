@@ -91,6 +91,8 @@ def rank_threads() -> int:
     return host_threads_per_rank()
 
 
+PHASE = ""          # --phase enc | dec: DIAGNOSTIC runs of one half of the pass (never a benchmark number)
+_PHASE_FEATS = {}
 BATCH = 64          # clips per GPU
 N_PIPELINE = 4      # consecutive passes kept in flight on separate HIP streams (see --pipeline).  Measured r01 with
                     # GPU_MAX_HW_QUEUES=8 (ms per 64-clip pass, repeatable to 0.5 %): 1 -> 133.2, 3 -> 98.8, 4 -> 94.7,
@@ -233,8 +235,19 @@ def pass_launch(model, audio_chunks, setup, stream_base: int):
     for sid, a in enumerate(audio_chunks):
         enc_sid = stream_base + sid if ENCODER_CUS is None else ENC_STREAM_BASE + (stream_base + sid) % ENC_STREAMS
         with use_stream(enc_sid) as s_enc:
+            key = (stream_base, sid)
+            if PHASE == "dec" and key in _PHASE_FEATS:  # DIAGNOSTIC (--phase dec): the decode loops alone, on the features of the warm-up pass
+                handles.append(greedy_launch(model, _PHASE_FEATS[key], init, always, first, eot, max_new_tokens=NEW_TOKENS))
+                continue
             mel = A.log_mel_padded(a, model.dims.n_mels, model.dtype)
             feats = model.encode_padded(mel, a.shape[0])
+            if PHASE == "enc" and key in _PHASE_FEATS:  # DIAGNOSTIC (--phase enc): log-mel + encoder alone
+                ev = torch.cuda.Event()
+                ev.record(s_enc)
+                handles.append(ev)
+                continue
+            if PHASE:
+                _PHASE_FEATS[key] = feats
             if DECODE_SPLIT <= 1 and ENCODER_CUS is None:
                 handles.append(greedy_launch(model, feats, init, always, first, eot, max_new_tokens=NEW_TOKENS))
                 continue
@@ -279,6 +292,10 @@ def group_launch(model, audio, setup, stream_id: int, n_batches: int):
 def pass_collect(handles):
     from whisper_ipa_amd.decoding import greedy_collect
 
+    if handles and isinstance(handles[0], torch.cuda.Event):  # --phase enc
+        for h in handles:
+            h.synchronize()
+        return np.zeros((1, 1), np.int64)
     return np.concatenate([greedy_collect(h).tokens for h in handles], axis=0)
 
 
@@ -450,7 +467,7 @@ def roofline_cross_absorbed(model, B: int, st, iters: int = 48):
 
         def full(i):
             _lib.check(L.wipa_cross_absorbed_attention(ptr(q), dd, ptr(wkT), ptr(xas[(i // per_buf) % n_buf]), ptr(wkv[dd:]), ptr(bkv[dd:]), ptr(out), dd,
-                                                       ptr(scratch), nbytes, B, H, dd, Ta, 64 ** -0.25, sptr(s)), "wipa_cross_absorbed_attention")
+                                                       ptr(scratch), nbytes, B, H, dd, Ta, 64 ** -0.25, model.cross_splits, sptr(s)), "wipa_cross_absorbed_attention")
 
         def stream_only(i):
             _lib.check(L.wipa_cross_absorbed_stream(ptr(xas[(i // per_buf) % n_buf]), ptr(scratch), nbytes, B, H, dd, Ta, model.cross_splits, sptr(s)),
@@ -985,7 +1002,7 @@ def measure_train(args, rank, world, dist, steps, warmup):
 
 
 def main():
-    global DECODE_SPLIT, ENCODER_CUS, NEW_TOKENS
+    global DECODE_SPLIT, ENCODER_CUS, NEW_TOKENS, PHASE
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
@@ -1026,13 +1043,16 @@ def main():
                          "block-scaled fp8 MFMA (LayerNorm / GELU outputs quantised per row) -- configs[4] '(CDNA4 fp8 MFMA)'")
     ap.add_argument("--f32", default="exact", choices=["exact", "split"],
                     help="float32 runs: exact f32 MFMA products (default, as the reference computes) or the split-bf16 opt-in")
+    ap.add_argument("--phase", default="", choices=["", "enc", "dec"],
+                    help="DIAGNOSTIC: time only log-mel + encoder (enc) or only the decode loops on the warm-up pass's features (dec) with "
+                         "the same passes in flight; prints ms per pass and exits -- not a benchmark line")
     ap.add_argument("--train-batch", type=int, default=32)
     ap.add_argument("--train-tokens", type=int, default=64)
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
-    DECODE_SPLIT, ENCODER_CUS, NEW_TOKENS = args.decode_split, args.encoder_cus, args.new_tokens
+    DECODE_SPLIT, ENCODER_CUS, NEW_TOKENS, PHASE = args.decode_split, args.encoder_cus, args.new_tokens, args.phase
     torch.set_num_threads(rank_threads())  # cores / LOCAL_WORLD_SIZE: eight ranks must not ask for 8 x 16 host threads
     if args.mode == "train":
         return run_train(args)
@@ -1103,6 +1123,14 @@ def main():
     timed_barrier(dist)
     elapsed = max_over_ranks(dist, time.perf_counter() - t0)
 
+    if PHASE:
+        if rank == 0:
+            print(json.dumps({"diagnostic_phase": PHASE, "ms_per_pass": round(1000.0 * elapsed / args.steps, 2), "passes_in_flight": args.pipeline,
+                              "cross_frame_splits": model.cross_splits or 4, "note": "one half of the pass only: NOT a benchmark number"}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     out = None
     absorbed_run = bench_absorbed(model, audio_chunks[0].shape[0])
     if rank == 0:

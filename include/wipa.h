@@ -312,7 +312,7 @@ size_t wipa_cross_absorbed_scratch_bytes(int B, int d, int Tk);
 int wipa_cross_absorbed_init(int d);
 int wipa_cross_absorbed_attention(const void* q, int64_t q_row_stride, const void* wkT, const void* xa, const void* wv, const float* bv,
                                   void* out, int64_t out_row_stride, void* scratch, size_t scratch_bytes, int B, int H, int d, int Tk,
-                                  float k_scale, wipa_stream_t s);
+                                  float k_scale, int n_splits, wipa_stream_t s);
 /* The absorbed cross block of ONE decode step in three launches (the decode loop's form; wipa_cross_absorbed_attention with a
  * given query serves the prompt prefill and the tests): [split-K slab sum + residual + cross_attn_ln + cross query + absorbed query]
  * -> streaming kernel -> [merge + value projection].  The descriptor is wipa_decode_cross_block's with c->kv = the encoder output

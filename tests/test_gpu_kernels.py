@@ -901,7 +901,7 @@ def test_cross_attention_with_absorbed_projections(B, H, Tk):
         nbytes = L.wipa_cross_absorbed_scratch_bytes(B, d, Tk)
         scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
         _lib.check(L.wipa_cross_absorbed_attention(ptr(qd[:, 1]), 2 * d, ptr(wkT), ptr(xad), ptr(wvd), ptr(bvd), ptr(out[:, 2]), 3 * d,
-                                                   ptr(scratch), nbytes, B, H, d, Tk, scale, sptr(s)), "wipa_cross_absorbed_attention")
+                                                   ptr(scratch), nbytes, B, H, d, Tk, scale, 0, sptr(s)), "wipa_cross_absorbed_attention")
     torch.cuda.synchronize()
     qq = q[:, 1].double().view(B, H, 64)
     K = (xa.double() @ wk.double().T * scale).view(B, Tk, H, 64)
@@ -945,7 +945,7 @@ def test_cross_attention_absorbed_when_scores_climb_past_the_fixed_reference(H, 
         scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
         for _ in range(2):
             _lib.check(L.wipa_cross_absorbed_attention(ptr(qd), d, ptr(wkT), ptr(xad), ptr(wvd), ptr(bvd), ptr(out), d, ptr(scratch), nbytes,
-                                                       B, H, d, Tk, scale, sptr(s)), "wipa_cross_absorbed_attention")
+                                                       B, H, d, Tk, scale, 0, sptr(s)), "wipa_cross_absorbed_attention")
     torch.cuda.synchronize()
     # reference from the bf16-rounded absorbed queries the kernel itself uses (the ramp amplifies their rounding: a score of 200
     # moves by ~0.4 when q' moves by one bf16 ulp, which is a property of the input, not of the kernel)
@@ -986,7 +986,7 @@ def test_cross_attention_absorbed_is_deterministic_with_four_streams_in_flight()
 
     def call(i):
         _lib.check(L.wipa_cross_absorbed_attention(ptr(q), d, ptr(wkT), ptr(xa), ptr(wv), ptr(bv), ptr(outs[i]), d, ptr(scr[i]), nbytes, B, H, d,
-                                                   Tk, 64 ** -0.25, streams[i].cuda_stream))
+                                                   Tk, 64 ** -0.25, 0, streams[i].cuda_stream))
 
     call(0)
     torch.cuda.synchronize()

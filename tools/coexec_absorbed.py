@@ -28,7 +28,7 @@ nbytes = L.wipa_cross_absorbed_scratch_bytes(B, d, Tk)
 scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
 _lib.check(L.wipa_cross_absorbed_init(d))
 _lib.check(L.wipa_cross_absorbed_attention(ptr(q), d, ptr(wkT), ptr(xas[0]), ptr(wv), ptr(bv), ptr(out), d, ptr(scratch), nbytes, B, H, d, Tk,
-                                           64 ** -0.25, sptr(torch.cuda.current_stream())))
+                                           64 ** -0.25, 0, sptr(torch.cuda.current_stream())))
 torch.cuda.synchronize()
 xs = torch.randn(64, 768, device="cuda", generator=g).bfloat16()
 Ws = (torch.randn(768, 768, device="cuda", generator=g) * 0.05).bfloat16()

@@ -29,7 +29,7 @@ streams = [torch.cuda.Stream() for _ in range(4)]
 scr = [torch.empty(nbytes, dtype=torch.uint8, device="cuda") for _ in range(4)]
 for i in range(4):
     _lib.check(L.wipa_cross_absorbed_attention(ptr(q), d, ptr(wkT), ptr(xas[0]), ptr(wv), ptr(bv), ptr(out), d, ptr(scr[i]), nbytes, B, H, d, Tk,
-                                               64 ** -0.25, streams[i].cuda_stream))
+                                               64 ** -0.25, 0, streams[i].cuda_stream))
 torch.cuda.synchronize()
 
 

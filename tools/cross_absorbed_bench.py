@@ -32,7 +32,7 @@ with on_stream() as s:
     def launch(i, rotate):
         xa = xas[i % N_BUF] if rotate else xas[0]
         _lib.check(L.wipa_cross_absorbed_attention(ptr(q), d, ptr(wkT[i % 12]), ptr(xa), ptr(wv[i % 12]), ptr(bv), ptr(out), d, ptr(scratch),
-                                                   nbytes, B, H, d, Tk, 64 ** -0.25, sptr(s)))
+                                                   nbytes, B, H, d, Tk, 64 ** -0.25, 0, sptr(s)))
 
     for rotate in (False, True):
         for i in range(12):

@@ -32,7 +32,7 @@ torch.cuda.synchronize()
 
 def call(i):
     _lib.check(L.wipa_cross_absorbed_attention(ptr(q), d, ptr(wkT), ptr(xa), ptr(wv), ptr(bv), ptr(outs[i]), d, ptr(scr[i]), nbytes, B, H, d,
-                                               Tk, 64 ** -0.25, streams[i].cuda_stream))
+                                               Tk, 64 ** -0.25, 0, streams[i].cuda_stream))
 
 
 call(0)

@@ -33,7 +33,7 @@ n_bad = 0
 kinds = {"loaded_stats": 0, "computed_weights": 0, "readback_other_wave": 0, "readback_thread0": 0}
 for it in range(int(os.environ.get("DUMP_ITERS", "200"))):
     _lib.check(L.wipa_cross_absorbed_attention(ptr(q), d, ptr(wkT), ptr(xa), ptr(wv), ptr(bv), ptr(out), d, ptr(scr), nbytes, B, H, d, Tk,
-                                               64 ** -0.25, st.cuda_stream))
+                                               64 ** -0.25, 0, st.cuda_stream))
     torch.cuda.synchronize()
     dump = out.view(torch.int16).cpu().numpy().view(np.float32).reshape(B, H, 32)  # 64 bf16 = 32 floats per (clip, head)
     stats = scr[B * 16 * d * 2:].cpu().numpy().view(np.float32)

@@ -34,7 +34,7 @@ torch.cuda.synchronize()
 n_glitch = n_w_bad = 0
 for it in range(int(os.environ.get("DUMP_ITERS", "300"))):
     _lib.check(L.wipa_cross_absorbed_attention(ptr(q), d, ptr(wkT), ptr(xa), ptr(wv), ptr(bv), ptr(out), d, ptr(scr), nbytes, B, H, d, Tk,
-                                               64 ** -0.25, st.cuda_stream))
+                                               64 ** -0.25, 0, st.cuda_stream))
     torch.cuda.synchronize()
     diff = (out != base)
     stats = scr[B * 16 * d * 2:].cpu().numpy().view(np.float32)

@@ -36,7 +36,7 @@ with on_stream() as s:
     scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
     # one whole call fills the absorbed queries the streaming kernel reads
     _lib.check(L.wipa_cross_absorbed_attention(ptr(q), d, ptr(wkT), ptr(xas[0]), ptr(wv), ptr(bv), ptr(out), d, ptr(scratch), nbytes, B, H, d, Tk,
-                                               64 ** -0.25, sptr(s)))
+                                               64 ** -0.25, 0, sptr(s)))
 
     def launch(i):
         _lib.check(L.wipa_cross_absorbed_stream(ptr(xas[(i // PER_BUF) % NBUF]), ptr(scratch), nbytes, B, H, d, Tk, SPLITS, sptr(s)))

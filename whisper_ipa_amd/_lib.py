@@ -125,7 +125,7 @@ SIGNATURES = {
     "wipa_cross_absorbed_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
     "wipa_cross_absorbed_init": (c_int, [c_int]),
     "wipa_cross_absorbed_attention": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_size_t,
-                                              c_int, c_int, c_int, c_int, c_float, c_void_p]),
+                                              c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "wipa_cross_absorbed_stream": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "wipa_decode_cross_absorbed_block": (c_int, [_P(CrossBlockDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wipa_decode_cross_absorbed_block_out": (c_int, [_P(CrossBlockDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,

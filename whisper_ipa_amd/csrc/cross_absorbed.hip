@@ -1121,8 +1121,9 @@ extern "C" int wipa_cross_absorbed_stream(const void* xa, void* scratch, size_t 
 
 extern "C" int wipa_cross_absorbed_attention(const void* q, int64_t q_row_stride, const void* wkT, const void* xa, const void* wv,
                                              const float* bv, void* out, int64_t out_row_stride, void* scratch, size_t scratch_bytes,
-                                             int B, int H, int d, int Tk, float k_scale, wipa_stream_t stream) {
+                                             int B, int H, int d, int Tk, float k_scale, int n_splits, wipa_stream_t stream) {
     WIPA_REQUIRE(q && wkT && xa && wv && bv && out && scratch, "wipa_cross_absorbed_attention: null pointer");
+    WIPA_REQUIRE(n_splits >= 0 && n_splits <= 4, "wipa_cross_absorbed_attention: n_splits %d (0 = default, 1..4)", n_splits);
     WIPA_REQUIRE(B > 0 && B <= 65535 && H >= 1 && H <= 16 && d == H * 64 && (d == 384 || d == 512 || d == 768 || d == 1024) && Tk >= 1,
                  "wipa_cross_absorbed_attention: bf16, <= 16 heads of 64, d in {384, 512, 768, 1024} (got H=%d d=%d)", H, d);
     WIPA_REQUIRE(q_row_stride % 8 == 0 && out_row_stride >= d && ((uintptr_t)q % 16) == 0 && ((uintptr_t)xa % 16) == 0 &&
@@ -1135,7 +1136,7 @@ extern "C" int wipa_cross_absorbed_attention(const void* q, int64_t q_row_stride
         const int rc0 = wipa_cross_absorbed_init(d);  // once per width
         if (rc0 != WIPA_OK) return rc0;
     }
-    const int S = wipa_cross_absorbed_splits(0, Tk);
+    const int S = wipa_cross_absorbed_splits(n_splits, Tk);
     char* sc = (char*)scratch;
     __bf16* qp = (__bf16*)sc;
     float* part_m = (float*)(sc + (size_t)B * 16 * d * 2);

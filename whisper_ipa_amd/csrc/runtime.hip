@@ -528,7 +528,7 @@ int enqueue_step(const wipa_model_cfg* cfg, const void* const* w, char* st, cons
                 const void* wkT = w[WIPA_DEC_GLOBAL + WIPA_DEC_PER_LAYER * cfg->n_text_layer + WIPA_DEC_ABSORBED_PER_LAYER * l];
                 RT_CALL(wipa_cross_absorbed_attention(q, d, wkT, st + L.cross_kv, (const char*)lw[10] + (size_t)d * d * e,
                                                       (const float*)lw[11] + d, ao, d, sc + S.absorbed, S.total - S.absorbed, B, H, d, Ta,
-                                                      QK_SCALE, stream));
+                                                      QK_SCALE, cfg->dec_cross_splits, stream));
             } else {
                 RT_CALL(wipa_decode_cross_attn(q, ckv, ao, B, H, Ta, dt, stream));
             }
@@ -737,7 +737,7 @@ int enqueue_prefill(const wipa_model_cfg* cfg, const void* const* w, char* st, c
                 RT_CALL(wipa_cross_absorbed_attention((const char*)q + (size_t)t * d * e, (int64_t)P * d, wkT, st + L.cross_kv,
                                                       (const char*)lw[10] + (size_t)d * d * e, (const float*)lw[11] + d,
                                                       (char*)ao + (size_t)t * d * e, (int64_t)P * d, sc + S.absorbed, S.total - S.absorbed, B,
-                                                      H, d, Ta, QK_SCALE, stream));
+                                                      H, d, Ta, QK_SCALE, cfg->dec_cross_splits, stream));
         } else {
             RT_CALL(wipa_decode_cross_attn_multi(q, ckv, ao, B, H, Ta, P, dt, stream));
         }
