@@ -1200,6 +1200,8 @@ def main():
                                          "decode_step_ms": dflt["ms_per_step"], "decode_step_frac": dflt["frac"],
                                          "streaming_launch": {k: rf4[k] for k in ("workgroups", "avg_launch_ms", "achieved", "frac", "traffic",
                                                                                   "algorithmic_bytes_per_launch")}}
+                # next to the timed setting's own figures: the same kernel as the library launches it by default (all 256 CUs)
+                out["roofline"]["library_default_setting"] = dict(out["default_splits"]["streaming_launch"], frame_splits=4)
                 model.cross_splits = keep
                 one_pass(model, audio_chunks, setup)  # back to the timed setting: the parity legs below check what was timed
             if args.dtype == "bf16" and args.batch <= 128:
