@@ -83,6 +83,10 @@ def test_bench_experiment_flags_keep_the_ids():
     assert limited["tokens_checksum"] == plain["tokens_checksum"]
     longer = _run(base + ["--new-tokens", "100"])
     assert longer["config"]["new_tokens"] == 100 and longer["passes_identical"]
+    # --phase: the two halves of the pass alone (diagnostic lines that cannot be mistaken for the metric)
+    for phase in ("enc", "dec"):
+        d = _run(base + ["--phase", phase])
+        assert d["diagnostic_phase"] == phase and d["ms_per_pass"] > 0 and "metric" not in d and "value" not in d
 
 
 def test_bench_gpus_2_launches_two_ranks():
