@@ -355,6 +355,26 @@ int wipa_greedy_step_embed(const float* logits, int64_t ldl, int B, int V, const
                            int eot, float* sum_logprobs, int32_t* not_done, const void* tok_emb, int emb_dtype,
                            const float* emb_scale, const float* pos_emb, int n_ctx, float* x, const float* ln_w, const float* ln_b,
                            void* y, int y_dtype, int D, float eps, wipa_stream_t s);
+/* The logits projection of a greedy decode step together with the arg-max / log-sum-exp PARTIALS of its filtered rows (round 4):
+ * logits[b][v] = x[b] . W[v] (x [B, d] bf16, row stride ldx; W [V, d] bf16 -- TextDecoder's tied token_embedding, mlx_whisper;
+ * transcribe_single.py:55) on the persistent wide kernel of wipa_gemm, whose waves also keep, per row, max / arg-max (lowest column
+ * on ties) / sum of exponentials of logit + mask over the columns they compute (mask = mask_first when *pos_dev + 1 == n_init, else
+ * mask_always; 0 / -inf, f32 [V]) and write one partial per (row, wave): partials [B][3][WIPA_GREEDY_PARTS] f32 (max | sum exp |
+ * arg-max as int32).  logits may be NULL: then the 13 MB of logits are neither written nor read back (the steps of a greedy loop
+ * whose logits nobody looks at).  bf16, B <= 64, V >= 8192, d in {384, 512, 768, 1024} (wipa_logits_greedy_supported).
+ * wipa_greedy_step_embed_partials is wipa_greedy_step_embed on those partials instead of the logits: the same tokens; the
+ * log-probability sum differs from the row scan's in the last bits (another summation order, fixed and batch-independent). */
+#define WIPA_GREEDY_PARTS 2048
+int wipa_logits_greedy_supported(int B, int V, int d, int dtype);
+size_t wipa_logits_greedy_partials_bytes(int B);
+int wipa_logits_greedy(const void* x, int64_t ldx, const void* w, int64_t ldw, float* logits, int64_t ldl, int B, int V, int d,
+                       const float* mask_first, const float* mask_always, const int32_t* pos_dev, int n_init, float* partials,
+                       size_t partials_bytes, wipa_stream_t s);
+int wipa_greedy_step_embed_partials(const float* partials, int n_parts, int B, int32_t* tokens, int64_t ld_tok, int32_t* pos_dev,
+                                    int64_t* posd_dev, int32_t* done_counter, int n_init, int eot, float* sum_logprobs,
+                                    int32_t* not_done, const void* tok_emb, int emb_dtype, const float* emb_scale, const float* pos_emb,
+                                    int n_ctx, float* x, const float* ln_w, const float* ln_b, void* y, int y_dtype, int D, float eps,
+                                    wipa_stream_t s);
 /* The same row routine alone, for the token ALREADY at position p = *pos_dev: x[b] = tok_emb[tokens[b][p]] + pos_emb[p],
  * y[b] = LayerNorm(x[b]).  wipa_decoder_run launches it once before its first step. */
 int wipa_embed_layernorm(const int32_t* tokens, int64_t ld_tok, int B, const int32_t* pos_dev, const void* tok_emb, int emb_dtype,

@@ -1121,6 +1121,92 @@ def test_absorbed_cross_block_frame_splits_are_a_property_of_the_call(H, Tk):
     c.cross_splits = 5
     assert L.wipa_decode_cross_absorbed_block(C.byref(c), None, None, None, None, 0, None) != 0
 
+@pytest.mark.parametrize("B,V,d,n_init", [(64, 51865, 768, 4), (5, 51865, 384, 4), (33, 8200, 512, 1), (64, 51865, 1024, 4)])
+def test_logits_projection_with_greedy_partials(B, V, d, n_init):
+    """Round 4: wipa_logits_greedy = the persistent wide GEMM of the logits projection whose waves also keep max / arg-max / sum-exp
+    of the filtered logits, + wipa_greedy_step_embed_partials = the step tail on those partials.  Against wipa_gemm +
+    wipa_greedy_step_embed on the same inputs: the logits bit-identical (when asked for; to 1e-5 for <= 32 rows, where wipa_gemm
+    runs another kernel), the chosen ids identical -- with
+    DUPLICATED weight rows, so that maxima tie across waves, lanes and tiles and the lowest column must win -- the log-prob sums
+    equal to 1e-6 relative, the EOT latch, the next position's embedding / LayerNorm rows and the position advance identical;
+    with logits = NULL nothing is written to the logits buffer; both masks (first / always by position); ragged B and V."""
+    from whisper_ipa_amd import _lib, ops
+    from whisper_ipa_amd.runtime import on_stream, ptr, sptr
+
+    L = _lib.lib()
+    assert L.wipa_logits_greedy_supported(B, V, d, _lib.WIPA_BF16) == 1 and L.wipa_logits_greedy_supported(65, V, d, _lib.WIPA_BF16) == 0
+    assert L.wipa_logits_greedy_supported(B, 4096, d, _lib.WIPA_BF16) == 0 and L.wipa_logits_greedy_supported(B, V, d, _lib.WIPA_F32) == 0
+    g = torch.Generator(device="cuda").manual_seed(B + d)
+    rn = lambda *sh, s=1.0: torch.randn(*sh, device="cuda", generator=g) * s
+    ldl, n_ctx, eot = (V + 7) // 8 * 8, 448, 50257 if V > 50257 else 7
+    W = rn(V, d, s=0.05).bfloat16()
+    # ties: copies of the winning rows further up AND further down the vocabulary (other tiles, other waves, other lane groups)
+    x = rn(B, d).bfloat16()
+    with on_stream() as s:
+        base = torch.empty(B, ldl, device="cuda")
+        ops.gemm(x, W, base, M=B, N=V, K=d, lda=d, ldw=d, ldc=ldl)
+    torch.cuda.synchronize()
+    win = base[:, :V].argmax(1)
+    for b in range(0, B, 3):
+        for dst in (int(win[b]) + 16 * 2048 + 5, int(win[b]) - 4099, V - 1 - b):
+            if 0 <= dst < V and dst != eot:
+                W[dst] = W[int(win[b])]
+    mask_always = torch.zeros(ldl, device="cuda")
+    mask_always[torch.randperm(V, device="cuda", generator=g)[:200]] = float("-inf")
+    mask_first = mask_always.clone()
+    mask_first[int(win[0])] = float("-inf")  # the first-position mask removes row 0's winner
+    emb, pos_emb = W, rn(n_ctx, d, s=0.02)
+    ln_w, ln_b = 1 + 0.1 * rn(d), 0.1 * rn(d)
+
+    def run(fused, p0, store):
+        tokens = torch.full((B, n_ctx + 8), 1, dtype=torch.int32, device="cuda")
+        tokens[2 % B, p0] = eot  # this row is latched
+        pos = torch.tensor([p0], dtype=torch.int32, device="cuda")
+        posd = torch.zeros(1, dtype=torch.int64, device="cuda")
+        done = torch.zeros(1, dtype=torch.int32, device="cuda")
+        slp = torch.zeros(B, device="cuda")
+        nd = torch.zeros(1, dtype=torch.int32, device="cuda")
+        logits = torch.full((B, ldl), 7.0, device="cuda")
+        xo, yo = torch.empty(B, d, device="cuda"), torch.empty(B, d, device="cuda", dtype=torch.bfloat16)
+        with on_stream() as s:
+            if fused:
+                nb = L.wipa_logits_greedy_partials_bytes(B)
+                part = torch.empty(nb, dtype=torch.uint8, device="cuda")
+                _lib.check(L.wipa_logits_greedy(ptr(x), d, ptr(W), d, ptr(logits) if store else None, ldl, B, V, d, ptr(mask_first), ptr(mask_always),
+                                                ptr(pos), n_init, ptr(part), nb, sptr(s)), "wipa_logits_greedy")
+                _lib.check(L.wipa_greedy_step_embed_partials(ptr(part), _lib.GREEDY_PARTS, B, ptr(tokens), n_ctx + 8, ptr(pos), ptr(posd), ptr(done),
+                                                             n_init, eot, ptr(slp), ptr(nd), ptr(emb), _lib.WIPA_BF16, None, ptr(pos_emb), n_ctx,
+                                                             ptr(xo), ptr(ln_w), ptr(ln_b), ptr(yo), _lib.WIPA_BF16, d, 1e-5, sptr(s)))
+            else:
+                ops.gemm(x, W, logits, M=B, N=V, K=d, lda=d, ldw=d, ldc=ldl)
+                _lib.check(L.wipa_greedy_step_embed(ptr(logits), ldl, B, V, ptr(mask_first), ptr(mask_always), ptr(tokens), n_ctx + 8, ptr(pos),
+                                                    ptr(posd), ptr(done), n_init, eot, ptr(slp), ptr(nd), ptr(emb), _lib.WIPA_BF16, None,
+                                                    ptr(pos_emb), n_ctx, ptr(xo), ptr(ln_w), ptr(ln_b), ptr(yo), _lib.WIPA_BF16, d, 1e-5, sptr(s)))
+        torch.cuda.synchronize()
+        return tokens[:, p0 + 1].cpu(), slp.cpu(), logits.cpu(), xo.cpu(), yo.cpu(), int(pos), int(posd), int(nd), int(done)
+
+    for p0 in (n_init - 1, n_init + 3):  # the first generated position (mask_first) and a later one (mask_always)
+        ref = run(False, p0, True)
+        for store in (True, False):
+            got = run(True, p0, store)
+            assert torch.equal(got[0], ref[0]), (p0, store, (got[0] != ref[0]).nonzero().flatten().tolist())
+            assert torch.allclose(got[1], ref[1], rtol=1e-6, atol=1e-6), (p0, store)
+            if store and B > 32:  # the same kernel arithmetic (wipa_gemm sends > 32 rows to the persistent wide kernel too)
+                assert torch.equal(got[2][:, :V], ref[2][:, :V])
+            elif store:  # <= 32 rows: wipa_gemm splits K over the waves of a workgroup -- another summation order
+                assert torch.allclose(got[2][:, :V], ref[2][:, :V], rtol=1e-5, atol=1e-5)
+            else:
+                assert bool((got[2] == 7.0).all())  # untouched
+            assert torch.equal(got[3], ref[3]) and torch.equal(got[4], ref[4]) and got[5:] == ref[5:], (p0, store)
+        filt = ref[2][:, :V] + (mask_first if p0 + 1 == n_init else mask_always)[:V].cpu()
+        want = filt.argmax(1).int()  # torch: first maximum
+        want[2 % B] = eot
+        assert torch.equal(ref[0], want) and ref[5] == p0 + 1 and ref[6] == (p0 + 1) * d and ref[8] == 0
+        lp = torch.log_softmax(filt.double(), 1).gather(1, filt.argmax(1, keepdim=True)).flatten().float()
+        lp[2 % B] = 0.0
+        assert torch.allclose(got[1], lp, rtol=1e-4, atol=1e-4)
+
+
 def test_gemm_fp8_384x256_tile_in_a_subprocess():
     """Round 4: gemm_fp8_384_kernel (fp8 x fp8 on the 384 x 256 tile; WIPA_GEMM_FP8_TILE=384 forces it, read once per process).
     EXACT on small integers with asymmetric operands (a row <-> column swap, a wrong k-group or LDS chunk would show), ragged

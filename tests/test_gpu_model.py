@@ -266,6 +266,9 @@ def test_fused_step_tail_is_bit_identical_to_the_separate_launches(micro, small2
     cases = [(MICRO, micro, "auto", False)]
     if dtype == torch.bfloat16:
         cases += [(SMALL2, small2, "absorbed", False), (SMALL2, small2, "cached", False), (SMALL2, small2, "auto", True)]
+    # the row-scanning tail: the logits projection that carries the greedy partials (another summation order of the log-prob;
+    # test_logits_projection_with_greedy_partials_*) is switched off for both sides
+    monkeypatch.setenv("WIPA_LOGITS_FUSED", "0")
     for dims, (W, mels, xa), cross, fp8 in cases:
         m = _model(dims, W, dtype, cross_attention=cross)
         if fp8:
@@ -299,6 +302,58 @@ def test_fused_step_tail_is_bit_identical_to_the_separate_launches(micro, small2
                 assert torch.equal(a[2], b[2]), (cross, fp8, k)
         g, e = out["1"][0], out["1"][1]
         assert (g[0] == e[0]).all() and torch.equal(g[2], e[2])  # graph == eager
+
+
+def test_logits_projection_with_greedy_partials_keeps_ids_and_last_logits(small2, monkeypatch):
+    """Round 4: the decode step's logits projection keeps per-(row, wave) max / arg-max / sum-exp partials of the filtered logits
+    (wipa_logits_greedy) and the step's last launch merges them (wipa_greedy_step_embed_partials) instead of reading the logits
+    back; every step of a run() call but the last does not write its logits at all.  Against WIPA_LOGITS_FUSED=0 (plain GEMM +
+    row-scanning tail): token ids identical, the logits of the last step and the log-probability sums equal up to the summation
+    order (1e-5 relative; bit-identical logits at > 32 rows: tests/test_gpu_kernels.py) -- graph and eager, one run() call and several (check_every), the prompt walked step by step,
+    a bare [sot] prompt, a forced history (every step's logits are read: all must be written), both cross-attention forms; and a
+    clip's ids / log-probs do not depend on the batch it rides in."""
+    from whisper_ipa_amd.decoding import forced_decode_logits, greedy_decode_tokens
+
+    W, mels, xa = small2
+    sp = R.SpecialTokens.multilingual()
+    always, first = R.suppress_lists(sp)
+    init = list(sp.sot_sequence_including_notimestamps(0))
+    feats = xa.cuda().to(torch.bfloat16)
+    for cross in ("absorbed", "cached"):
+        m = _model(SMALL2, W, torch.bfloat16, cross_attention=cross)
+        out = {}
+        for fused in ("1", "0"):
+            monkeypatch.setenv("WIPA_LOGITS_FUSED", fused)
+            res = []
+            for use_graph in (True, False):
+                r = greedy_decode_tokens(m, feats, init, always, first, sp.eot, max_new_tokens=21, stop_on_eot=False, use_graph=use_graph)
+                res.append((r.tokens, r.sum_logprobs.copy(), r.last_logits.float().cpu().clone()))
+            r = greedy_decode_tokens(m, feats, init, always, first, sp.eot, max_new_tokens=21, stop_on_eot=True, check_every=3)
+            res.append((r.tokens, r.sum_logprobs.copy(), None))
+            monkeypatch.setenv("WIPA_NO_PREFILL", "1")
+            r = greedy_decode_tokens(m, feats, init, always, first, sp.eot, max_new_tokens=9, stop_on_eot=False)
+            res.append((r.tokens, r.sum_logprobs.copy(), r.last_logits.float().cpu().clone()))
+            monkeypatch.delenv("WIPA_NO_PREFILL")
+            r = greedy_decode_tokens(m, feats, init[:1], always, first, sp.eot, max_new_tokens=5, stop_on_eot=False)  # bare [sot]
+            res.append((r.tokens, r.sum_logprobs.copy(), r.last_logits.float().cpu().clone()))
+            hist = res[0][0][:, : 4 + 10].copy()
+            hist[:, 6] = 1000 + np.arange(hist.shape[0])
+            tr, chosen = forced_decode_logits(m, feats, hist, 4, always, first, sp.eot)
+            res.append((chosen, np.zeros(1), tr.float().cpu().clone()))
+            one = greedy_decode_tokens(m, feats[1:2].contiguous(), init, always, first, sp.eot, max_new_tokens=21, stop_on_eot=False)
+            res.append((one.tokens, one.sum_logprobs.copy(), None))
+            out[fused] = res
+        monkeypatch.delenv("WIPA_LOGITS_FUSED")
+        for k, (a, b) in enumerate(zip(out["1"], out["0"])):
+            assert a[0].shape == b[0].shape and (a[0] == b[0]).all(), (cross, k, a[0].tolist(), b[0].tolist())
+            assert np.allclose(a[1], b[1], rtol=1e-5, atol=1e-5), (cross, k, a[1], b[1])
+            if a[2] is not None:  # (a few rows: the plain path's GEMM splits K over waves -- equal up to the summation order)
+                fin = torch.isfinite(b[2])
+                assert torch.equal(fin, torch.isfinite(a[2])) and torch.allclose(a[2][fin], b[2][fin], rtol=1e-5, atol=1e-5), (cross, k)
+        # graph == eager bit for bit, and clip 1 alone == clip 1 in the batch (ids and log-prob sum)
+        g, e, alone = out["1"][0], out["1"][1], out["1"][-1]
+        assert (g[0] == e[0]).all() and np.array_equal(g[1], e[1]) and torch.equal(g[2], e[2])
+        assert (alone[0][0] == g[0][1]).all() and alone[1][0] == g[1][1]
 
 
 def test_absorbed_cross_block_fused_prologue_equals_separate_launches(small2, monkeypatch):

@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwipa.so")
 
 WIPA_F32, WIPA_BF16, WIPA_FP8_E4M3 = 0, 1, 2
+GREEDY_PARTS = 2048  # WIPA_GREEDY_PARTS
 ENC_GLOBAL, ENC_PER_LAYER = 7, 14
 DEC_GLOBAL, DEC_PER_LAYER, DEC_FP8_PER_LAYER = 4, 20, 6
 GEMM_DISPATCH = ("tile128", "tile256", "tile384", "tile384n", "tile256p", "skinny", "skinny_fp8", "skinny_ln", "kmajor", "split_k",
@@ -136,6 +137,13 @@ SIGNATURES = {
     "wipa_greedy_step_embed": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                        c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "wipa_logits_greedy_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "wipa_logits_greedy_partials_bytes": (c_size_t, [c_int]),
+    "wipa_logits_greedy": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                   c_int, c_void_p, c_size_t, c_void_p]),
+    "wipa_greedy_step_embed_partials": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                                c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                c_int, c_int, c_float, c_void_p]),
     "wipa_embed_layernorm": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "wipa_bpe_create": (c_void_p, [c_void_p, c_void_p, c_void_p, c_int]),

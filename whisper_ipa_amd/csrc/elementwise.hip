@@ -427,6 +427,7 @@ struct TailParams {
     float* sum_logprobs; int32_t* not_done;
     const void* emb; int emb_dtype; const float* emb_scale; const float* pos_emb;
     float* x; const float* ln_w; const float* ln_b; void* y; int D; float eps;
+    const float* part; int n_part;  // wipa_logits_greedy's partials [B][3][n_part] instead of the logits (part != nullptr)
 };
 
 template <typename TO>
@@ -454,6 +455,38 @@ __global__ __launch_bounds__(GS_THREADS) void greedy_tail_kernel(TailParams q) {
     int next;
     if (p + 1 < q.n_init) {  // prompt walk: the token is already in place (uniform branch: p is the same for every thread)
         next = q.tokens[(int64_t)b * q.ld_tok + p + 1];
+    } else if (q.part) {
+        // the logits GEMM left one (max, sum exp, arg-max) per wave of its grid for this row: merge them -- (value, lowest column)
+        // for the arg-max, then sum_i s_i exp(m_i - M) in a fixed order (per thread ascending, wave tree, waves in order)
+        const float* pm = q.part + (int64_t)b * 3 * q.n_part;
+        const float* ps = pm + q.n_part;
+        const int* pi = reinterpret_cast<const int*>(pm + 2 * q.n_part);
+        MaxIdx m{-INFINITY, 0x7fffffff};
+        for (int i = tid; i < q.n_part; i += GS_THREADS) m = better(m, MaxIdx{pm[i], pi[i]});
+        m = wave_argmax(m);
+        if (lane == 0) {
+            s_v[wave] = m.v;
+            s_i[wave] = m.i;
+        }
+        __syncthreads();
+        MaxIdx bm{s_v[0], s_i[0]};
+#pragma unroll
+        for (int w = 1; w < GS_THREADS / 64; ++w) bm = better(bm, MaxIdx{s_v[w], s_i[w]});
+        float se = 0.f;
+        for (int i = tid; i < q.n_part; i += GS_THREADS) se += ps[i] * __expf(pm[i] - bm.v);
+        se = wave_reduce_sum(se);
+        if (lane == 0) s_sum[wave] = se;
+        __syncthreads();
+        const int prev = q.tokens[(int64_t)b * q.ld_tok + p];
+        next = (prev == q.eot) ? q.eot : bm.i;
+        if (tid == 0) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < GS_THREADS / 64; ++w) tot += s_sum[w];
+            if (prev != q.eot) q.sum_logprobs[b] += -logf(tot);
+            q.tokens[(int64_t)b * q.ld_tok + p + 1] = next;
+            if (next != q.eot) atomicAdd(q.not_done, 1);
+        }
     } else {
         const float* mask = (p + 1 == q.n_init) ? q.mask_first : q.mask_always;
         const float* row = q.logits + (int64_t)b * q.ldl;
@@ -751,6 +784,28 @@ extern "C" int wipa_greedy_step_embed(const float* logits, int64_t ldl, int B, i
     if (y_dtype == WIPA_F32) hipLaunchKernelGGL((greedy_tail_kernel<float>), dim3(B), dim3(GS_THREADS), 0, (hipStream_t)stream, q);
     else if (y_dtype == WIPA_BF16) hipLaunchKernelGGL((greedy_tail_kernel<__bf16>), dim3(B), dim3(GS_THREADS), 0, (hipStream_t)stream, q);
     else WIPA_REQUIRE(false, "wipa_greedy_step_embed: bad dtype %d", y_dtype);
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
+}
+
+extern "C" int wipa_greedy_step_embed_partials(const float* partials, int n_parts, int B, int32_t* tokens, int64_t ld_tok, int32_t* pos_dev,
+                                               int64_t* posd_dev, int32_t* done_counter, int n_init, int eot, float* sum_logprobs,
+                                               int32_t* not_done, const void* tok_emb, int emb_dtype, const float* emb_scale,
+                                               const float* pos_emb, int n_ctx, float* x, const float* ln_w, const float* ln_b, void* y,
+                                               int y_dtype, int D, float eps, wipa_stream_t stream) {
+    WIPA_REQUIRE(partials && n_parts > 0 && tokens && pos_dev && posd_dev && done_counter && sum_logprobs && not_done && tok_emb && pos_emb && x &&
+                     ln_w && ln_b && y && B > 0 && n_ctx > 0, "wipa_greedy_step_embed_partials: bad arguments");
+    const int rc = tail_params_check("wipa_greedy_step_embed_partials", nullptr, 0, 0, nullptr, nullptr, D, emb_dtype, emb_scale);
+    if (rc != WIPA_OK) return rc;
+    TailParams q = {};
+    q.part = partials; q.n_part = n_parts;
+    q.tokens = tokens; q.ld_tok = ld_tok; q.pos = pos_dev; q.posd = posd_dev; q.done_counter = done_counter;
+    q.n_init = n_init; q.eot = eot; q.n_ctx = n_ctx; q.sum_logprobs = sum_logprobs; q.not_done = not_done;
+    q.emb = tok_emb; q.emb_dtype = emb_dtype; q.emb_scale = emb_scale; q.pos_emb = pos_emb;
+    q.x = x; q.ln_w = ln_w; q.ln_b = ln_b; q.y = y; q.D = D; q.eps = eps;
+    if (y_dtype == WIPA_F32) hipLaunchKernelGGL((greedy_tail_kernel<float>), dim3(B), dim3(GS_THREADS), 0, (hipStream_t)stream, q);
+    else if (y_dtype == WIPA_BF16) hipLaunchKernelGGL((greedy_tail_kernel<__bf16>), dim3(B), dim3(GS_THREADS), 0, (hipStream_t)stream, q);
+    else WIPA_REQUIRE(false, "wipa_greedy_step_embed_partials: bad dtype %d", y_dtype);
     WIPA_LAUNCH_CHECK();
     return WIPA_OK;
 }

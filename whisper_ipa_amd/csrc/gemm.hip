@@ -54,6 +54,13 @@ struct GemmParams {
     const float* ln_b = nullptr;
     int64_t ln_ldx = 0;
     float ln_eps = 0.f;
+    // greedy partials (gemm_wide_persistent_kernel<.., GREEDY = true>: wipa_logits_greedy)
+    const float* g_mask_first = nullptr;
+    const float* g_mask_always = nullptr;
+    const int32_t* g_pos = nullptr;
+    int g_n_init = 0;
+    float* g_part = nullptr;  // [M rows][3: max | sum exp | arg-max][gridDim.x * 8 waves]
+    int g_store = 1;          // 0: the logits themselves are not written
 };
 
 template <typename OutT>
@@ -612,7 +619,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p) {
 // ([64][K + 8] bf16) and its eight waves then walk 16-column tiles of the weight matrix on their own (tile = wave index + k x
 // number of waves): a tile is 16 rows x K, all of its 16-byte loads in flight together, multiplied against the four 16-row
 // activation tiles read from LDS; no reduction between waves.  bf16 in, any epilogue of the skinny kernel.
-template <typename OutT, int KS>
+//
+// GREEDY (wipa_logits_greedy: the logits projection of a greedy decode step, plain f32 output): the wave also keeps, per row, the
+// running maximum / arg-max / sum of exponentials of the FILTERED logits (logit + suppress mask) over the columns it computes, and
+// writes ONE partial per (row, wave) at the end -- the step's last launch merges 2 048 partials per row instead of reading the
+// 13 MB of logits back, and with g_store = 0 the logits are not written at all (8 of this launch's 32 us were its 64-byte stores).
+// Ties resolve to the lowest column like the row-scanning kernels: columns ascend within a wave, merges compare (value, index).
+template <typename OutT, int KS, bool GREEDY = false>
 __global__ __launch_bounds__(512) void gemm_wide_persistent_kernel(GemmParams p) {
     typedef Mma<__bf16>::Frag Frag;
     constexpr int K = KS * 32, LROW = K + 8;
@@ -650,6 +663,10 @@ __global__ __launch_bounds__(512) void gemm_wide_persistent_kernel(GemmParams p)
     int64_t coff_dev = p.c_offset;
     if (p.c_offset_dev) coff_dev += *p.c_offset_dev;
     __syncthreads();
+    [[maybe_unused]] const float* gmask = nullptr;
+    [[maybe_unused]] float gm[4] = {-1.0e30f, -1.0e30f, -1.0e30f, -1.0e30f}, gs[4] = {0.f, 0.f, 0.f, 0.f};
+    [[maybe_unused]] int gi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+    if constexpr (GREEDY) gmask = (*p.g_pos + 1 == p.g_n_init) ? p.g_mask_first : p.g_mask_always;
     for (int tile = tile0; tile < n_tiles; tile += stride) {
         const int n0 = tile * 16;
         const bool more = tile + stride < n_tiles;
@@ -685,8 +702,55 @@ __global__ __launch_bounds__(512) void gemm_wide_persistent_kernel(GemmParams p)
             for (int ks = 0; ks < KH; ++ks) fb[ks] = *reinterpret_cast<const Frag*>(wpn + (KH + ks) * 64);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (GREEDY) {
+            // the lane holds rows 16 j + frow, columns n0 + 4 fq + 0..3
+            const int nb = n0 + 4 * fq;
+            float mk[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mk[e] = (nb + e < p.N) ? gmask[nb + e] : -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[j][e] + mk[e];
+                float best = gm[j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (v[e] > best) {  // strict: the first (lowest) column of a maximum stays
+                        best = v[e];
+                        gi[j] = nb + e;
+                    }
+                gs[j] = gs[j] * __expf(gm[j] - best) + ((__expf(v[0] - best) + __expf(v[1] - best)) + (__expf(v[2] - best) + __expf(v[3] - best)));
+                gm[j] = best;
+            }
+            if (!p.g_store) continue;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) epilogue4<OutT>(p, acc[j], epi_row(p, 16 * j + frow, coff_dev), cc, vec);
+    }
+    if constexpr (GREEDY) {
+        // the four lanes of a row (fq = 0..3) -> one partial per (row, wave); every lane pair computes the same sums
+        const int nw = gridDim.x * 8, wg = blockIdx.x * 8 + wave;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int off = 16; off <= 32; off <<= 1) {
+                const float om = __shfl_xor(gm[j], off, 64), os = __shfl_xor(gs[j], off, 64);
+                const int oi = __shfl_xor(gi[j], off, 64);
+                const float M = fmaxf(gm[j], om);
+                const float a = gs[j] * __expf(gm[j] - M), b = os * __expf(om - M);
+                gs[j] = (lane & off) ? b + a : a + b;  // the same operand order in both lanes of a pair
+                if (om > gm[j] || (om == gm[j] && oi < gi[j])) gi[j] = oi;
+                gm[j] = M;
+            }
+            const int row = 16 * j + frow;
+            if (fq == 0 && row < p.M) {
+                float* pr = p.g_part + (int64_t)row * 3 * nw + wg;
+                pr[0] = gm[j];
+                pr[nw] = gs[j];
+                reinterpret_cast<int*>(pr)[2 * nw] = gi[j];
+            }
+        }
     }
 }
 
@@ -1970,7 +2034,11 @@ int init_attrs() {
                                reinterpret_cast<const void*>(&gemm_wide_persistent_kernel<__bf16, 12>),
                                reinterpret_cast<const void*>(&gemm_wide_persistent_kernel<__bf16, 16>),
                                reinterpret_cast<const void*>(&gemm_wide_persistent_kernel<__bf16, 24>),
-                               reinterpret_cast<const void*>(&gemm_wide_persistent_kernel<__bf16, 32>)};
+                               reinterpret_cast<const void*>(&gemm_wide_persistent_kernel<__bf16, 32>),
+                               reinterpret_cast<const void*>(&gemm_wide_persistent_kernel<float, 12, true>),
+                               reinterpret_cast<const void*>(&gemm_wide_persistent_kernel<float, 16, true>),
+                               reinterpret_cast<const void*>(&gemm_wide_persistent_kernel<float, 24, true>),
+                               reinterpret_cast<const void*>(&gemm_wide_persistent_kernel<float, 32, true>)};
         for (const void* f : widek) {
             const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (1024 + 8) * 2);
             if (e != hipSuccess) err = e;
@@ -2237,4 +2305,48 @@ extern "C" int wipa_gemm(const wipa_gemm_desc* d, wipa_stream_t stream) {
         return d->out_dtype == WIPA_BF16 ? launch<__bf16, __bf16>(p, s) : launch<__bf16, float>(p, s);
     }
     return d->out_dtype == WIPA_BF16 ? launch<float, __bf16>(p, s) : launch<float, float>(p, s);
+}
+
+// ---------------------------------------------------------------------------------------
+// Logits projection of a greedy decode step with the arg-max / log-sum-exp partials of the filtered rows (round 4): see
+// gemm_wide_persistent_kernel<.., GREEDY>.  256 workgroups x 8 waves = WIPA_GREEDY_PARTS partials per row.
+extern "C" int wipa_logits_greedy_supported(int B, int V, int d, int dtype) {
+    return dtype == WIPA_BF16 && B >= 1 && B <= 64 && V >= 8192 && (d == 384 || d == 512 || d == 768 || d == 1024);
+}
+extern "C" size_t wipa_logits_greedy_partials_bytes(int B) { return (size_t)B * 3 * WIPA_GREEDY_PARTS * 4; }
+
+extern "C" int wipa_logits_greedy(const void* x, int64_t ldx, const void* w, int64_t ldw, float* logits, int64_t ldl, int B, int V, int d,
+                                  const float* mask_first, const float* mask_always, const int32_t* pos_dev, int n_init, float* partials,
+                                  size_t partials_bytes, wipa_stream_t stream) {
+    WIPA_REQUIRE(x && w && mask_first && mask_always && pos_dev && partials, "wipa_logits_greedy: null pointer");
+    WIPA_REQUIRE(wipa_logits_greedy_supported(B, V, d, WIPA_BF16), "wipa_logits_greedy: bf16, 1..64 rows, V >= 8192, d in {384, 512, 768, 1024} (B=%d V=%d d=%d)",
+                 B, V, d);
+    WIPA_REQUIRE(partials_bytes >= wipa_logits_greedy_partials_bytes(B), "wipa_logits_greedy: partials buffer too small");
+    WIPA_REQUIRE((ldx * 2) % 16 == 0 && (ldw * 2) % 16 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 &&
+                     (!logits || (((uintptr_t)logits % 16) == 0 && ldl % 4 == 0 && ldl >= V)),
+                 "wipa_logits_greedy: rows must be 16-byte aligned");
+    GemmParams p;
+    static float dummy_c[4];
+    p.A = (const char*)x; p.W = (const char*)w; p.C = (char*)(logits ? logits : dummy_c);
+    p.bias = nullptr; p.residual = nullptr; p.pos = nullptr; p.c_offset_dev = nullptr;
+    p.lda_b = ldx * 2; p.ldw_b = ldw * 2; p.ldc = logits ? ldl : 0; p.ldpos = 0;
+    p.M = B; p.N = V; p.K = d;
+    p.rg_in = B; p.rg_valid = B; p.rg_stride = 0; p.cg_in = V; p.cg_stride = 0; p.c_offset = 0;
+    p.zero_invalid = 0; p.bias_along_m = 0; p.act = 0; p.col_scale_n = 0; p.col_scale = 1.f;
+    p.tiles_m = 1; p.tiles_n = 1; p.k_slices = 1; p.slab_stride = 0;
+    p.vec_ok = 1; p.stage_ok = 0;
+    p.g_mask_first = mask_first; p.g_mask_always = mask_always; p.g_pos = pos_dev; p.g_n_init = n_init; p.g_part = partials;
+    p.g_store = logits ? 1 : 0;
+    const int rc = init_attrs();
+    if (rc != WIPA_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(WIPA_GREEDY_PARTS / 8), block(512);
+    switch (d) {
+        case 384: hipLaunchKernelGGL((gemm_wide_persistent_kernel<float, 12, true>), grid, block, (size_t)64 * (384 + 8) * 2, s, p); break;
+        case 512: hipLaunchKernelGGL((gemm_wide_persistent_kernel<float, 16, true>), grid, block, (size_t)64 * (512 + 8) * 2, s, p); break;
+        case 768: hipLaunchKernelGGL((gemm_wide_persistent_kernel<float, 24, true>), grid, block, (size_t)64 * (768 + 8) * 2, s, p); break;
+        default: hipLaunchKernelGGL((gemm_wide_persistent_kernel<float, 32, true>), grid, block, (size_t)64 * (1024 + 8) * 2, s, p); break;
+    }
+    WIPA_LAUNCH_CHECK();
+    return WIPA_OK;
 }

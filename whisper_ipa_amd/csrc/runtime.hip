@@ -305,7 +305,7 @@ namespace {
 
 constexpr int MAX_SLABS = 4;
 struct DecScratch {
-    size_t x, x2, ln, q, ao, h, slabs, posd, absorbed, total;
+    size_t x, x2, ln, q, ao, h, slabs, posd, absorbed, greedy_part, total;
 };
 // split-K factor of a decode-step residual GEMM: keep >= 3 fragment steps per wave (4 waves)
 inline int k_slices_for(int K, int dtype) {
@@ -331,6 +331,8 @@ DecScratch dec_scratch(const wipa_model_cfg* c, int B) {
     s.posd = o; o += 256;
     s.absorbed = o;  // Qp + split partials of the absorbed cross-attention (cfg.dec_cross_absorbed)
     if (c->dec_cross_absorbed) o += align256(wipa_cross_absorbed_scratch_bytes(B, (int)d, c->n_audio_ctx));
+    s.greedy_part = o;  // arg-max / log-sum-exp partials of the logits projection (wipa_logits_greedy)
+    if (wipa_logits_greedy_supported(B, c->n_vocab, (int)d, c->dtype)) o += align256(wipa_logits_greedy_partials_bytes(B));
     s.total = o;
     return s;
 }
@@ -392,6 +394,16 @@ bool absorbed_merge_out() {
 bool tail_fused() {
     const char* e = getenv("WIPA_DECODE_TAIL");
     return !(e && atoi(e) == 0);
+}
+// The logits projection with the greedy partials in its epilogue + a tail that merges them (round 4; WIPA_LOGITS_FUSED=0 restores
+// the plain GEMM + the row-scanning tail): bf16 models without fp8 decoder tables, <= 64 rows, tail-fused steps.  Measured on
+// whisper-small, 64 clips: the logits' 64-byte stores were 8 of the GEMM's 32 us, the tail's read-back of the 13 MB another ~10.
+// A step whose logits nobody reads (every step of a wipa_decoder_run call but the last) does not write them at all: t_lean_logits.
+thread_local bool t_lean_logits = false;
+bool logits_fused(const wipa_model_cfg* cfg, int B) {
+    const char* e = getenv("WIPA_LOGITS_FUSED");  // read per call like the other step variants: part of the graph key
+    const bool on = !(e && atoi(e) == 0);
+    return on && tail_fused() && cfg->dec_w_dtype == 0 && wipa_logits_greedy_supported(B, cfg->n_vocab, cfg->n_text_state, cfg->dtype);
 }
 int32_t* done_counter_of(char* st, const wipa_dec_layout& L) { return (int32_t*)(st + L.pos + 64); }  // zeroed with pos by wipa_decoder_begin
 
@@ -505,13 +517,13 @@ int enqueue_step(const wipa_model_cfg* cfg, const void* const* w, char* st, cons
                 // ... and the cross-attention OUT projection rides in the third launch: one slab per head, summed by the mlp LayerNorm
                 RT_CALL(wipa_decode_cross_absorbed_block_out(&c, wkT, (const char*)lw[10] + (size_t)d * d * e, (const float*)lw[11] + d,
                                                              lw[12], (const float*)lw[13], slabs, slab_stride, sc + S.absorbed,
-                                                             S.total - S.absorbed, stream));
+                                                             S.greedy_part - S.absorbed, stream));
                 pend = H;
                 std::swap(x, x_other);
                 cross_out_done = true;
             } else {
                 RT_CALL(wipa_decode_cross_absorbed_block(&c, wkT, (const char*)lw[10] + (size_t)d * d * e, (const float*)lw[11] + d,
-                                                         sc + S.absorbed, S.total - S.absorbed, stream));
+                                                         sc + S.absorbed, S.greedy_part - S.absorbed, stream));
                 pend = 0;
                 std::swap(x, x_other);
             }
@@ -527,7 +539,7 @@ int enqueue_step(const wipa_model_cfg* cfg, const void* const* w, char* st, cons
                 // scores and values from ONE pass over the encoder output: Wk absorbed into the query, Wv into the output
                 const void* wkT = w[WIPA_DEC_GLOBAL + WIPA_DEC_PER_LAYER * cfg->n_text_layer + WIPA_DEC_ABSORBED_PER_LAYER * l];
                 RT_CALL(wipa_cross_absorbed_attention(q, d, wkT, st + L.cross_kv, (const char*)lw[10] + (size_t)d * d * e,
-                                                      (const float*)lw[11] + d, ao, d, sc + S.absorbed, S.total - S.absorbed, B, H, d, Ta,
+                                                      (const float*)lw[11] + d, ao, d, sc + S.absorbed, S.greedy_part - S.absorbed, B, H, d, Ta,
                                                       QK_SCALE, cfg->dec_cross_splits, stream));
             } else {
                 RT_CALL(wipa_decode_cross_attn(q, ckv, ao, B, H, Ta, dt, stream));
@@ -540,6 +552,17 @@ int enqueue_step(const wipa_model_cfg* cfg, const void* const* w, char* st, cons
     }
     RT_CALL(ln_step(w[2], w[3]));
     float* logits = (float*)(st + L.logits);
+    if (logits_fused(cfg, B)) {
+        const void* const* lw0 = w + WIPA_DEC_GLOBAL;
+        float* part = (float*)(sc + S.greedy_part);
+        RT_CALL(wipa_logits_greedy(ln, d, w[0], d, t_lean_logits ? nullptr : logits, L.ld_logits, B, cfg->n_vocab, d, mask_first, mask_always, pos,
+                                   n_init, part, wipa_logits_greedy_partials_bytes(B), stream));
+        RT_CALL(wipa_greedy_step_embed_partials(part, WIPA_GREEDY_PARTS, B, tokens, L.ld_tok, pos, posd, done_counter_of(st, L), n_init, eot,
+                                                (float*)(st + L.sum_logprobs), (int32_t*)(st + L.not_done), w[0], emb_dtype(cfg), emb_scale(cfg, w),
+                                                (const float*)w[1], nctx, x_first, (const float*)lw0[0], (const float*)lw0[1], ln, dt, d, 1e-5f,
+                                                stream));
+        return WIPA_OK;
+    }
     RT_CALL(gemm(ln, d, w[0], d, logits, L.ld_logits, B, cfg->n_vocab, d, dt, WIPA_F32, nullptr, 0, nullptr, stream));
     if (tail) {
         // greedy update + embedding of the chosen token + first LayerNorm of the NEXT position + position advance: one launch
@@ -736,7 +759,7 @@ int enqueue_prefill(const wipa_model_cfg* cfg, const void* const* w, char* st, c
             for (int t = 0; t < P; ++t)
                 RT_CALL(wipa_cross_absorbed_attention((const char*)q + (size_t)t * d * e, (int64_t)P * d, wkT, st + L.cross_kv,
                                                       (const char*)lw[10] + (size_t)d * d * e, (const float*)lw[11] + d,
-                                                      (char*)ao + (size_t)t * d * e, (int64_t)P * d, sc + S.absorbed, S.total - S.absorbed, B,
+                                                      (char*)ao + (size_t)t * d * e, (int64_t)P * d, sc + S.absorbed, S.greedy_part - S.absorbed, B,
                                                       H, d, Ta, QK_SCALE, cfg->dec_cross_splits, stream));
         } else {
             RT_CALL(wipa_decode_cross_attn_multi(q, ckv, ao, B, H, Ta, P, dt, stream));
@@ -929,35 +952,57 @@ extern "C" int wipa_decoder_run(const wipa_model_cfg* cfg, const void* const* w,
     // them from the previous step's last launch.  Outside the graph: once per call, whatever wrote the token (the greedy
     // update, the prompt, a forced history)
     if (step_needs_head(cfg, B)) RT_CALL(enqueue_step_head(cfg, w, st, L, B, stream));
+    // every step of the call but the LAST is "lean" when the logits projection carries the greedy partials: its logits are not
+    // written (state.logits holds those of the last step of a call, which is what callers read)
+    const bool lean_ok = !use_fused_step(cfg, B) && logits_fused(cfg, B);
+    struct LeanScope {
+        explicit LeanScope(bool v) { t_lean_logits = v; }
+        ~LeanScope() { t_lean_logits = false; }
+    };
     if (!use_graph || !graphs_allowed()) {
-        for (int i = 0; i < n_steps; ++i)
+        for (int i = 0; i < n_steps; ++i) {
+            LeanScope lean(lean_ok && i + 1 < n_steps);
             RT_CALL(enqueue_decode_step(cfg, w, st, L, B, n_init, eot, mask_first, mask_always, stream));
+        }
         return WIPA_OK;
     }
     WIPA_REQUIRE(s != nullptr, "wipa_decoder_run: graph capture needs a non-default stream");
-    hipGraphExec_t exec = nullptr;
-    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * decode_mode(cfg, B) + 16 * cfg->dec_w_dtype + 64 * cfg->dec_cross_absorbed * (absorbed_block_fused() ? 2 : 1) + 256 * (int)tail_fused() + 512 * (int)absorbed_merge_out() + 1024 * cfg->dec_cross_splits, cfg->weights_generation, 0);
-    {
-        std::lock_guard<std::mutex> lk(g_graph_mu);
-        auto it = g_graphs.find(key);
-        if (it != g_graphs.end()) exec = it->second;
-    }
-    if (!exec) {
-        hipGraph_t graph = nullptr;
-        WIPA_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
-        const int rc = enqueue_decode_step(cfg, w, st, L, B, n_init, eot, mask_first, mask_always, stream);
-        const hipError_t ee = hipStreamEndCapture(s, &graph);
-        if (rc != WIPA_OK) {
-            if (graph) hipGraphDestroy(graph);
-            return rc;
+    const int variant = cfg->dtype * 2 + t_f32_split + 4 * decode_mode(cfg, B) + 16 * cfg->dec_w_dtype + 64 * cfg->dec_cross_absorbed * (absorbed_block_fused() ? 2 : 1) + 256 * (int)tail_fused() + 512 * (int)absorbed_merge_out() + 1024 * cfg->dec_cross_splits + 8192 * (int)lean_ok;
+    auto step_graph = [&](bool lean, hipGraphExec_t* out) -> int {  // kind 0: the full step, 2: the lean one
+        hipGraphExec_t exec = nullptr;
+        const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, variant, cfg->weights_generation,
+                           lean ? 2 : 0);
+        {
+            std::lock_guard<std::mutex> lk(g_graph_mu);
+            auto it = g_graphs.find(key);
+            if (it != g_graphs.end()) exec = it->second;
         }
-        WIPA_CHECK_HIP(ee);
-        WIPA_CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-        WIPA_CHECK_HIP(hipGraphDestroy(graph));
-        std::lock_guard<std::mutex> lk(g_graph_mu);
-        g_graphs[key] = exec;
-    }
-    for (int i = 0; i < n_steps; ++i) WIPA_CHECK_HIP(hipGraphLaunch(exec, s));
+        if (!exec) {
+            hipGraph_t graph = nullptr;
+            WIPA_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+            int rc;
+            {
+                LeanScope scope(lean);
+                rc = enqueue_decode_step(cfg, w, st, L, B, n_init, eot, mask_first, mask_always, stream);
+            }
+            const hipError_t ee = hipStreamEndCapture(s, &graph);
+            if (rc != WIPA_OK) {
+                if (graph) hipGraphDestroy(graph);
+                return rc;
+            }
+            WIPA_CHECK_HIP(ee);
+            WIPA_CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            WIPA_CHECK_HIP(hipGraphDestroy(graph));
+            std::lock_guard<std::mutex> lk(g_graph_mu);
+            g_graphs[key] = exec;
+        }
+        *out = exec;
+        return WIPA_OK;
+    };
+    hipGraphExec_t full = nullptr, lean = nullptr;
+    RT_CALL(step_graph(false, &full));
+    if (lean_ok && n_steps > 1) RT_CALL(step_graph(true, &lean));
+    for (int i = 0; i < n_steps; ++i) WIPA_CHECK_HIP(hipGraphLaunch((lean && i + 1 < n_steps) ? lean : full, s));
     return WIPA_OK;
 }
 
@@ -983,7 +1028,7 @@ extern "C" int wipa_decoder_prefill(const wipa_model_cfg* cfg, const void* const
     RT_CALL(init_before_capture(cfg));
     if (!use_graph || s == nullptr || !graphs_allowed()) return enqueue();
     hipGraphExec_t exec = nullptr;
-    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * decode_mode(cfg, B) + 16 * cfg->dec_w_dtype + 64 * cfg->dec_cross_absorbed * (absorbed_block_fused() ? 2 : 1) + 256 * (int)tail_fused() + 512 * (int)absorbed_merge_out() + 1024 * cfg->dec_cross_splits, cfg->weights_generation, 1);
+    const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * decode_mode(cfg, B) + 16 * cfg->dec_w_dtype + 64 * cfg->dec_cross_absorbed * (absorbed_block_fused() ? 2 : 1) + 256 * (int)tail_fused() + 512 * (int)absorbed_merge_out() + 1024 * cfg->dec_cross_splits + 8192 * (int)(!use_fused_step(cfg, B) && logits_fused(cfg, B)), cfg->weights_generation, 1);
     {
         std::lock_guard<std::mutex> lk(g_graph_mu);
         auto it = g_graphs.find(key);
