@@ -485,7 +485,8 @@ typedef struct wipa_dec_layout {
     int64_t pos;          /* int32 scalar: index of the last filled token */
     int64_t not_done;     /* int32 scalar, accumulated by greedy steps */
     int64_t sum_logprobs; /* f32 [B] */
-    int64_t logits;       /* f32 [B, ld_logits]: logits of the last step */
+    int64_t logits;       /* f32 [B, ld_logits]: logits of the last step of the last wipa_decoder_run / wipa_decoder_prefill call
+                           * (earlier steps of a call may not write them: wipa_logits_greedy) */
     int64_t ld_logits;
     int64_t cross_kv;     /* T [n_layer][B][2H][n_audio_ctx][64] */
     int64_t self_kv;      /* T [n_layer][3][B][n_text_ctx][d]  (slot 0 q staging, 1 K, 2 V) */
@@ -503,7 +504,9 @@ int wipa_decoder_begin(const wipa_model_cfg* cfg, void* state, size_t state_byte
                        int n_init, wipa_stream_t s);
 /* n_steps decoder steps (each: one token position through all layers + greedy update).
  * The prompt is consumed one position per step.  use_graph != 0 captures one step into a
- * hipGraph and replays it. */
+ * hipGraph and replays it.  state.logits holds the logits of the call's LAST step (where the logits projection carries the
+ * greedy partials -- wipa_logits_greedy -- the other steps do not write them; a caller that wants every step's logits runs
+ * one step per call, as decoding.forced_decode_logits does). */
 int wipa_decoder_run(const wipa_model_cfg* cfg, const void* const* weights, void* state, size_t state_bytes, int B, int n_init,
                      int eot, const float* mask_first, const float* mask_always, int n_steps, int use_graph,
                      wipa_stream_t s);
