@@ -838,7 +838,7 @@ int state_fits(const char* who, const wipa_dec_layout& L, size_t state_bytes) {
 // graph cache: one captured step per (state blob, weights, masks, shape)
 // The key carries cfg->weights_generation: the host address of a weight table can be reused by a NEW table after the old
 // one was freed, so the address alone does not identify the device pointers baked into a captured graph.
-typedef std::tuple<const void*, const void*, const void*, const void*, int, int, int, int, int, int> GraphKey;  // ..., generation, kind: 0 step, 1 prefill
+typedef std::tuple<const void*, const void*, const void*, const void*, int, int, int, int, int, int> GraphKey;  // ..., generation, kind: 0 step, 1 prefill, 2 lean step (no logit stores)
 std::mutex g_graph_mu;
 std::map<GraphKey, hipGraphExec_t> g_graphs;
 
