@@ -1113,10 +1113,17 @@ def main():
             i += g
             gi += 1
     else:
+        host_launch, host_collect = [], []  # host seconds inside pass_launch / pass_collect (diagnostic, logged to stderr)
         for i in range(args.steps):
             if len(inflight) == args.pipeline:
+                tc = time.perf_counter()
                 collected.append(pass_collect(inflight.pop(0)))
+                host_collect.append(time.perf_counter() - tc)
+            tl = time.perf_counter()
             inflight.append(pass_launch(model, audio_chunks, setup, (i % args.pipeline) * args.streams))
+            host_launch.append(time.perf_counter() - tl)
+        log("host ms inside pass_launch: " + " ".join(f"{1e3 * t:.1f}" for t in host_launch) + " | inside pass_collect: "
+            + " ".join(f"{1e3 * t:.1f}" for t in host_collect))
     while inflight:
         collected.append(pass_collect(inflight.pop(0)))
     tokens = collected[-1]
