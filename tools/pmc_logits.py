@@ -20,8 +20,26 @@ M, N, K = 64, 51865, 768
 A = torch.randn(M, K, device="cuda", generator=g).bfloat16()
 W = (torch.randn(N, K, device="cuda", generator=g) * 0.05).bfloat16()
 out = torch.zeros(M, 51872, device="cuda")
+GREEDY = os.environ.get("GREEDY", "0")  # 1: wipa_logits_greedy without logit stores (the lean step's launch); 2: with them
+if GREEDY != "0":
+    from whisper_ipa_amd import _lib
+    from whisper_ipa_amd.runtime import ptr, sptr, stream as lib_stream
+
+    L = _lib.lib()
+    mask = torch.zeros(51872, device="cuda")
+    pos = torch.tensor([5], dtype=torch.int32, device="cuda")
+    nb = L.wipa_logits_greedy_partials_bytes(M)
+    part = torch.empty(nb, dtype=torch.uint8, device="cuda")
+
+    def launch(w):
+        _lib.check(L.wipa_logits_greedy(ptr(A), K, ptr(w), K, ptr(out) if GREEDY == "2" else None, 51872, M, N, K, ptr(mask), ptr(mask), ptr(pos), 4,
+                                        ptr(part), nb, sptr(lib_stream())), "wipa_logits_greedy")
+else:
+    def launch(w):
+        ops.gemm(A, w, out, M=M, N=N, K=K, lda=K, ldw=K, ldc=51872)
+torch.cuda.synchronize()  # the operands were made on torch's stream; the launches go to the library stream
 for _ in range(10):
-    ops.gemm(A, W, out, M=M, N=N, K=K, lda=K, ldw=K, ldc=51872)
+    launch(W)
 torch.cuda.synchronize()
 if "ROCPROF_COUNTER_COLLECTION" not in os.environ:  # plain run: event timing over graph-replayed launches
     from whisper_ipa_amd.runtime import stream
@@ -31,11 +49,11 @@ if "ROCPROF_COUNTER_COLLECTION" not in os.environ:  # plain run: event timing ov
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.stream(s):
         for w in Ws:
-            ops.gemm(A, w, out, M=M, N=N, K=K, lda=K, ldw=K, ldc=51872)
+            launch(w)
     s.synchronize()
     with torch.cuda.graph(graph, stream=s):
         for i in range(40):
-            ops.gemm(A, Ws[i % 4], out, M=M, N=N, K=K, lda=K, ldw=K, ldc=51872)
+            launch(Ws[i % 4])
     with torch.cuda.stream(s):
         graph.replay()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -44,5 +62,6 @@ if "ROCPROF_COUNTER_COLLECTION" not in os.environ:  # plain run: event timing ov
         e1.record(s)
     e1.synchronize()
     us = e0.elapsed_time(e1) / 40 * 1e3
-    print(f"logits GEMM WIPA_SKINNY_WIDE_NT={os.environ.get('WIPA_SKINNY_WIDE_NT', '4')}: {us:.2f} us  {(N * K * 2 + M * 51872 * 4) / us / 1e6:.2f} TB/s")
+    bytes_alg = N * K * 2 + (M * 51872 * 4 if GREEDY != "1" else 0) + (M * 3 * 2048 * 4 if GREEDY != "0" else 0)
+    print(f"logits GEMM GREEDY={GREEDY}: {us:.2f} us  {bytes_alg / 1e6:.1f} MB algorithmic  {bytes_alg / us / 1e6:.2f} TB/s")
 print("done")
