@@ -534,6 +534,9 @@ def roofline_cross_absorbed(model, B: int, st, iters: int = 48):
             "algorithmic_bytes_per_launch": bytes_alg, "avg_launch_ms": round(ms, 5),
             "launch_order": f"{per_buf} consecutive launches (the layers of one decode step) per encoder output, {n_buf} encoder outputs (passes in flight) in turn",
             "frame_splits": S, "workgroups": S * B,
+            **({"note": f"this launch holds {S * B} of the 256 CUs BY DESIGN (Whisper.cross_splits = {S}: the setting for several passes in flight): `frac` is one "
+                        "launch alone against the whole chip's HBM peak; `two_launches_side_by_side` is the chip-level rate in the situation the setting "
+                        "exists for, `library_default_setting` the same kernel launched on all 256 CUs"} if S * B <= 128 else {}),
             **({"two_launches_side_by_side": {
                 "what": f"the launch holds {S * B} of the 256 CUs by design (half-chip launches for several passes in flight): the same launches on "
                         "two HIP streams at once, aggregate algorithmic bytes over the wall time",
