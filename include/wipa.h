@@ -576,11 +576,16 @@ int wipa_attention_bwd(const wipa_attn_desc* d, const float* out, const float* d
  * (no bias correction): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p = p (1 - lr wd) - lr m / (sqrt(v)+eps).
  * Tensors live in flat f32 buffers; a chunk table (<= 4096 elements per chunk, never crossing tensors)
  * drives the kernels: chunk_off/len/seg [n_chunks], seg_first_chunk [n_seg+1]; partial [n_chunks],
- * coef/norms [n_seg] are scratch/outputs. */
+ * coef/norms [n_seg] are scratch/outputs.
+ * seg_clip int32 [n_seg] or NULL: which tensors the clip reaches.  The reference's clip_grad_dict
+ * (scripts/train_whisper_ipa.py:287-303) recurses through dict values only; a list value (decoder.blocks) is neither a
+ * dict nor an array and is passed through (:299-300), so a caller reproducing it passes 0 for every decoder.blocks.*
+ * tensor (coefficient exactly 1, norm still reported) and 1 for token_embedding.weight, positional_embedding, ln.*.
+ * NULL clips every tensor. */
 int wipa_clip_adamw(float* params, float* grads, float* m, float* v, const int64_t* chunk_off, const int32_t* chunk_len,
                     const int32_t* chunk_seg, const int32_t* seg_first_chunk, int n_chunks, int n_seg, float* partial,
-                    float* coef, float* norms, double max_norm, double lr, double beta1, double beta2, double eps,
-                    double weight_decay, wipa_stream_t s);
+                    float* coef, float* norms, const int32_t* seg_clip, double max_norm, double lr, double beta1, double beta2,
+                    double eps, double weight_decay, wipa_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -19,7 +19,9 @@ mirrors openai/whisper), anchored on the reference's own call sites:
                              scripts/transcribe_single.py:54
 * teacher-forced logits .... scripts/train_whisper_ipa.py:228-232
 * masked CE loss ........... scripts/train_whisper_ipa.py:207-263
-* per-tensor clip + AdamW .. scripts/train_whisper_ipa.py:287-306,513
+* clip_grad_dict + AdamW ... scripts/train_whisper_ipa.py:287-306,513
+                             (the clip walks dicts only: decoder.blocks, a list,
+                             passes through unclipped -- clip_grad_dict below)
 * greedy decode ............ scripts/transcribe_single.py:49-56,
                              scripts/train_whisper_ipa.py:338-356
 * token framing / EOT pad .. scripts/ipa_data_loader.py:102-131
@@ -481,10 +483,83 @@ def loss_from_features(
 
 
 def clip_per_tensor(g: torch.Tensor, max_norm: float = 1.0) -> torch.Tensor:
-    """train_whisper_ipa.py:295-298 -- PER-TENSOR L2 clip."""
+    """train_whisper_ipa.py:295-298 -- the arithmetic applied to ONE gradient array: L2 norm, coefficient
+    max_norm / (norm + 1e-6) capped at 1, scale."""
     norm = torch.sqrt(torch.sum(g * g))
     coef = torch.clamp(max_norm / (norm + 1e-6), max=1.0)
     return g * coef
+
+
+def unflatten_params(flat: Dict[str, torch.Tensor]):
+    """Flat dotted keys -> the NESTED tree mlx hands to ``clip_grad_dict``: a dict per module, and a Python LIST wherever
+    every key at a level is an integer (``decoder.blocks`` is a list of blocks in mlx_whisper; the reference's own
+    ``flatten_params`` has the matching ``isinstance(params, list)`` branch, train_whisper_ipa.py:43-57, which is where the
+    ``decoder.blocks.{i}.`` checkpoint keys come from)."""
+    root: dict = {}
+    for key, val in flat.items():
+        node = root
+        parts = key.split(".")
+        for part in parts[:-1]:
+            node = node.setdefault(part, {})
+        node[parts[-1]] = val
+
+    def listify(node):
+        if not isinstance(node, dict):
+            return node
+        node = {k: listify(v) for k, v in node.items()}
+        if node and all(k.isdigit() for k in node):
+            return [node[str(i)] for i in range(len(node))]
+        return node
+
+    return listify(root)
+
+
+def flatten_params(params, prefix: str = "") -> Dict[str, torch.Tensor]:
+    """train_whisper_ipa.py:43-57: dict -> dotted keys, list -> index keys."""
+    flat: Dict[str, torch.Tensor] = {}
+    if isinstance(params, dict):
+        for k, v in params.items():
+            flat.update(flatten_params(v, f"{prefix}.{k}" if prefix else k))
+    elif isinstance(params, list):
+        for i, v in enumerate(params):
+            flat.update(flatten_params(v, f"{prefix}.{i}" if prefix else str(i)))
+    elif prefix:
+        flat[prefix] = params
+    return flat
+
+
+def clip_grad_dict(grad_dict: dict, max_norm: float = 1.0) -> dict:
+    """train_whisper_ipa.py:287-303 AS WRITTEN: walk the ``dict`` values only -- a dict recurses (:290-291), anything with a
+    ``.shape`` is clipped by its own L2 norm (:292-298), ANYTHING ELSE IS PASSED THROUGH (:299-300).  A ``list`` is neither a
+    dict nor an array, so the whole ``decoder.blocks`` list -- every tensor of every decoder block -- leaves this function
+    unclipped; what it clips is ``decoder.token_embedding.weight``, ``decoder.positional_embedding`` and
+    ``decoder.ln.{weight,bias}``.  [UPSTREAM-UNVERIFIED only in that ``blocks`` is a list in mlx_whisper's TextDecoder; the
+    reference's flatten_params and its checkpoint keys say so.]"""
+    clipped = {}
+    for key, value in grad_dict.items():
+        if isinstance(value, dict):
+            clipped[key] = clip_grad_dict(value, max_norm)
+        elif hasattr(value, "shape"):
+            clipped[key] = clip_per_tensor(value, max_norm)
+        else:
+            clipped[key] = value
+    return clipped
+
+
+def clip_gradients(grads: Dict[str, torch.Tensor], max_norm: float = 1.0, scope: str = "reference") -> Dict[str, torch.Tensor]:
+    """Flat-keyed front of the two readings of the clip.  ``scope="reference"``: the tree walk of ``clip_grad_dict`` above
+    (block tensors pass through).  ``scope="all"``: every tensor clipped by its own norm -- what the reference's docstring
+    says it does, and what this oracle restated until round 5."""
+    if scope == "reference":
+        return flatten_params(clip_grad_dict(unflatten_params(grads), max_norm))
+    if scope == "all":
+        return {k: clip_per_tensor(g, max_norm) for k, g in grads.items()}
+    raise ValueError(f"clip scope {scope!r}: 'reference' or 'all'")
+
+
+def clipped_by_reference(name: str) -> bool:
+    """True for the tensors ``clip_grad_dict`` reaches (no list on the path from the root)."""
+    return not any(part.isdigit() for part in name.split("."))
 
 
 def adamw_mlx(
@@ -502,24 +577,25 @@ def adamw_mlx(
 def train_step(
     W: Dict[str, torch.Tensor], dims: ModelDimensions, mel: torch.Tensor, tokens: torch.Tensor, eot: int,
     state: Dict[str, Tuple[torch.Tensor, torch.Tensor]], lr: float = 1e-5, max_grad_norm: float = 1.0,
+    clip_scope: str = "reference",
 ) -> Tuple[float, Dict[str, torch.Tensor]]:
     """One reference training step on the decoder parameters (encoder frozen,
-    train_whisper_ipa.py:181-204,266-311).  Updates ``W`` and ``state`` in
-    place; returns (loss, clipped grads)."""
+    train_whisper_ipa.py:181-204,266-311): loss + grads (:284), ``clip_grad_dict`` on the nested gradient tree (:287-303),
+    AdamW (:306).  Updates ``W`` and ``state`` in place; returns (loss, grads after the clip)."""
     names = [k for k in W if k.startswith("decoder.")]
     leaves = {k: W[k].detach().clone().requires_grad_(True) for k in names}
     Wl = dict(W)
     Wl.update(leaves)
     loss = compute_loss(Wl, dims, mel, tokens, eot)
-    grads = torch.autograd.grad(loss, [leaves[k] for k in names])
-    out = {}
-    for k, g in zip(names, grads):
-        g = clip_per_tensor(g, max_grad_norm)
+    grads = dict(zip(names, torch.autograd.grad(loss, [leaves[k] for k in names])))
+    out = clip_gradients(grads, max_grad_norm, clip_scope)
+    assert list(out) == names or set(out) == set(names)
+    for k in names:
+        g = out[k]
         m, v = state.get(k, (torch.zeros_like(g), torch.zeros_like(g)))
         p, m, v = adamw_mlx(W[k], g, m, v, lr=lr)
         W[k] = p.detach()
         state[k] = (m, v)
-        out[k] = g
     return float(loss.detach()), out
 
 

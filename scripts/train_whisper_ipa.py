@@ -261,7 +261,8 @@ def _init_distributed():
 def train(model_name: str, train_data_path: str, test_data_path: str, output_dir: str, num_steps: int = 1000,
           batch_size: int = 4, learning_rate: float = 1e-5, validate_every: int = 100, save_every: int = 500,
           test_run: bool = False, audio_root: str = "", seed: Optional[int] = None, fast_f32: bool = False,
-          allow_byte_fallback: bool = False, cache_encoder_features: bool = True, feature_cache_clips: Optional[int] = None):
+          allow_byte_fallback: bool = False, cache_encoder_features: bool = True, feature_cache_clips: Optional[int] = None,
+          clip_scope: str = "reference"):
     rank, world = _init_distributed()
     try:
         parallel.require_even_shards(batch_size, world)  # every rank gets clips; no mismatched collectives
@@ -276,7 +277,7 @@ def train(model_name: str, train_data_path: str, test_data_path: str, output_dir
                      "num_steps": num_steps, "batch_size": batch_size, "learning_rate": learning_rate,
                      "validate_every": validate_every, "save_every": save_every, "test_run": test_run,
                      "world_size": world, "f32_products": "split" if fast_f32 else "exact",
-                     "cache_encoder_features": bool(cache_encoder_features)}
+                     "cache_encoder_features": bool(cache_encoder_features), "clip_scope": clip_scope}
         save_training_config(output_dir, args_dict, get_hardware_info())
     logger = TrainingLogger(output_dir) if main else None
     print(f"Loading model: {model_name}")
@@ -285,7 +286,9 @@ def train(model_name: str, train_data_path: str, test_data_path: str, output_dir
     model.set_dtype(torch.float32)
     print(f"  ✓ Model loaded in {time.time() - t0:.1f}s")
     freeze_encoder(model)
-    trainer = DecoderTrainer(model, lr=learning_rate, f32_split=fast_f32)  # mlx AdamW defaults (reference :513)
+    # mlx AdamW defaults (reference :513); the clip reaches what the reference's clip_grad_dict reaches (:287-303: dicts only,
+    # the decoder.blocks list passes through) unless --clip-scope all
+    trainer = DecoderTrainer(model, lr=learning_rate, f32_split=fast_f32, clip_scope=clip_scope)
     n_mels = 128 if "large" in model_name else 80  # reference :517
     if model.dims.n_mels != n_mels:
         n_mels = model.dims.n_mels
@@ -422,6 +425,11 @@ def main():
     p.add_argument("--feature-cache-clips", type=int, default=None,
                    help="capacity of the frozen-encoder feature cache in clips (default: the training list, or what half of the "
                         "free HBM holds); clips beyond it are recomputed")
+    p.add_argument("--clip-scope", choices=["reference", "all"], default="reference",
+                   help="which gradients the per-tensor clip (max norm 1.0) reaches.  reference (default): exactly what the "
+                        "reference's clip_grad_dict reaches -- it recurses through dicts only, so the decoder.blocks LIST is "
+                        "passed through and only token_embedding.weight, positional_embedding and ln.* are clipped; "
+                        "all: every decoder tensor by its own norm")
     p.add_argument("--allow-byte-fallback", action="store_true",
                    help="run without the Whisper vocabulary (WIPA_TIKTOKEN unset): raw-byte text ids; synthetic weights only")
     a = p.parse_args()
@@ -429,7 +437,7 @@ def main():
           num_steps=a.steps, batch_size=a.batch_size, learning_rate=a.lr, validate_every=a.validate_every,
           save_every=a.save_every, test_run=a.test_run, audio_root=a.audio_root, fast_f32=a.fast_f32,
           allow_byte_fallback=a.allow_byte_fallback, cache_encoder_features=not a.no_cache_encoder_features,
-          feature_cache_clips=a.feature_cache_clips)
+          feature_cache_clips=a.feature_cache_clips, clip_scope=a.clip_scope)
 
 
 if __name__ == "__main__":

@@ -138,9 +138,12 @@ def test_layernorm_gelu_backward(M, chunked):
     assert _rel(u, torch.nn.functional.gelu(z.detach())) < 1e-6 and _rel(dz, z.grad) < 1e-5
 
 
-def test_clip_adamw_kernel_exact():
+@pytest.mark.parametrize("clip_scope", ["reference", "all"])
+def test_clip_adamw_kernel_exact(clip_scope):
     """the flat multi-tensor optimiser on given gradients: per-tensor clip coefficient, clipped g, m, v, p
-    equal the oracle's formulas (train_whisper_ipa.py:295-298; mlx AdamW without bias correction)."""
+    equal the oracle's formulas (train_whisper_ipa.py:295-298; mlx AdamW without bias correction).  ``reference``: the clip as
+    the reference wrote it -- clip_grad_dict walks dicts only (:290-300), every decoder.blocks.* tensor passes through with a
+    coefficient of exactly 1; ``all``: every tensor clipped by its own norm."""
     from whisper_ipa_amd.training import DecoderTrainer
     from whisper_ipa_amd.whisper import ModelDimensions, Whisper
 
@@ -148,9 +151,9 @@ def test_clip_adamw_kernel_exact():
     W = R.synthetic_weights(dims, seed=2)
     m = Whisper(ModelDimensions(**dims.__dict__), dtype=torch.float32)
     m.load_weights(W)
-    tr = DecoderTrainer(m, lr=3e-4)
+    tr = DecoderTrainer(m, lr=3e-4, clip_scope=clip_scope)
     g = torch.Generator().manual_seed(1)
-    ref_p, ref_m, ref_v, ref_g = {}, {}, {}, {}
+    ref_p, ref_m, ref_v, ref_g, raw = {}, {}, {}, {}, {}
     for i, n in enumerate(tr.names):
         scale = [1e-3, 0.3, 5.0][i % 3]  # some tensors below, some above the clip threshold
         gn = torch.randn(tr.shapes[n], generator=g) * scale / max(1.0, np.sqrt(np.prod(tr.shapes[n])) / 30)
@@ -159,12 +162,24 @@ def test_clip_adamw_kernel_exact():
         o = tr.offsets[n]
         tr.flat_m[o:o + gn.numel()].copy_(m0.reshape(-1).cuda())
         tr.flat_v[o:o + gn.numel()].copy_(v0.reshape(-1).cuda())
-        gc = R.clip_per_tensor(gn, 1.0)
-        ref_g[n] = gc
-        ref_p[n], ref_m[n], ref_v[n] = R.adamw_mlx(W[n], gc, m0, v0, lr=3e-4)
+        raw[n] = (gn, m0, v0)
+    ref_g = R.clip_gradients({n: raw[n][0] for n in tr.names}, 1.0, clip_scope)  # the tree walk of clip_grad_dict, or every tensor
+    for n in tr.names:
+        ref_p[n], ref_m[n], ref_v[n] = R.adamw_mlx(W[n], ref_g[n], raw[n][1], raw[n][2], lr=3e-4)
     tr.apply_update()
     torch.cuda.synchronize()
     clipped = 0
+    big_block = [n for n in tr.names if ".blocks." in n and float(raw[n][0].norm()) > 1.0]
+    big_other = [n for n in tr.names if ".blocks." not in n and float(raw[n][0].norm()) > 1.0]
+    assert big_block and big_other  # both kinds have a tensor above the threshold, so the scopes differ
+    for n in big_other:
+        assert float(tr.coef[tr.names.index(n)]) < 1.0
+    for n in big_block:
+        if clip_scope == "reference":  # passed through: coefficient exactly 1, gradient bit-identical, its norm still reported
+            assert float(tr.coef[tr.names.index(n)]) == 1.0 and torch.equal(tr.g(n).cpu(), raw[n][0])
+            assert abs(float(tr.norms[tr.names.index(n)]) - float(raw[n][0].norm())) < 1e-4 * float(raw[n][0].norm())
+        else:
+            assert float(tr.coef[tr.names.index(n)]) < 1.0
     for n in tr.names:
         o, k = tr.offsets[n], ref_g[n].numel()
         assert _rel(tr.g(n), ref_g[n]) < 2e-6, n
@@ -215,8 +230,13 @@ def test_loss_and_every_decoder_gradient_match_oracle(setup):
     assert set(tr.names) == set(ref)
 
 
-def test_train_step_matches_oracle_clip_and_adamw(setup, f32_mode):
-    """two full steps: clipped gradients and updated parameters equal the oracle's.  The parameter bound is the sensitive one:
+@pytest.mark.parametrize("clip_scope", ["reference", "all"])
+def test_train_step_matches_oracle_clip_and_adamw(setup, f32_mode, clip_scope):
+    """two full steps: gradients after the clip and updated parameters equal the oracle's, whose clip is the reference's
+    ``clip_grad_dict`` restated on the NESTED gradient tree (train_whisper_ipa.py:287-303: dict -> recurse, array -> clip,
+    anything else incl. the ``decoder.blocks`` list -> pass through); ``all`` = every tensor.  The setup has un-clipped norms
+    above 1 among the block tensors (mlp1.weight 6.9, attn.value.weight 5.7) and outside them (token_embedding.weight 2.6),
+    asserted below, so the two scopes give different updates.  The parameter bound is the sensitive one:
     without bias correction an element with |g| ~ eps moves by lr * m / (sqrt(v) + eps), which amplifies a 1e-5 relative
     gradient difference; 2e-4 holds with exact f32 GEMMs, 5e-4 with the three-term bf16 split."""
     p_tol = 2e-4 if f32_mode == "exact" else 5e-4
@@ -227,19 +247,25 @@ def test_train_step_matches_oracle_clip_and_adamw(setup, f32_mode):
     Wo = {k: v.clone() for k, v in W.items()}
     m = Whisper(ModelDimensions(**MICRO.__dict__), dtype=torch.float32)
     m.load_weights(W)
-    tr = DecoderTrainer(m, lr=1e-3, f32_split=(f32_mode == "split"))
+    tr = DecoderTrainer(m, lr=1e-3, f32_split=(f32_mode == "split"), clip_scope=clip_scope)
     state = {}
     for step in range(2):
         loss, _, _ = tr.loss_and_grads(xa.cuda(), tokens.cuda(), EOT)
         tr.apply_update()
-        ref_loss, g = _oracle_grads(Wo, xa, tokens)
+        ref_loss, g_raw = _oracle_grads(Wo, xa, tokens)
+        over = [k for k, gk in g_raw.items() if float(gk.norm()) > 1.0]
+        assert any(".blocks." in k for k in over) and any(".blocks." not in k for k in over), over
+        g = R.clip_gradients(g_raw, 1.0, clip_scope)
+        for k in over:  # what the scope means, on the oracle's side
+            if ".blocks." in k and clip_scope == "reference":
+                assert torch.equal(g[k], g_raw[k])
+            else:
+                assert abs(float(g[k].norm()) - 1.0) < 1e-4
         for k, gk in g.items():
-            gk = R.clip_per_tensor(gk, 1.0)
             mm, vv = state.get(k, (torch.zeros_like(gk), torch.zeros_like(gk)))
             Wo[k], mm, vv = R.adamw_mlx(Wo[k], gk, mm, vv, lr=1e-3)
             Wo[k] = Wo[k].detach()
             state[k] = (mm, vv)
-            g[k] = gk
         torch.cuda.synchronize()
         assert abs(float(loss) - ref_loss) < 1e-3, (step, float(loss), ref_loss)  # north_star: loss within 1e-3 in fp32
         for n in tr.names:

@@ -304,8 +304,21 @@ def _dp8_worker(rank, world, port, q):
             red.reduce(lo, hi)
         joined = red.wait()
         fail_seen = P.agree_on_step(11, failed=(rank == 5))  # one rank cannot build its batch: EVERY rank must see -1
+        # the clip runs AFTER the exchange, on the reduced gradients, over the tensors the trainer's seg_clip flags mark
+        # (training.clip_reaches: what wipa_clip_adamw is handed); the arithmetic below is the kernel's, per tensor
+        from whisper_ipa_amd.training import clip_reaches
+
+        after = {}
+        if rank in (0, 7):
+            for scope in ("reference", "all"):
+                out = flat.clone()
+                for k in names:
+                    gk = out[offs[k]: offs[k] + W[k].numel()]
+                    if clip_reaches(k, scope):
+                        gk *= torch.clamp(1.0 / (torch.sqrt(torch.sum(gk * gk)) + 1e-6), max=1.0)
+                after[scope] = out.numpy().tobytes()
         q.put((rank, per, mine, width, float(g_sum / g_cnt), int(g_cnt), joined, fail_seen, P.host_threads_per_rank(cores=64),
-               flat.numpy().tobytes() if rank in (0, 7) else None))
+               flat.numpy().tobytes() if rank in (0, 7) else None, after))
     finally:
         dist.destroy_process_group()
 
@@ -315,7 +328,9 @@ def test_dp_world8_global_batch_256_gradients_equal_single_process():
     step of a tiny decoder on a global batch of 256 = 8 x 32 (require_even_shards, shard_indices of one shared draw,
     agree_on_step, allreduce_loss_stats before the backward, SegmentReducer over the flat gradient buffer in the backward's
     segment order): loss and the reduced gradients on every rank equal the single-process loss / autograd over the 256 clips
-    (reference scripts/train_whisper_ipa.py:260-261,287-303,548)."""
+    (reference scripts/train_whisper_ipa.py:260-261,287-303,548).  Round 5: the clip that follows the exchange is checked
+    against the oracle's TREE-WALKING clip_grad_dict (:287-303 as written: the decoder.blocks list passes through) on the
+    single-process gradients, in both scopes; un-clipped norms above 1 exist among the block tensors and outside them."""
     import torch.multiprocessing as mp
 
     world = 8
@@ -350,6 +365,23 @@ def test_dp_world8_global_batch_256_gradients_equal_single_process():
         assert got.shape == want.shape
         assert float((got - want).abs().max() / want.abs().max()) < 2e-5  # same gradients as ONE process over 256 clips
     assert float(want.abs().max()) > 1e-4
+    g_single = {k: g.detach() for k, g in zip(names, grads)}
+    over = [k for k in names if float(g_single[k].norm()) > 1.0]
+    assert any(".blocks." in k for k in over) and any(".blocks." not in k for k in over), over
+    for scope in ("reference", "all"):
+        ref = R.clip_gradients(g_single, 1.0, scope)  # scope "reference": unflatten -> clip_grad_dict (dicts only) -> flatten
+        want_c = torch.cat([ref[k].reshape(-1) for k in names])
+        for r in (res[0], res[7]):
+            got = torch.from_numpy(np.frombuffer(r[10][scope], dtype=np.float32).copy())
+            assert float((got - want_c).abs().max() / want_c.abs().max()) < 2e-5, scope
+        for k in over:
+            n_after = float(ref[k].norm())
+            if ".blocks." in k and scope == "reference":
+                assert n_after > 1.0 and torch.equal(ref[k], g_single[k])  # the list is handed back untouched
+            else:
+                assert abs(n_after - 1.0) < 1e-4
+    blk = [k for k in over if ".blocks." in k][0]
+    assert not torch.equal(R.clip_gradients(g_single, 1.0, "reference")[blk], R.clip_gradients(g_single, 1.0, "all")[blk])
 
 
 class _FakeValModel:

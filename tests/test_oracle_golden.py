@@ -150,6 +150,42 @@ def test_clip_and_adamw_semantics():
     assert abs(p2.item() - exp) < 1e-6 and abs(m.item() - m_e) < 1e-7 and abs(v.item() - v_e) < 1e-9
 
 
+def test_clip_grad_dict_walks_dicts_only_as_the_reference_wrote_it():
+    """reference scripts/train_whisper_ipa.py:287-303: ``isinstance(value, dict)`` recurses, ``hasattr(value, 'shape')`` clips,
+    everything else -- a LIST included -- is returned as it came.  mlx_whisper keeps ``decoder.blocks`` in a list (the
+    reference's flatten_params :50-53 has the list branch, and its checkpoint keys are ``decoder.blocks.{i}.``), so no block
+    tensor is ever clipped; the four tensors outside the list are."""
+    big = lambda *shape: torch.full(shape, 3.0)
+    flat = {
+        "decoder.token_embedding.weight": big(4, 4), "decoder.positional_embedding": big(2, 4),
+        "decoder.blocks.0.attn.query.weight": big(4, 4), "decoder.blocks.0.mlp1.bias": big(8),
+        "decoder.blocks.1.attn.query.weight": big(4, 4), "decoder.blocks.1.mlp_ln.weight": big(4) * 0.01,
+        "decoder.ln.weight": big(4), "decoder.ln.bias": big(4) * 0.01,
+    }
+    tree = R.unflatten_params(flat)
+    assert isinstance(tree["decoder"]["blocks"], list) and len(tree["decoder"]["blocks"]) == 2
+    assert isinstance(tree["decoder"]["blocks"][0], dict) and isinstance(tree["decoder"]["ln"], dict)
+    assert list(R.flatten_params(tree)) == list(flat) and all(R.flatten_params(tree)[k] is flat[k] for k in flat)
+    walked = R.clip_grad_dict(tree, 1.0)
+    assert walked["decoder"]["blocks"] is tree["decoder"]["blocks"]  # :299-300: the very same list object comes back
+    out = R.flatten_params(walked)
+    for k, g in flat.items():
+        n0, n1 = float(g.norm()), float(out[k].norm())
+        if ".blocks." in k:
+            assert torch.equal(out[k], g) and not R.clipped_by_reference(k)
+        elif n0 > 1:
+            assert abs(n1 - n0 / (n0 + 1e-6)) < 1e-6 and R.clipped_by_reference(k)
+        else:
+            assert torch.equal(out[k], g)
+    assert R.clip_gradients(flat, 1.0, "reference").keys() == flat.keys()
+    every = R.clip_gradients(flat, 1.0, "all")
+    assert all(float(every[k].norm()) <= 1.0 for k in flat)
+    # the product marks the same tensors (what wipa_clip_adamw's seg_clip carries)
+    from whisper_ipa_amd.training import clip_reaches
+
+    assert all(clip_reaches(k, "reference") == R.clipped_by_reference(k) and clip_reaches(k, "all") for k in flat)
+
+
 def test_train_step_reduces_loss():
     torch.manual_seed(0)
     dims = R.ModelDimensions(80, 1500, 64, 1, 1, 51865, 448, 64, 1, 1)

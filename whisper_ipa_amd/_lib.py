@@ -182,7 +182,7 @@ SIGNATURES = {
     "wipa_attention_bwd": (c_int, [_P(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                    c_void_p]),
     "wipa_clip_adamw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                c_void_p, c_void_p, c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                c_void_p, c_void_p, c_void_p, c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                 C.c_double, c_void_p]),
 }
 

@@ -321,8 +321,11 @@ __global__ __launch_bounds__(256) void sumsq_chunks_kernel(const float* __restri
 // one workgroup per segment (tensor): thread i adds chunks i, i + 256, ... in order, then a fixed tree over the 256 partial
 // sums -> clip coefficient.  Deterministic; the token embedding alone has 9 724 chunks, which one thread per segment walked
 // in 0.7 ms.
+// seg_clip (may be null = every segment): 0 marks a tensor the reference's clip_grad_dict never reaches (it walks dicts only,
+// decoder.blocks is a list: train_whisper_ipa.py:290-300) -- its norm is still reported, its coefficient is exactly 1.
 __global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict__ partial, const int32_t* __restrict__ seg_first_chunk,
-                                                        int n_seg, float max_norm, float* __restrict__ coef, float* __restrict__ norms) {
+                                                        int n_seg, float max_norm, const int32_t* __restrict__ seg_clip,
+                                                        float* __restrict__ coef, float* __restrict__ norms) {
     __shared__ float s_red[4];
     const int s = blockIdx.x;
     float t = 0.f;
@@ -333,7 +336,8 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict_
     if (threadIdx.x == 0) {
         const float nrm = sqrtf((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
         norms[s] = nrm;
-        coef[s] = fminf(max_norm / (nrm + 1e-6f), 1.0f);  // train_whisper_ipa.py:295-297
+        const bool clip = !seg_clip || seg_clip[s] != 0;
+        coef[s] = clip ? fminf(max_norm / (nrm + 1e-6f), 1.0f) : 1.0f;  // train_whisper_ipa.py:295-297 / :299-300
     }
 }
 __global__ __launch_bounds__(256) void adamw_chunks_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
@@ -477,15 +481,15 @@ extern "C" int wipa_embed_bwd(const int32_t* tokens_flat, const float* dx, int B
 
 extern "C" int wipa_clip_adamw(float* params, float* grads, float* m, float* v, const int64_t* chunk_off,
                                const int32_t* chunk_len, const int32_t* chunk_seg, const int32_t* seg_first_chunk, int n_chunks,
-                               int n_seg, float* partial, float* coef, float* norms, double max_norm, double lr, double beta1,
-                               double beta2, double eps, double weight_decay, wipa_stream_t stream) {
+                               int n_seg, float* partial, float* coef, float* norms, const int32_t* seg_clip, double max_norm,
+                               double lr, double beta1, double beta2, double eps, double weight_decay, wipa_stream_t stream) {
     WIPA_REQUIRE(params && grads && m && v && chunk_off && chunk_len && chunk_seg && seg_first_chunk && partial && coef && norms,
                  "wipa_clip_adamw: null pointer");
     WIPA_REQUIRE(n_chunks > 0 && n_seg > 0, "wipa_clip_adamw: empty");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(sumsq_chunks_kernel, dim3(n_chunks), dim3(256), 0, s, grads, chunk_off, chunk_len, partial);
     hipLaunchKernelGGL(clip_coef_kernel, dim3(n_seg), dim3(256), 0, s, partial, seg_first_chunk, n_seg, (float)max_norm,
-                       coef, norms);
+                       seg_clip, coef, norms);
     // the scalar coefficients are formed in double like the Python reference forms them, then rounded once
     hipLaunchKernelGGL(adamw_chunks_kernel, dim3(n_chunks), dim3(256), 0, s, params, grads, m, v, chunk_off, chunk_len, chunk_seg,
                        coef, (float)lr, (float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,

@@ -127,10 +127,29 @@ class FrozenFeatureCache:
         return out
 
 
+CLIP_SCOPES = ("reference", "all")
+
+
+def clip_reaches(name: str, scope: str = "reference") -> bool:
+    """Does the reference's ``clip_grad_dict`` (train_whisper_ipa.py:287-303) reach the gradient ``name``?  It walks dict
+    values only: a tensor below a list (``decoder.blocks.{i}....``; mlx_whisper keeps the blocks in a Python list, and the
+    reference's flatten_params :50-53 has the matching list branch) is handed back as it came (:299-300)."""
+    if scope == "all":
+        return True
+    return not any(part.isdigit() for part in name.split("."))
+
+
 class DecoderTrainer:
     def __init__(self, model: Whisper, lr: float = 1e-5, max_grad_norm: float = 1.0, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 0.01, f32_split: Optional[bool] = None):
-        """``f32_split`` (default: the model's setting, i.e. off): split-bf16 products in the large GEMMs of the step."""
+                 weight_decay: float = 0.01, f32_split: Optional[bool] = None, clip_scope: str = "reference"):
+        """``f32_split`` (default: the model's setting, i.e. off): split-bf16 products in the large GEMMs of the step.
+        ``clip_scope``: which tensors the per-tensor clip reaches.  ``"reference"`` (default) is ``clip_grad_dict`` as the
+        reference wrote it (train_whisper_ipa.py:287-303): it recurses through dict values only, so the ``decoder.blocks``
+        LIST is passed through (:299-300) and only ``token_embedding.weight``, ``positional_embedding`` and ``ln.*`` are
+        clipped; ``"all"`` clips every decoder tensor by its own norm (what that function's docstring intends)."""
+        if clip_scope not in CLIP_SCOPES:
+            raise _lib.WipaError(f"DecoderTrainer: clip_scope {clip_scope!r}: one of {CLIP_SCOPES}")
+        self.clip_scope = clip_scope
         if model.dtype != torch.float32:
             raise _lib.WipaError("DecoderTrainer: the fine-tune step runs in float32 (reference: set_dtype(mx.float32))")
         self.model, self.lr, self.max_grad_norm = model, lr, max_grad_norm
@@ -181,6 +200,7 @@ class DecoderTrainer:
             self.partial = torch.empty(self.n_chunks, dtype=torch.float32, device=dev)
             self.coef = torch.empty(self.n_seg, dtype=torch.float32, device=dev)
             self.norms = torch.empty(self.n_seg, dtype=torch.float32, device=dev)
+            self.seg_clip = torch.tensor([int(clip_reaches(n, clip_scope)) for n in self.names], dtype=torch.int32, device=dev)
         model._invalidate()
         self.step_count = 0
         self._colsum_ws = None  # partial sums of the chunked bias-gradient reduction (wipa_colsum)
@@ -537,11 +557,12 @@ class DecoderTrainer:
         return float(ev[0].elapsed_time(ev[1]))
 
     def apply_update(self) -> None:
-        """per-tensor clip + AdamW on the flat buffers (flat_g becomes the clipped gradient)."""
+        """per-tensor clip (of the tensors ``clip_scope`` reaches) + AdamW on the flat buffers (flat_g becomes the gradient
+        after the clip; ``self.norms`` the un-clipped L2 norm of every tensor)."""
         with on_stream() as s:
             _lib.check(self.L.wipa_clip_adamw(ptr(self.flat_p), ptr(self.flat_g), ptr(self.flat_m), ptr(self.flat_v), ptr(self.ch_off),
                                               ptr(self.ch_len), ptr(self.ch_seg), ptr(self.seg_first), self.n_chunks, self.n_seg,
-                                              ptr(self.partial), ptr(self.coef), ptr(self.norms), self.max_grad_norm, self.lr,
+                                              ptr(self.partial), ptr(self.coef), ptr(self.norms), ptr(self.seg_clip), self.max_grad_norm, self.lr,
                                               self.b1, self.b2, self.eps, self.wd, sptr(s)), "wipa_clip_adamw")
         self.model._invalidate()  # fused inference tables are rebuilt lazily from the updated weights
         self.step_count += 1
