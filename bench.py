@@ -36,16 +36,17 @@ import os
 import sys
 import time
 
-# The pipelined passes live on several HIP streams; ROCm multiplexes streams onto GPU_MAX_HW_QUEUES hardware
-# queues (default 4).  Measured r01 with 4 passes in flight: 2 queues 119.9 ms, 4 -> 108.4, 8 -> 95.4 per pass.
-# Must be set before the HIP runtime starts (i.e. before torch touches the GPU).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+# The passes in flight live on several HIP streams; ROCm multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4)
+# and reads the variable when the HIP runtime starts.  Importing the package asks for 8 (runtime.request_hw_queues: measured
+# with 4 passes in flight, 4 queues 86.5-88 ms per pass, 8 queues 72 ms) -- nothing in this file sets it; `config.hw_queues`
+# in the line is what the package reports.  Imported before anything can touch the GPU.
+import whisper_ipa_amd  # noqa: E402,F401
 
 T_START = time.time()
 
@@ -91,20 +92,11 @@ def rank_threads() -> int:
     return host_threads_per_rank()
 
 
-PHASE = ""          # --phase enc | dec: DIAGNOSTIC runs of one half of the pass (never a benchmark number)
-_PHASE_FEATS = {}
 BATCH = 64          # clips per GPU
-N_PIPELINE = 4      # consecutive passes kept in flight on separate HIP streams (see --pipeline).  Measured r01 with
-                    # GPU_MAX_HW_QUEUES=8 (ms per 64-clip pass, repeatable to 0.5 %): 1 -> 133.2, 3 -> 98.8, 4 -> 94.7,
+N_PIPELINE = 4      # consecutive passes kept in flight (pipeline.transcribe_batches(passes_in_flight=...)).  Measured r01 with
+                    # 8 hardware queues (ms per 64-clip pass, repeatable to 0.5 %): 1 -> 133.2, 3 -> 98.8, 4 -> 94.7,
                     # 5 -> 123.5: the MFMA-bound encoder of later passes runs in the shadows of the launch/HBM-bound
                     # decode loops of earlier ones
-N_STREAMS = 1       # sub-batches of the 64 clips, one HIP stream each (measured r01: 1 -> 162 ms,
-                    # 2 -> 156 ms, 4 -> 200 ms, 8 -> 266 ms per pass: the per-step cost of the decode
-                    # loop is launch/latency bound and does not shrink with the sub-batch)
-DECODE_SPLIT = 1    # see --decode-split
-ENCODER_CUS = None  # see --encoder-cus
-ENC_STREAM_BASE = 2000
-ENC_STREAMS = int(os.environ.get("WIPA_BENCH_ENC_STREAMS", "1"))
 NEW_TOKENS = 64     # decode positions per clip (SURVEY.md section 8d primary setting)
 HBM_PEAK_GBS = 8000.0
 MFMA_BF16_PEAK_TFLOPS = 2500.0
@@ -216,87 +208,39 @@ def decode_setup(num_languages: int = 99):
     return list(tok.sot_sequence_including_notimestamps), always, first, tok.eot
 
 
-def one_pass(model, audio_chunks, setup):
-    """One pass over the batch.  The clips are split into sub-batches, each on its own HIP stream:
-    log-mel -> encoder -> cross-KV -> decode loop are enqueued asynchronously per sub-batch, so the
-    MFMA-bound encoder of one sub-batch overlaps the HBM/latency-bound decode loop of another.
-    Returns the token matrix of the whole batch (host), i.e. the pass ends when all ids are on the host."""
-    return pass_collect(pass_launch(model, audio_chunks, setup, 0))
+def bench_options():
+    """what the reference's inference callers pass (scripts/transcribe_single.py:49-52, scripts/evaluate_model.py:170-173)"""
+    from whisper_ipa_amd.decoding import DecodingOptions
+
+    return DecodingOptions(language="en", without_timestamps=True)
 
 
-def pass_launch(model, audio_chunks, setup, stream_base: int):
-    """enqueue one whole pass (asynchronously) on library streams stream_base, stream_base+1, ..."""
+def one_pass(model, audio) -> np.ndarray:
+    """ONE batch through the product path with nothing else in flight (pipeline.transcribe_batches(passes_in_flight=1): log-mel
+    -> encoder -> prompt + NEW_TOKENS greedy steps, the model's own cross_splits); returns the token matrix on the host."""
+    from whisper_ipa_amd.pipeline import transcribe_batches
+
+    (r,) = list(transcribe_batches(model, [audio], bench_options(), passes_in_flight=1, max_new_tokens=NEW_TOKENS, stop_on_eot=False))
+    return r.tokens
+
+
+def phase_enc_loop(model, audio, steps: int, pipeline: int) -> None:
+    """DIAGNOSTIC (--phase enc): log-mel + encoder alone on the pipeline's stream sets, `pipeline` of them in flight"""
     from whisper_ipa_amd import audio as A
-    from whisper_ipa_amd.decoding import greedy_launch
     from whisper_ipa_amd.runtime import use_stream
 
-    init, always, first, eot = setup
-    handles = []
-    for sid, a in enumerate(audio_chunks):
-        enc_sid = stream_base + sid if ENCODER_CUS is None else ENC_STREAM_BASE + (stream_base + sid) % ENC_STREAMS
-        with use_stream(enc_sid) as s_enc:
-            key = (stream_base, sid)
-            if PHASE == "dec" and key in _PHASE_FEATS:  # DIAGNOSTIC (--phase dec): the decode loops alone, on the features of the warm-up pass
-                handles.append(greedy_launch(model, _PHASE_FEATS[key], init, always, first, eot, max_new_tokens=NEW_TOKENS))
-                continue
-            mel = A.log_mel_padded(a, model.dims.n_mels, model.dtype)
-            feats = model.encode_padded(mel, a.shape[0])
-            if PHASE == "enc" and key in _PHASE_FEATS:  # DIAGNOSTIC (--phase enc): log-mel + encoder alone
-                ev = torch.cuda.Event()
-                ev.record(s_enc)
-                handles.append(ev)
-                continue
-            if PHASE:
-                _PHASE_FEATS[key] = feats
-            if DECODE_SPLIT <= 1 and ENCODER_CUS is None:
-                handles.append(greedy_launch(model, feats, init, always, first, eot, max_new_tokens=NEW_TOKENS))
-                continue
-            done = torch.cuda.Event()
-            done.record(s_enc)
-        if DECODE_SPLIT <= 1:
-            # --encoder-cus: log-mel + encoder on a CU-limited stream, the decode loop on the pass's unrestricted stream
-            with use_stream(stream_base + sid) as s_dec:
-                s_dec.wait_event(done)
-                feats.record_stream(s_dec)
-                handles.append(greedy_launch(model, feats, init, always, first, eot, max_new_tokens=NEW_TOKENS))
-            continue
-        # EXPERIMENT (--decode-split): the decode loop of the batch as DECODE_SPLIT independent row groups on their own streams,
-        # so one group's latency-bound small kernels run beside the other's chip-filling cross-attention
-        n = a.shape[0]
-        per = (n + DECODE_SPLIT - 1) // DECODE_SPLIT
-        for g in range(DECODE_SPLIT):
-            with use_stream(1000 + (stream_base + sid) * DECODE_SPLIT + g) as s_dec:
-                s_dec.wait_event(done)
-                feats.record_stream(s_dec)
-                handles.append(greedy_launch(model, feats[g * per:(g + 1) * per], init, always, first, eot, max_new_tokens=NEW_TOKENS))
-    return handles
-
-
-def group_launch(model, audio, setup, stream_id: int, n_batches: int):
-    """enqueue n_batches passes as ONE decode group: log-mel + encoder per 64-clip batch, then one greedy loop over all
-    n_batches * B clips (the decode-step projections stream the decoder weights once for the whole group)."""
-    from whisper_ipa_amd import audio as A
-    from whisper_ipa_amd.decoding import greedy_launch
-    from whisper_ipa_amd.runtime import use_stream
-
-    init, always, first, eot = setup
-    with use_stream(stream_id):
-        feats = []
-        for _ in range(n_batches):
-            mel = A.log_mel_padded(audio, model.dims.n_mels, model.dtype)
-            feats.append(model.encode_padded(mel, audio.shape[0]))
-        allf = feats[0] if n_batches == 1 else torch.cat(feats, dim=0)
-        return [greedy_launch(model, allf, init, always, first, eot, max_new_tokens=NEW_TOKENS)]
-
-
-def pass_collect(handles):
-    from whisper_ipa_amd.decoding import greedy_collect
-
-    if handles and isinstance(handles[0], torch.cuda.Event):  # --phase enc
-        for h in handles:
-            h.synchronize()
-        return np.zeros((1, 1), np.int64)
-    return np.concatenate([greedy_collect(h).tokens for h in handles], axis=0)
+    pending = {}
+    for i in range(steps):
+        slot = i % pipeline
+        if slot in pending:
+            pending.pop(slot).synchronize()
+        with use_stream(slot) as s:
+            model.encode_padded(A.log_mel_padded(audio, model.dims.n_mels, model.dtype), audio.shape[0])
+            ev = torch.cuda.Event()
+            ev.record(s)
+            pending[slot] = ev
+    for ev in pending.values():
+        ev.synchronize()
 
 
 def roofline_cross_attn(model, B: int, iters: int = 48):
@@ -454,7 +398,7 @@ def roofline_cross_absorbed(model, B: int, st, iters: int = 48):
     pk = model.packed(absorbed=True)
     # launch order of the real decode loop: the n_layer launches of a step read the SAME encoder output (the first finds it cold,
     # the others largely in the 256 MB Infinity Cache), then another in-flight pass's step runs on its own encoder output
-    n_buf, per_buf = N_PIPELINE, d.n_text_layer
+    n_buf, per_buf = N_PIPELINE, d.n_text_layer  # four encoder outputs in turn, whatever --pipeline says (comparable across runs)
     with on_stream() as s:
         xas = [torch.randn(B, Ta, dd, device=model.device).to(torch.bfloat16) for _ in range(n_buf)]
         q = (torch.randn(B, dd, device=model.device) * 0.3).to(torch.bfloat16)
@@ -1004,8 +948,145 @@ def measure_train(args, rank, world, dist, steps, warmup):
     return None
 
 
+def build_model(name: str, dtype: str = "bf16", weights: str = "bf16", activations: str = "bf16", cross_attention: str = "auto",
+                f32: str = "exact"):
+    """random-init whisper-<name> on the GPU (seed 0; no checkpoint exists offline), optionally with fp8 e4m3 weights / activations"""
+    from whisper_ipa_amd.whisper import Whisper
+
+    if activations == "fp8" and weights != "fp8":
+        sys.exit("bench.py: --activations fp8 needs --weights fp8")
+    dims, W = synthetic_weights_small(0, name)
+    log(f"whisper-{name} weights generated")
+    model = Whisper(dims, dtype=torch.bfloat16 if dtype == "bf16" else torch.float32, f32_split=(f32 == "split"),
+                    cross_attention=cross_attention)
+    model.load_weights(W)
+    del W
+    if weights == "fp8":
+        model.quantize_weights("fp8_e4m3", activations=activations)
+        log(f"weights quantised to fp8 e4m3 (encoder activations: {activations})")
+    return model
+
+
+def run_phase(args, model, audio_dev, opts, bench_splits: int, rank: int, dist) -> None:
+    """DIAGNOSTIC (--phase enc | dec): one half of the pass alone with the same passes in flight -- never a benchmark number"""
+    from whisper_ipa_amd.pipeline import TranscribePipeline
+
+    P = args.pipeline
+    if args.phase == "enc":
+        phase_enc_loop(model, audio_dev, P, P)
+        torch.cuda.synchronize()
+        timed_barrier(dist)
+        t0 = time.perf_counter()
+        phase_enc_loop(model, audio_dev, args.steps, P)
+    else:
+        feats = [gpu_features(model, audio_dev) for _ in range(P)]  # one stored encoder output per pass in flight
+        torch.cuda.synchronize()
+        with TranscribePipeline(model, opts, P, max_new_tokens=NEW_TOKENS, stop_on_eot=False, cross_splits=bench_splits) as pipe:
+            for i in range(P):
+                pipe.submit(feats[i])
+            for _ in pipe.drain():
+                pass
+            torch.cuda.synchronize()
+            timed_barrier(dist)
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                pipe.submit(feats[i % P])
+            for _ in pipe.drain():
+                pass
+    timed_barrier(dist)
+    elapsed = max_over_ranks(dist, time.perf_counter() - t0)
+    if rank == 0:
+        print(json.dumps({"diagnostic_phase": args.phase, "ms_per_pass": round(1000.0 * elapsed / args.steps, 2), "passes_in_flight": P,
+                          "cross_frame_splits": bench_splits or 4, "note": "one half of the pass only: NOT a benchmark number"}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def evaluate_style(model, audio_dev, args, world: int, value: float):
+    """The headline workload the way the reference's batch caller consumes it (scripts/evaluate_model.py:127-232, here
+    scripts/evaluate_model.py -> pipeline.transcribe_batches): DecodingOptions(language="en", without_timestamps=True,
+    sample_len=NEW_TOKENS), EARLY STOP ON (the decode steps go out in chunks of 8 with an EOT probe behind each; the random-init
+    model never ends a row, so the work equals the timed region's), every row turned into text on the host, results consumed
+    in order.  Audio resident on the GPU, as in the timed region."""
+    from whisper_ipa_amd.decoding import DecodingOptions
+    from whisper_ipa_amd.pipeline import transcribe_batches
+
+    B, P = audio_dev.shape[0], args.pipeline
+    opts = DecodingOptions(language="en", without_timestamps=True, sample_len=NEW_TOKENS)
+    kw = dict(passes_in_flight=P, cross_splits=args.cross_splits)
+    for _ in transcribe_batches(model, [audio_dev] * P, opts, **kw):  # the chunked calls replay the graphs captured above
+        pass
+    torch.cuda.synchronize()
+    n = max(args.steps, 2 * P)
+    rows = steps = 0
+    t0 = time.perf_counter()
+    for r in transcribe_batches(model, (audio_dev for _ in range(n)), opts, **kw):
+        rows += len(r.texts)
+        steps += r.n_steps
+    dt = time.perf_counter() - t0
+    v = world * B * 30.0 * n / dt
+    return {"what": "scripts/evaluate_model.py's loop on resident audio: transcribe_batches(model, batches, DecodingOptions(language='en', "
+                    f"without_timestamps=True, sample_len={NEW_TOKENS}), passes_in_flight={P}), early stop armed (EOT probes every 8 steps), "
+                    "ids -> text on the host for every row",
+            "value": round(v, 1), "unit": "audio-s/s", "ms_per_batch": round(1e3 * dt / n, 2), "batches": n, "rows_transcribed": rows,
+            "decode_steps_per_batch": steps // n, "frac_of_value": round(v / value, 4)}
+
+
+def other_configs(args):
+    """BASELINE.json configs[3] and configs[4] through the same product path, next to the headline (outside its timed region):
+    whisper-medium bf16, 256 clips per batch, and whisper-large-v3 with fp8 e4m3 weights + fp8 x fp8 encoder GEMMs, 128 clips per
+    batch; two batches in flight each, NEW_TOKENS = 64 positions, fixed length.  Each entry carries its own rooflines."""
+    import gc
+
+    from whisper_ipa_amd.pipeline import TranscribePipeline
+
+    res = {}
+    for key, name, B, weights, acts in (("configs[3]", "medium", 256, "bf16", "bf16"), ("configs[4]", "large-v3", 128, "fp8", "fp8")):
+        t_cfg = time.perf_counter()
+        model = build_model(name, "bf16", weights, acts)
+        audio = torch.from_numpy(synthetic_audio(0, B)).cuda()
+        P, steps = 2, 4
+        with TranscribePipeline(model, bench_options(), P, max_new_tokens=NEW_TOKENS, stop_on_eot=False) as pipe:
+            for _ in range(P):
+                pipe.submit(audio)
+            warm = [r.tokens for r in pipe.drain()]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            got = []
+            for _ in range(steps):
+                got += [r.tokens for r in pipe.submit(audio)]
+            got += [r.tokens for r in pipe.drain()]
+            dt = time.perf_counter() - t0
+            splits = model.cross_splits
+        absorbed = bench_absorbed(model, B)
+        model.cross_splits = splits if absorbed else 0
+        one_pass(model, audio)  # stream 0's state in the timed setting for the step roofline
+        entry = {
+            "metric": f"audio-seconds/sec transcribed (whisper-{name}, 30s clips)", "value": round(B * 30.0 * steps / dt, 1), "unit": "audio-s/s",
+            "ms_per_step": round(1e3 * dt / steps, 2), "steps": steps, "n_gpus": 1, "dtype": "bf16",
+            "config": {"workload": f"whisper-{name} bf16{' (fp8 e4m3 weights, fp8 x fp8 encoder GEMMs)' if weights == 'fp8' else ''} batched inference, "
+                                   f"batch={B}x30s synthetic clips, log-mel + encoder{'' if absorbed else ' + cross-K/V projection'} + {NEW_TOKENS} greedy "
+                                   f"KV-cached decode steps; {P} such passes in flight",
+                       "weights": model.weights_format, "encoder_activations": model.activations_format,
+                       "cross_attention": "absorbed" if absorbed else "cached", "clips_per_gpu": B, "passes_in_flight": P,
+                       "cross_frame_splits": (splits or 4) if absorbed else None},
+            "passes_identical": bool(all((t == warm[0]).all() for t in got + warm)),
+            "roofline": roofline_cross_attn(model, B, iters=24),
+            "decode_step": decode_step_roofline(model, B, n_steps=16),
+        }
+        if B <= 128:
+            entry["roofline_mfma"] = roofline_mfma(model, audio)
+        res[key] = entry
+        del model, audio, pipe
+        gc.collect()
+        torch.cuda.empty_cache()
+        log(f"other_configs {key}: {entry['ms_per_step']} ms per {B}-clip pass ({time.perf_counter() - t_cfg:.1f} s incl. weights)")
+    return res
+
+
 def main():
-    global DECODE_SPLIT, ENCODER_CUS, NEW_TOKENS, PHASE
+    global NEW_TOKENS
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
@@ -1013,20 +1094,15 @@ def main():
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="infer: the headline metric (BASELINE.json); train: the decoder fine-tune step (configs[2] share)")
     ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--streams", type=int, default=N_STREAMS, help="clip sub-batches run on this many HIP streams")
-    ap.add_argument("--pipeline", type=int, default=N_PIPELINE, help="consecutive passes kept in flight on separate HIP streams")
+    ap.add_argument("--pipeline", type=int, default=N_PIPELINE,
+                    help="consecutive passes kept in flight: whisper_ipa_amd.pipeline.transcribe_batches(passes_in_flight=...)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-finetune", action="store_true", help="skip the short fine-tune step measurement appended to the default line")
-    ap.add_argument("--decode-split", type=int, default=1,
-                    help="EXPERIMENT: decode the batch as this many independent row groups on separate HIP streams")
-    ap.add_argument("--encoder-cus", type=int, default=None,
-                    help="log-mel + encoder of every pass on a HIP stream limited to this many CUs (multiple of 8), the decode loop "
-                         "on an unrestricted one: the decode loops of the other passes in flight keep the remaining CUs")
-    ap.add_argument("--decoder-cus", type=int, default=None, help="EXPERIMENT: limit the decode streams to this many CUs")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the one-pass measurements of BASELINE.json configs[3] (whisper-medium, 256 clips) and configs[4] "
+                         "(whisper-large-v3 fp8, 128 clips) appended to the default line")
     ap.add_argument("--new-tokens", type=int, default=NEW_TOKENS,
                     help="decode positions per clip: 64 is the benchmark setting (SURVEY.md 8d), 224 the reference's cap (secondary)")
-    ap.add_argument("--decode-group", type=int, default=1,
-                    help="EXPERIMENT: decode this many consecutive 64-clip batches together (encoder still per batch)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"],
                     help="sizing runs only: the benchmark metric is quoted in bf16 (f32 is what the reference's scripts set)")
     ap.add_argument("--model", default="small", choices=["tiny", "base", "small", "medium", "large-v3"],
@@ -1038,16 +1114,16 @@ def main():
                     help="decode-step cross-attention: the encoder output with absorbed key / value projections (what auto picks for "
                          "bf16 models of <= 16 heads) or mlx_whisper's projected K / V caches (Whisper(cross_attention=...))")
     ap.add_argument("--cross-splits", type=int, default=None, choices=[0, 1, 2, 3, 4],
-                    help="absorbed cross-attention: frame splits per clip of the decode step's streaming launch "
-                         "(Whisper(cross_splits=...)).  Default: 2 (half-chip launches: the library's setting for several passes in "
-                         "flight) when --pipeline >= 2, else 0 = the library default 4 (shortest lone step)")
+                    help="absorbed cross-attention: frame splits per clip of the decode step's streaming launch.  Default: what "
+                         "pipeline.transcribe_batches sets -- 2 (half-chip launches) with >= 2 passes in flight, else the "
+                         "library default 4 (shortest lone step)")
     ap.add_argument("--activations", default="bf16", choices=["bf16", "fp8"],
                     help="with --weights fp8: fp8 also runs the encoder's q|k, value, mlp1, mlp2 projections fp8 x fp8 on the "
                          "block-scaled fp8 MFMA (LayerNorm / GELU outputs quantised per row) -- configs[4] '(CDNA4 fp8 MFMA)'")
     ap.add_argument("--f32", default="exact", choices=["exact", "split"],
                     help="float32 runs: exact f32 MFMA products (default, as the reference computes) or the split-bf16 opt-in")
     ap.add_argument("--phase", default="", choices=["", "enc", "dec"],
-                    help="DIAGNOSTIC: time only log-mel + encoder (enc) or only the decode loops on the warm-up pass's features (dec) with "
+                    help="DIAGNOSTIC: time only log-mel + encoder (enc) or only the decode loops on stored features (dec) with "
                          "the same passes in flight; prints ms per pass and exits -- not a benchmark line")
     ap.add_argument("--train-batch", type=int, default=32)
     ap.add_argument("--train-tokens", type=int, default=64)
@@ -1055,94 +1131,58 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
-    DECODE_SPLIT, ENCODER_CUS, NEW_TOKENS, PHASE = args.decode_split, args.encoder_cus, args.new_tokens, args.phase
+    NEW_TOKENS = args.new_tokens
     torch.set_num_threads(rank_threads())  # cores / LOCAL_WORLD_SIZE: eight ranks must not ask for 8 x 16 host threads
     if args.mode == "train":
         return run_train(args)
     rank, world, dist, device_index = init_ranks(args)
 
-    from whisper_ipa_amd.whisper import Whisper
-    from whisper_ipa_amd.runtime import limit_stream_cus
-    for sid in range(args.pipeline * args.streams):
-        if args.encoder_cus:  # 0: the split into an encoder and a decode stream alone, no CU limit
-            limit_stream_cus(ENC_STREAM_BASE + sid, args.encoder_cus)
-        if args.decoder_cus is not None:
-            limit_stream_cus(sid, args.decoder_cus)
+    from whisper_ipa_amd.pipeline import PIPELINE_CROSS_SPLITS, TranscribePipeline, transcribe_batches
+    from whisper_ipa_amd.runtime import hw_queues
 
     B = args.batch
-    log(f"start: rank {rank}/{world}, host cores {host_cores()}, torch threads of this rank {torch.get_num_threads()}")
-    dims, W = synthetic_weights_small(0, args.model)
-    log("weights generated")
-    model = Whisper(dims, dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32, f32_split=(args.f32 == "split"),
-                    cross_attention=args.cross_attention)
-    if args.cross_splits is None:
-        args.cross_splits = 2 if args.pipeline >= 2 else 0
-    model.cross_splits = args.cross_splits
-    model.load_weights(W)
-    del W
-    if args.activations == "fp8" and args.weights != "fp8":
-        sys.exit("bench.py: --activations fp8 needs --weights fp8")
-    if args.weights == "fp8":
-        model.quantize_weights("fp8_e4m3", activations=args.activations)
-        log(f"weights quantised to fp8 e4m3 (encoder activations: {args.activations})")
+    log(f"start: rank {rank}/{world}, host cores {host_cores()}, torch threads of this rank {torch.get_num_threads()}, "
+        f"hardware queues {hw_queues()}")
+    model = build_model(args.model, args.dtype, args.weights, args.activations, args.cross_attention, args.f32)
+    # the streaming-launch setting of the timed region: the pipeline's own rule unless --cross-splits overrides it
+    bench_splits = args.cross_splits if args.cross_splits is not None else (PIPELINE_CROSS_SPLITS if args.pipeline >= 2 else 0)
     audio_dev = torch.from_numpy(synthetic_audio(rank * B, B)).cuda()
-    audio_chunks = [c.contiguous() for c in audio_dev.chunk(args.streams)]
-    setup = decode_setup()
-    bench_packed(model, audio_chunks[0].shape[0])
+    setup = decode_setup(model.num_languages)
+    opts = bench_options()
+    bench_packed(model, B)
     torch.cuda.synchronize()
     log("model + audio resident on the GPU")
 
-    for i in range(args.warmup):
-        for pset in range(args.pipeline):  # warm every stream set (workspaces, KV caches, captured graphs)
-            if args.decode_group > 1:
-                pass_collect(group_launch(model, audio_chunks[0], setup, pset, args.decode_group))
-            else:
-                pass_collect(pass_launch(model, audio_chunks, setup, pset * args.streams))
-        torch.cuda.synchronize()
-        log(f"warmup pass {i} done")
-    timed_barrier(dist)
-    t0 = time.perf_counter()
-    # --pipeline P > 1: pass i runs on stream set (i % P) and is only collected when its stream set is needed
-    # again, so the encoder of pass i+1 can overlap the decode loop of pass i (each pass still does all its work
-    # inside the timed region; every pass owns separate workspaces / KV caches)
-    inflight, collected = [], []  # collected: every pass's ids (host arrays), compared after the timed region
-    if args.decode_group > 1:
-        i, gi = 0, 0
-        while i < args.steps:
-            g = min(args.decode_group, args.steps - i)
-            if len(inflight) == args.pipeline:
-                collected.append(pass_collect(inflight.pop(0)))
-            inflight.append(group_launch(model, audio_chunks[0], setup, gi % args.pipeline, g))
-            i += g
-            gi += 1
-    else:
-        host_launch, host_collect = [], []  # host seconds inside pass_launch / pass_collect (diagnostic, logged to stderr)
-        for i in range(args.steps):
-            if len(inflight) == args.pipeline:
-                tc = time.perf_counter()
-                collected.append(pass_collect(inflight.pop(0)))
-                host_collect.append(time.perf_counter() - tc)
-            tl = time.perf_counter()
-            inflight.append(pass_launch(model, audio_chunks, setup, (i % args.pipeline) * args.streams))
-            host_launch.append(time.perf_counter() - tl)
-        log("host ms inside pass_launch: " + " ".join(f"{1e3 * t:.1f}" for t in host_launch) + " | inside pass_collect: "
-            + " ".join(f"{1e3 * t:.1f}" for t in host_collect))
-    while inflight:
-        collected.append(pass_collect(inflight.pop(0)))
-    tokens = collected[-1]
-    timed_barrier(dist)
-    elapsed = max_over_ranks(dist, time.perf_counter() - t0)
+    if args.phase:
+        return run_phase(args, model, audio_dev, opts, bench_splits, rank, dist)
 
-    if PHASE:
-        if rank == 0:
-            print(json.dumps({"diagnostic_phase": PHASE, "ms_per_pass": round(1000.0 * elapsed / args.steps, 2), "passes_in_flight": args.pipeline,
-                              "cross_frame_splits": model.cross_splits or 4, "note": "one half of the pass only: NOT a benchmark number"}), flush=True)
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
+    # THE TIMED REGION IS THE PRODUCT PATH: whisper_ipa_amd.pipeline.TranscribePipeline -- the scheduler behind
+    # transcribe_batches(model, batches, options, passes_in_flight=P), which scripts/evaluate_model.py and validate() call.
+    # Pass i runs on stream set (i % P) and is only collected when its stream set is needed again, so the encoder of pass
+    # i + 1 overlaps the decode loop of pass i; each pass does all of its work inside the timed region on its own workspaces /
+    # KV caches.  stop_on_eot=False: a fixed NEW_TOKENS positions per clip (EOT latch on), so the work is fixed.
+    collected = []  # every timed pass's ids (host arrays), compared after the timed region
+    with TranscribePipeline(model, opts, args.pipeline, max_new_tokens=NEW_TOKENS, stop_on_eot=False, cross_splits=bench_splits) as pipe:
+        for i in range(args.warmup):
+            for _ in range(args.pipeline):  # warm every stream set (workspaces, KV caches, captured graphs)
+                pipe.submit(audio_dev)
+            for _ in pipe.drain():
+                pass
+            torch.cuda.synchronize()
+            log(f"warmup pass {i} done")
+        timed_barrier(dist)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            collected += [r.tokens for r in pipe.submit(audio_dev)]
+        collected += [r.tokens for r in pipe.drain()]
+        timed_barrier(dist)
+        elapsed = max_over_ranks(dist, time.perf_counter() - t0)
+    tokens = collected[-1]
+    assert len(collected) == args.steps
+    model.cross_splits = bench_splits  # the legs below measure the setting that was timed
+
     out = None
-    absorbed_run = bench_absorbed(model, audio_chunks[0].shape[0])
+    absorbed_run = bench_absorbed(model, B)
     if rank == 0:
         audio_seconds = world * B * 30.0 * args.steps
         out = {
@@ -1170,10 +1210,11 @@ def main():
                                       f"passes in flight; 4 = the lone-decode default, timed below as *_default_splits)"
                                       if absorbed_run and model.cross_splits not in (0, 4) else ""),
                        "cross_frame_splits": (model.cross_splits or 4) if absorbed_run else None,
-                       "clips_per_gpu": B, "clips_in_flight_per_gpu": args.pipeline * B, "new_tokens": NEW_TOKENS, "streams_per_gpu": args.streams,
-                       "passes_in_flight": args.pipeline, "decode_group": args.decode_group,
-                       "encoder_cus": args.encoder_cus, "decoder_cus": args.decoder_cus,
-                       "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+                       "clips_per_gpu": B, "clips_in_flight_per_gpu": args.pipeline * B, "new_tokens": NEW_TOKENS,
+                       "passes_in_flight": args.pipeline,
+                       "schedule": "whisper_ipa_amd.pipeline.TranscribePipeline (the scheduler of transcribe_batches; what "
+                                   "scripts/evaluate_model.py and validate() call)",
+                       "hw_queues": hw_queues(),
                        "parallelism": f"dp{world} (clip sharding, no collective)"},
             "tokens_checksum": int(tokens.sum() % 1000003),
             # every timed pass transcribes the same clips: identical ids in all of them (a race in a kernel would show here)
@@ -1183,39 +1224,40 @@ def main():
         # ---- everything below is OUTSIDE the timed region, one pass in flight
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        single = one_pass(model, audio_chunks, setup)
+        single = one_pass(model, audio_dev)
         out["ms_per_pass_single_in_flight"] = round((time.perf_counter() - t1) * 1e3, 2)
         # the same metric with ONE pass (B clips) resident at a time: the latency figure next to the throughput figure `value`
         out["value_single_in_flight"] = round(world * B * 30.0 / (out["ms_per_pass_single_in_flight"] * 1e-3), 1)
-        assert args.decode_group > 1 or (single == tokens).all(), "the pipelined and the single pass disagree on the ids"
-        assert args.decode_group > 1 or out["passes_identical"], "timed passes over the same clips produced different ids"
-        if args.decode_split == 1:
-            out["roofline"] = roofline_cross_attn(model, audio_chunks[0].shape[0])
-        if args.streams == 1 and args.decode_split == 1:
-            out["decode_step"] = decode_step_roofline(model, audio_chunks[0].shape[0])
-            if absorbed_run and model.cross_splits not in (0, 4):
-                # the same two latency figures in the library's DEFAULT setting (4 frame splits: what a caller with one pass at a
-                # time runs); the bench setting trades them for throughput with several passes in flight
-                keep = model.cross_splits
-                model.cross_splits = 0
-                one_pass(model, audio_chunks, setup)  # captures the step graph of this setting
-                torch.cuda.synchronize()
-                t2 = time.perf_counter()
-                one_pass(model, audio_chunks, setup)
-                ms1 = (time.perf_counter() - t2) * 1e3
-                dflt = decode_step_roofline(model, audio_chunks[0].shape[0])
-                rf4 = roofline_cross_attn(model, audio_chunks[0].shape[0])
-                out["default_splits"] = {"cross_frame_splits": 4, "ms_per_pass_single_in_flight": round(ms1, 2),
-                                         "value_single_in_flight": round(world * B * 30.0 / (ms1 * 1e-3), 1),
-                                         "decode_step_ms": dflt["ms_per_step"], "decode_step_frac": dflt["frac"],
-                                         "streaming_launch": {k: rf4[k] for k in ("workgroups", "avg_launch_ms", "achieved", "frac", "traffic",
-                                                                                  "algorithmic_bytes_per_launch")}}
-                # next to the timed setting's own figures: the same kernel as the library launches it by default (all 256 CUs)
-                out["roofline"]["library_default_setting"] = dict(out["default_splits"]["streaming_launch"], frame_splits=4)
-                model.cross_splits = keep
-                one_pass(model, audio_chunks, setup)  # back to the timed setting: the parity legs below check what was timed
-            if args.dtype == "bf16" and args.batch <= 128:
-                out["roofline_mfma"] = roofline_mfma(model, audio_chunks[0])
+        assert (single == tokens).all(), "the pipelined and the single pass disagree on the ids"
+        assert out["passes_identical"], "timed passes over the same clips produced different ids"
+        out["evaluate_style"] = evaluate_style(model, audio_dev, args, world, out["value"])
+        log("evaluate-style run done")
+        one_pass(model, audio_dev)  # stream 0's decode state back to the timed setting (evaluate_style re-captured nothing else)
+        out["roofline"] = roofline_cross_attn(model, B)
+        out["decode_step"] = decode_step_roofline(model, B)
+        if absorbed_run and model.cross_splits not in (0, 4):
+            # the same two latency figures in the library's DEFAULT setting (4 frame splits: what a caller with one pass at a
+            # time runs); the bench setting trades them for throughput with several passes in flight
+            keep = model.cross_splits
+            model.cross_splits = 0
+            one_pass(model, audio_dev)  # captures the step graph of this setting
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            one_pass(model, audio_dev)
+            ms1 = (time.perf_counter() - t2) * 1e3
+            dflt = decode_step_roofline(model, B)
+            rf4 = roofline_cross_attn(model, B)
+            out["default_splits"] = {"cross_frame_splits": 4, "ms_per_pass_single_in_flight": round(ms1, 2),
+                                     "value_single_in_flight": round(world * B * 30.0 / (ms1 * 1e-3), 1),
+                                     "decode_step_ms": dflt["ms_per_step"], "decode_step_frac": dflt["frac"],
+                                     "streaming_launch": {k: rf4[k] for k in ("workgroups", "avg_launch_ms", "achieved", "frac", "traffic",
+                                                                              "algorithmic_bytes_per_launch")}}
+            # next to the timed setting's own figures: the same kernel as the library launches it by default (all 256 CUs)
+            out["roofline"]["library_default_setting"] = dict(out["default_splits"]["streaming_launch"], frame_splits=4)
+            model.cross_splits = keep
+            one_pass(model, audio_dev)  # back to the timed setting: the parity legs below check what was timed
+        if args.dtype == "bf16" and args.batch <= 128:
+            out["roofline_mfma"] = roofline_mfma(model, audio_dev)
         log("roofline microbenches done")
         if world == 1 and not args.no_cpu_baseline and args.model == "small" and B >= 8:
             out["cpu_baseline"], ref, xa_ref = cpu_baseline(8)  # ~25 s of host work
@@ -1230,7 +1272,7 @@ def main():
                 _, Wp = synthetic_weights_small(0, args.model, preset="peaky")
                 model.load_weights({"decoder.positional_embedding": Wp["decoder.positional_embedding"]}, strict=False)
                 del Wp
-                peaky_ids = one_pass(model, [audio_dev[:8].contiguous()], setup)
+                peaky_ids = one_pass(model, audio_dev[:8].contiguous())
                 out["parity_vs_cpu_peaky"] = parity_vs_cpu(model, audio_dev, peaky_ids, ref_p, setup, "peaky")
                 model.load_weights({"decoder.positional_embedding": lively_pos}, strict=False)
                 log("peaky preset parity done")
@@ -1247,6 +1289,15 @@ def main():
             out["finetune_step"] = {k: ft[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "stages", "roofline", "loss",
                                                        "with_feature_cache")}
             log("fine-tune step measured")
+            model = None
+        if (world == 1 and not args.no_other_configs and args.model == "small" and args.dtype == "bf16" and args.weights == "bf16"
+                and B == BATCH and NEW_TOKENS == 64):
+            import gc
+
+            model = None
+            gc.collect()
+            torch.cuda.empty_cache()
+            out["other_configs"] = other_configs(args)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -4,9 +4,10 @@ checkpoint, print the first three examples, PER / PFER (mean ± std), the compar
 target thresholds (reference :127-268), same CLI flags (:272-308).
 
 Differences that the hardware asks for:
-  * clips are decoded in batches of ``--batch-size`` (the reference is batch 1, :181-212); the
-    result per clip is the same because every kernel on the path is batch-invariant
-    (tests/test_gpu_model.py::tests/test_gpu_model.py::test_full_size_bench_workload_properties);
+  * clips are decoded in batches of ``--batch-size`` (the reference is batch 1, :181-212), ``--passes-in-flight`` batches
+    at a time on one GPU (whisper_ipa_amd.pipeline.transcribe_batches -- the schedule bench.py times); the result per clip is
+    the same because every kernel on the path is batch-invariant and passes share no state
+    (tests/test_gpu_model.py::test_full_size_bench_workload_properties, ::test_transcribe_batches_*);
   * under ``torchrun`` every rank takes a contiguous slice of the test list with a full weight
     replica and no collective on the data path; the hypotheses are gathered once at the end;
   * the base model is a local directory (no hub access) and the base-model leg uses the same
@@ -24,6 +25,7 @@ import sys
 from pathlib import Path
 from typing import Dict, List, Optional
 
+import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -31,9 +33,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from evaluate_ipa import evaluate_batch  # noqa: E402
 from whisper_ipa_amd import parallel  # noqa: E402
-from whisper_ipa_amd.audio import load_audio, log_mel_spectrogram, pad_or_trim  # noqa: E402
-from whisper_ipa_amd.decoding import DecodingOptions, decode  # noqa: E402
+from whisper_ipa_amd.audio import load_audio, pad_or_trim  # noqa: E402
+from whisper_ipa_amd.decoding import DecodingOptions  # noqa: E402
 from whisper_ipa_amd.load_models import load_model, overlay_decoder_weights  # noqa: E402
+from whisper_ipa_amd.pipeline import transcribe_batches  # noqa: E402
 
 
 def load_checkpoint_model(checkpoint_path: str, base_model: str = "mlx-community/whisper-small-mlx"):
@@ -51,26 +54,53 @@ def load_checkpoint_model(checkpoint_path: str, base_model: str = "mlx-community
     return model
 
 
-def transcribe_batch(model, audio_paths: List[str], n_mels: int, options: DecodingOptions) -> List[str]:
-    """reference :184-201 for a list of clips; a clip that cannot be read yields "" (:202-204)."""
-    mels, slots = [], []
+def load_clips(audio_paths: List[str]):
+    """host side of reference :184-189 for a list of clips: (audio [n_ok, 480000] f32 or None, positions of the readable clips);
+    a clip that cannot be read is reported and yields "" (:202-204)."""
+    clips, slots = [], []
     for i, path in enumerate(audio_paths):
         try:
-            mels.append(log_mel_spectrogram(pad_or_trim(load_audio(path)), n_mels=n_mels).to(torch.float32))
+            clips.append(np.asarray(pad_or_trim(load_audio(path)), dtype=np.float32))
             slots.append(i)
         except Exception as e:
             print(f"\nError transcribing {path}: {e}")
+    return (torch.from_numpy(np.stack(clips)) if clips else None), slots
+
+
+def transcribe_clips(model, audio_paths: List[str], options: DecodingOptions, batch_size: int = 64,
+                     passes_in_flight: int = 4, progress=None) -> List[str]:
+    """reference :181-212 for the whole list: ``batch_size`` clips per batch, ``passes_in_flight`` batches in flight on one GPU
+    (whisper_ipa_amd.pipeline.transcribe_batches: log-mel -> encoder -> greedy decode per batch on its own stream set, the
+    files of the next batches read on a helper thread meanwhile).  One text per path, "" where the file could not be read."""
     texts = [""] * len(audio_paths)
-    if mels:
-        feats = model.encoder(torch.stack(mels))
-        for i, r in zip(slots, decode(model, feats, options)):
-            texts[i] = r.text.strip()
+    metas = []  # (first clip of the batch, positions of its readable clips), in submission order
+
+    def batches():
+        for b in range(0, len(audio_paths), batch_size):
+            audio, slots = load_clips(audio_paths[b:b + batch_size])
+            if audio is None:
+                continue
+            metas.append((b, slots))
+            yield audio
+
+    for r in transcribe_batches(model, batches(), options, passes_in_flight=passes_in_flight, prefetch=passes_in_flight):
+        b, slots = metas[r.index]
+        for i, text in zip(slots, r.texts):
+            texts[b + i] = text.strip()
+        if progress is not None:
+            progress(min(b + batch_size, len(audio_paths)))
     return texts
+
+
+def transcribe_batch(model, audio_paths: List[str], n_mels: int, options: DecodingOptions) -> List[str]:
+    """ONE batch with nothing else in flight (round 4's entry point, kept for callers that hold a single batch)"""
+    assert n_mels == model.dims.n_mels
+    return transcribe_clips(model, audio_paths, options, batch_size=max(1, len(audio_paths)), passes_in_flight=1)
 
 
 def evaluate_model(model_path: str, test_data_path: str, num_samples: Optional[int] = None, model_name: str = "Model",
                    is_checkpoint: bool = False, n_mels: int = 80, base_model: str = "mlx-community/whisper-small-mlx",
-                   batch_size: int = 64) -> Dict:
+                   batch_size: int = 64, passes_in_flight: int = 4) -> Dict:
     rank, world_size = parallel.world()
     say = print if rank == 0 else (lambda *a, **k: None)
     say("=" * 70)
@@ -99,11 +129,9 @@ def evaluate_model(model_path: str, test_data_path: str, num_samples: Optional[i
     lo, hi = parallel.shard_bounds(len(test_data), world_size, rank)
     mine = test_data[lo:hi]
     say("\nTranscribing test samples...")
-    local_hyp: List[str] = []
-    for b in range(0, len(mine), batch_size):
-        chunk = mine[b:b + batch_size]
-        local_hyp.extend(transcribe_batch(model, [s["audio_path"] for s in chunk], n_mels, options))
-        say(f"  {min(b + batch_size, len(mine))}/{len(mine)} clips on rank 0", flush=True)
+    local_hyp = transcribe_clips(model, [s["audio_path"] for s in mine], options, batch_size=batch_size,
+                                 passes_in_flight=passes_in_flight,
+                                 progress=lambda n: say(f"  {n}/{len(mine)} clips on rank 0", flush=True))
     hypotheses = local_hyp
     if world_size > 1:
         import torch.distributed as dist
@@ -171,6 +199,8 @@ def main(argv=None) -> Dict:
     ap.add_argument("--skip-base", action="store_true", help="Skip base model evaluation (only evaluate checkpoint)")
     ap.add_argument("--n-mels", type=int, default=128, help="Number of mel bins (80 for small/medium, 128 for large)")
     ap.add_argument("--batch-size", type=int, default=64, help="clips decoded together per GPU")
+    ap.add_argument("--passes-in-flight", type=int, default=4,
+                    help="batches kept in flight on one GPU (whisper_ipa_amd.pipeline.transcribe_batches); 1 = one batch at a time")
     ap.add_argument("--results-json", type=str, default=None, help="also write both result dicts here (rank 0)")
     ap.add_argument("--allow-byte-fallback", action="store_true",
                     help="run without the Whisper vocabulary (WIPA_TIKTOKEN unset): hypotheses render ids >= 256 as <|idN|>; "
@@ -191,9 +221,11 @@ def main(argv=None) -> Dict:
     base_results = None
     if not args.skip_base:
         base_results = evaluate_model(args.base_model, args.test_data, num_samples, model_name="Base Whisper Model",
-                                      is_checkpoint=False, n_mels=args.n_mels, base_model=args.base_model, batch_size=args.batch_size)
+                                      is_checkpoint=False, n_mels=args.n_mels, base_model=args.base_model, batch_size=args.batch_size,
+                                      passes_in_flight=args.passes_in_flight)
     trained_results = evaluate_model(args.checkpoint, args.test_data, num_samples, model_name="Trained Checkpoint",
-                                     is_checkpoint=True, n_mels=args.n_mels, base_model=args.base_model, batch_size=args.batch_size)
+                                     is_checkpoint=True, n_mels=args.n_mels, base_model=args.base_model, batch_size=args.batch_size,
+                                      passes_in_flight=args.passes_in_flight)
     if rank == 0:
         if base_results:
             compare_models(base_results, trained_results)

@@ -37,6 +37,7 @@ from ipa_data_loader import create_data_loader  # noqa: E402
 from whisper_ipa_amd import parallel  # noqa: E402
 from whisper_ipa_amd.decoding import DecodingOptions  # noqa: E402
 from whisper_ipa_amd.load_models import load_model, save_safetensors  # noqa: E402
+from whisper_ipa_amd.pipeline import transcribe_batches  # noqa: E402
 from whisper_ipa_amd.training import DecoderTrainer  # noqa: E402
 
 
@@ -170,6 +171,9 @@ def train_step(trainer: DecoderTrainer, batch: Dict, tokenizer):
     return trainer.train_step(batch["mel_features"], batch["tokens"], tokenizer.eot, clip_keys=batch.get("clip_keys"))
 
 
+VALIDATE_PASSES_IN_FLIGHT = 4  # validation batches in flight on one GPU (whisper_ipa_amd.pipeline.transcribe_batches)
+
+
 def validate(model, dataset, tokenizer, num_samples: int = 100) -> Dict:
     """reference :314-407: batched greedy decode (language=None -> detection, fp16=False), PER / PFER.
 
@@ -185,24 +189,36 @@ def validate(model, dataset, tokenizer, num_samples: int = 100) -> Dict:
     val_batch_size = 4
     options = DecodingOptions(language=None, without_timestamps=True, fp16=False, length_penalty=1.0)
     mine = []  # (batch index, refs, hyps)
-    for i in range((num_samples + val_batch_size - 1) // val_batch_size):
-        indices = list(range(i * val_batch_size, min((i + 1) * val_batch_size, num_samples)))
-        if not indices:
-            break
-        if i % world != rank:
-            continue
-        try:
-            batch = dataset.get_batch(indices)
-            results = model.decode(batch["mel_features"], options)
-            if not isinstance(results, list):
-                results = [results]
-            hyps = [r.text.strip() for r in results]
-            refs = [re.sub(r"<\|.*?\|>", "", tokenizer.decode(batch["tokens"][j].tolist())).strip() for j in range(len(indices))]
-            mine.append((i, refs, hyps))
-        except Exception as e:  # reference :393-396 keeps going
-            print(f"Error during validation decoding: {e}")
-            import traceback
-            traceback.print_exc()
+    metas = []  # (batch index, refs) of every batch handed to the pipeline, in submission order
+
+    def batches():
+        for i in range((num_samples + val_batch_size - 1) // val_batch_size):
+            indices = list(range(i * val_batch_size, min((i + 1) * val_batch_size, num_samples)))
+            if not indices:
+                break
+            if i % world != rank:
+                continue
+            try:
+                batch = dataset.get_batch(indices)
+                refs = [re.sub(r"<\|.*?\|>", "", tokenizer.decode(batch["tokens"][j].tolist())).strip() for j in range(len(indices))]
+            except Exception as e:  # reference :393-396 keeps going
+                print(f"Error during validation decoding: {e}")
+                import traceback
+                traceback.print_exc()
+                continue
+            metas.append((i, refs))
+            yield batch["mel_features"]
+
+    # the reference decodes one 4-clip batch at a time (:338-362); here VALIDATE_PASSES_IN_FLIGHT of them are in flight on their
+    # own streams (whisper_ipa_amd.pipeline): same ids per clip, the encoder of one batch beside the decode loops of the others
+    try:
+        for r in transcribe_batches(model, batches(), options, passes_in_flight=VALIDATE_PASSES_IN_FLIGHT):
+            i, refs = metas[r.index]
+            mine.append((i, refs, [t.strip() for t in r.texts]))
+    except Exception as e:  # reference :393-396: report and score what was decoded
+        print(f"Error during validation decoding: {e}")
+        import traceback
+        traceback.print_exc()
     if world > 1:
         import torch.distributed as dist
 

@@ -683,9 +683,9 @@ def test_full_size_bench_workload_properties(cross_attention):
     f96, t96 = run(audio96)
     assert torch.equal(f96[:64], f64) and (t96[:64] == t64).all()
     assert len({tuple(r) for r in t96[64:, 4:].tolist()}) > 4
-    # cross-batch decode grouping (bench.py --decode-group): two batches decoded as one group of 128 rows give each
-    # clip the tokens it gets in its own batch
-    grouped = bench.pass_collect(bench.group_launch(m, audio, (init, always, first, eot), 0, 2))
+    # two batches decoded as one group of 128 rows give each clip the tokens it gets in its own batch
+    feats = m.encode_padded(A.log_mel_padded(audio, dims.n_mels, torch.bfloat16), 64)
+    grouped = greedy_decode_tokens(m, torch.cat([feats, feats]), init, always, first, eot, max_new_tokens=16, stop_on_eot=False).tokens
     assert grouped.shape[0] == 128 and (grouped[:64] == grouped[64:]).all()
     assert (grouped[:64, : 4 + 16] == t64).all()
 
@@ -941,3 +941,96 @@ def test_fp8_activation_encoder_on_the_fp8_mfma(name, dims):
     assert rms_vs_bf16 < 0.15, rms_vs_bf16              # e4m3 activations: a few percent of the feature rms
     assert (margins[flips] <= 2.0 * err[flips]).all()   # ids differ only where the measured logit difference allows it
     assert err.max() < 0.35 * spread, (err.max(), spread)
+
+
+# ---- several batches in flight: whisper_ipa_amd.pipeline (the schedule bench.py times and the scripts call) ----------------------
+
+def test_transcribe_batches_early_stop_language_detection_and_order_match_decode():
+    """pipeline.transcribe_batches against ``decode`` one batch at a time (float32, a model that does end its rows): ragged
+    batch sizes, more batches than slots, early stop armed (chunks of 3 steps, EOT probes behind them), per-clip language
+    detection on the device.  Every field the reference's callers read (scripts/evaluate_model.py:190-201,
+    scripts/train_whisper_ipa.py:352-362) is the one ``decode`` gives: tokens, text, language, avg_logprob; results come
+    back in input order; the model's cross_splits setting is restored."""
+    import whisper_ipa_amd as wipa
+
+    dims = R.ModelDimensions(80, 1500, 64, 1, 1, 51865, 448, 64, 1, 1)
+    W = R.synthetic_weights(dims, seed=3)
+    m = _model(dims, W, torch.float32)
+    sp = R.SpecialTokens.multilingual()
+    allowed = {sp.eot, 100, 200, 300}
+    suppress = [t for t in range(dims.n_vocab) if t not in allowed]
+    torch.manual_seed(1)
+    batches = [torch.randn(b, 1500, 64) for b in (3, 1, 4, 2, 3, 4, 1)]
+    for language in ("en", None):
+        opts = wipa.DecodingOptions(language=language, without_timestamps=True, fp16=False, suppress_tokens=suppress, suppress_blank=False,
+                                    sample_len=40)
+        want = [wipa.decode(m, b.cuda(), opts) for b in batches]
+        before = m.cross_splits
+        got = list(wipa.transcribe_batches(m, batches, opts, passes_in_flight=3, check_every=3))
+        assert m.cross_splits == before
+        assert [r.index for r in got] == list(range(len(batches)))
+        lens = set()
+        for r, w in zip(got, want):
+            assert len(r.results) == len(w)
+            for a, b in zip(r.results, w):
+                assert a.tokens == b.tokens and a.text == b.text and a.language == b.language
+                assert abs(a.avg_logprob - b.avg_logprob) < 1e-4
+                if language is None:
+                    assert max(abs(a.language_probs[k] - b.language_probs[k]) for k in b.language_probs) < 1e-5
+            lens.add(r.n_steps)
+        assert len(lens) > 1 and min(lens) < 40, lens  # the passes did stop early, at different lengths
+    # the serial schedule and a prefetching iterator give the same
+    opts = wipa.DecodingOptions(language="en", without_timestamps=True, fp16=False, suppress_tokens=suppress, suppress_blank=False, sample_len=40)
+    a = [r.rows() for r in wipa.transcribe_batches(m, batches, opts, passes_in_flight=1)]
+    b = [r.rows() for r in wipa.transcribe_batches(m, iter(batches), opts, passes_in_flight=4, prefetch=2)]
+    assert a == b == [[r.tokens for r in wipa.decode(m, x.cuda(), opts)] for x in batches]
+    with pytest.raises(wipa._lib.WipaError):
+        list(wipa.transcribe_batches(m, [torch.zeros(1, 2, 3, 4)], opts))  # neither audio, mel nor features
+
+
+def test_transcribe_batches_320_clips_ids_identical_to_the_serial_path():
+    """the 4-passes-in-flight schedule at FULL size (whisper-small 12+12 bf16, 64-clip batches of distinct
+    clips, 5 batches = 320 clips so a stream set is reused) gives every clip the ids of the serial path -- one batch at a
+    time through log_mel_padded -> encode_padded -> greedy_decode_tokens in the same streaming-launch setting (cross_splits = 2,
+    what the schedule sets) -- bit for bit; with early stop armed (the random-init model never ends a row) the same again;
+    audio handed over on the host the same again.  Informational: the match rate against the serial path in the library's
+    default setting (4 splits), where only the order of the softmax merges differs."""
+    import bench
+    from whisper_ipa_amd import audio as A
+    from whisper_ipa_amd.decoding import DecodingOptions, greedy_decode_tokens
+    from whisper_ipa_amd.pipeline import PIPELINE_CROSS_SPLITS, transcribe_batches
+    from whisper_ipa_amd.whisper import Whisper
+
+    dims, W = bench.synthetic_weights_small(0)
+    m = Whisper(dims, dtype=torch.bfloat16)
+    m.load_weights(W)
+    del W
+    init, always, first, eot = bench.decode_setup()
+    opts = DecodingOptions(language="en", without_timestamps=True)
+    n_new = 24
+    host = [torch.from_numpy(bench.synthetic_audio(64 * i, 64)) for i in range(5)]
+    dev = [a.cuda() for a in host]
+
+    def serial(splits):
+        m.cross_splits = splits
+        out = []
+        for a in dev:
+            feats = m.encode_padded(A.log_mel_padded(a, dims.n_mels, torch.bfloat16), 64)
+            out.append(greedy_decode_tokens(m, feats, init, always, first, eot, max_new_tokens=n_new, stop_on_eot=False).tokens)
+        m.cross_splits = 0
+        return out
+
+    want = serial(PIPELINE_CROSS_SPLITS)
+    got = [r.tokens for r in transcribe_batches(m, dev, opts, passes_in_flight=4, max_new_tokens=n_new, stop_on_eot=False)]
+    assert m.cross_splits == 0
+    assert len(got) == 5 and all((g == w).all() for g, w in zip(got, want))
+    assert len({tuple(r) for t in got for r in t[:, 4:].tolist()}) > 160  # distinct clips, distinct ids
+    armed = [r.tokens for r in transcribe_batches(m, dev, opts, passes_in_flight=4, max_new_tokens=n_new, check_every=8)]
+    assert all((g == w).all() for g, w in zip(armed, want))
+    from_host = [r.tokens for r in transcribe_batches(m, host[:2], opts, passes_in_flight=2, max_new_tokens=n_new, stop_on_eot=False)]
+    assert all((g == w).all() for g, w in zip(from_host, want))
+    one = [r.tokens for r in transcribe_batches(m, dev[:2], opts, passes_in_flight=1, max_new_tokens=n_new, stop_on_eot=False)]
+    dflt = serial(0)
+    assert all((g == w).all() for g, w in zip(one, dflt))  # one batch at a time: the model's own setting
+    match = np.mean([(g[:, 4:] == w[:, 4:]).mean() for g, w in zip(got, dflt)])
+    print(f"\n4 passes in flight (2 frame splits) vs serial default (4 splits), random-init bf16: token match {match:.4f}")

@@ -238,8 +238,8 @@ def test_train_step_matches_oracle_clip_and_adamw(setup, f32_mode, clip_scope):
     above 1 among the block tensors (mlp1.weight 6.9, attn.value.weight 5.7) and outside them (token_embedding.weight 2.6),
     asserted below, so the two scopes give different updates.  The parameter bound is the sensitive one:
     without bias correction an element with |g| ~ eps moves by lr * m / (sqrt(v) + eps), which amplifies a 1e-5 relative
-    gradient difference; 2e-4 holds with exact f32 GEMMs, 5e-4 with the three-term bf16 split."""
-    p_tol = 2e-4 if f32_mode == "exact" else 5e-4
+    gradient difference; 2e-4 holds with exact f32 GEMMs, 5e-4 with the three-term bf16 split (per unit of gradient norm)."""
+    p_tol0 = 2e-4 if f32_mode == "exact" else 5e-4
     from whisper_ipa_amd.training import DecoderTrainer
     from whisper_ipa_amd.whisper import ModelDimensions, Whisper
 
@@ -261,6 +261,10 @@ def test_train_step_matches_oracle_clip_and_adamw(setup, f32_mode, clip_scope):
                 assert torch.equal(g[k], g_raw[k])
             else:
                 assert abs(float(g[k].norm()) - 1.0) < 1e-4
+        # the update of an element with |g| ~ eps / sqrt(1 - b2) turns an ABSOLUTE gradient error into lr * 0.1 / eps times as much
+        # parameter error, and a tensor's absolute round-off scales with its norm: tensors that pass through unclipped (norms up
+        # to 6.9 here) get the bound of a norm-1 tensor times their norm
+        p_tol = {k: p_tol0 * max(1.0, float(gk.norm())) for k, gk in g.items()}
         for k, gk in g.items():
             mm, vv = state.get(k, (torch.zeros_like(gk), torch.zeros_like(gk)))
             Wo[k], mm, vv = R.adamw_mlx(Wo[k], gk, mm, vv, lr=1e-3)
@@ -273,7 +277,7 @@ def test_train_step_matches_oracle_clip_and_adamw(setup, f32_mode, clip_scope):
             # without bias correction an element with |g| ~ eps moves by lr*0.1*g/eps: 1e-9 of gradient
             # round-off is 1e-5 of parameter, so the end-to-end bound is loose; the exact update rule
             # is pinned by test_clip_adamw_kernel_exact below
-            assert (tr.p(n).cpu() - Wo[n]).abs().max() < p_tol, (step, "param", n)
+            assert (tr.p(n).cpu() - Wo[n]).abs().max() < p_tol[n], (step, "param", n)
     # the model's inference tables see the updated weights (no_grad: the forward-only C++ pass over the packed tables)
     with torch.no_grad():
         lg = m.logits(tokens[:, :-1].cuda(), xa.cuda())

@@ -419,11 +419,23 @@ class _FakeValTok:
         return "".join("<|sot|>" if t == 50258 else "<|eot|>" if t == 50257 else chr(t) for t in ids)
 
 
+def _fake_transcribe_batches(model, batches, options, passes_in_flight=4, **kw):
+    """pipeline.transcribe_batches' contract as validate() uses it (lazy iteration, one result per batch in input order with
+    .index and .texts), on the fake model: no GPU in this test"""
+    from types import SimpleNamespace
+
+    assert passes_in_flight >= 1
+    for i, mel in enumerate(batches):
+        yield SimpleNamespace(index=i, texts=[r.text for r in model.decode(mel, options)])
+
+
 def _validate_worker(rank, world, port, q):
     import torch.distributed as dist
 
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import train_whisper_ipa as T
+
+    T.transcribe_batches = _fake_transcribe_batches
 
     if world > 1:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -827,3 +839,36 @@ def test_native_bpe_matches_the_python_merge_loop(tmp_path):
     assert out[:, :w].tolist() == want and (out[:, w:] == -1).all()
     assert L.wipa_build_token_batch((C.c_int32 * len(flat))(*flat), (C.c_int32 * 4)(*[len(r) for r in rows]), 4, (C.c_int32 * 4)(*prefix), 4, eot,
                                     out.data_ptr(), 10) < 0  # rows do not fit
+
+
+def test_hw_queue_request_and_batch_prefetch(monkeypatch):
+    """pipeline's host-side plumbing without a GPU: the hardware-queue request never overrides the user's GPU_MAX_HW_QUEUES,
+    sets 8 when nothing has initialised the GPU, reports the ROCm default when it came too late; the prefetching iterator
+    keeps order and surfaces the producer's exception in the consumer."""
+    import whisper_ipa_amd.runtime as RT
+    from whisper_ipa_amd.pipeline import _prefetched
+
+    assert os.environ.get("GPU_MAX_HW_QUEUES") is not None  # importing the package asked for it (or the user had set it)
+    monkeypatch.setitem(RT._hwq, "requested_in_time", None)
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "6")
+    assert RT.request_hw_queues() == 6 and RT.hw_queues() == 6  # the user's value stands
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES")
+    monkeypatch.setitem(RT._hwq, "requested_in_time", None)
+    assert RT.request_hw_queues() == 8 and os.environ["GPU_MAX_HW_QUEUES"] == "8" and RT.hw_queues() == 8
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES")
+    monkeypatch.setattr(torch.cuda, "is_initialized", lambda: True)
+    assert RT.request_hw_queues() == RT.ROCM_DEFAULT_HW_QUEUES and "GPU_MAX_HW_QUEUES" not in os.environ  # too late: not pretended
+    assert RT.hw_queues() == RT.ROCM_DEFAULT_HW_QUEUES
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")  # set after the runtime started: not in effect
+    assert RT.hw_queues() == RT.ROCM_DEFAULT_HW_QUEUES
+
+    assert list(_prefetched(iter(range(7)), 2)) == list(range(7))
+
+    def bad():
+        yield 1
+        raise OSError("unreadable")
+
+    it = _prefetched(bad(), 1)
+    assert next(it) == 1
+    with pytest.raises(OSError):
+        next(it)

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import os
 import threading
 from typing import Optional
 
@@ -22,6 +23,40 @@ from . import _lib
 _streams = {}
 _stream_cus = {}  # library stream id -> CU limit (limit_stream_cus), read when the stream is first used
 _tls = threading.local()
+
+
+ROCM_DEFAULT_HW_QUEUES = 4
+_hwq = {"requested_in_time": None}
+
+
+def request_hw_queues(n: int = 8) -> int:
+    """ROCm multiplexes the HIP streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable
+    ONCE, when the HIP runtime starts.  Several passes in flight (pipeline.transcribe_batches) want 8: with 4 passes on 4 queues
+    a pass takes 86-88 ms, on 8 queues 72 ms (whisper-small, 64 clips).  Called when the package is imported:
+    if the user has not set the variable and nothing has initialised the GPU yet, set it; a user's own value is never
+    overridden.  Returns the count that will be (or is) in effect."""
+    if "GPU_MAX_HW_QUEUES" in os.environ:
+        if _hwq["requested_in_time"] is None:
+            _hwq["requested_in_time"] = not torch.cuda.is_initialized()  # set by the user (or an earlier import) before HIP started?
+        return hw_queues()
+    if torch.cuda.is_initialized():
+        _hwq["requested_in_time"] = False  # too late: the runtime has read its flags
+        return ROCM_DEFAULT_HW_QUEUES
+    os.environ["GPU_MAX_HW_QUEUES"] = str(int(n))
+    _hwq["requested_in_time"] = True
+    return int(n)
+
+
+def hw_queues() -> int:
+    """the hardware-queue count in effect for this process, as far as the host can know it: GPU_MAX_HW_QUEUES when it was in
+    the environment before the HIP runtime started, the ROCm default otherwise"""
+    v = os.environ.get("GPU_MAX_HW_QUEUES")
+    if v is None or _hwq["requested_in_time"] is False:
+        return ROCM_DEFAULT_HW_QUEUES
+    try:
+        return max(1, int(v))
+    except ValueError:
+        return ROCM_DEFAULT_HW_QUEUES
 
 
 def device() -> torch.device:
