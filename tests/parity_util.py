@@ -95,3 +95,16 @@ def masked_margins(trace: torch.Tensor, always, first) -> np.ndarray:
         t[:, 0, list(first)] = float("-inf")
     top2 = torch.topk(t, 2, dim=-1).values
     return (top2[..., 0] - top2[..., 1]).cpu().numpy()
+
+
+def norm64(t) -> float:
+    """L2 norm in float64 -- the yardstick for every norm a test asserts.  torch's float32 ``.norm()`` is NOT one: on the
+    [51865, 128] token-embedding gradient of the training tests it reads 0.99988 where the float64 norm (and the oracle's own
+    f32 ``sqrt(sum(g*g))``, the reference's formula) is 0.9999995 -- measured r05, 1.2e-4 off, enough to fail or pass a 1e-4
+    bound by the host's luck."""
+    return float(t.detach().double().cpu().norm())
+
+
+def clipped_norm(n: float, max_norm: float = 1.0) -> float:
+    """the norm ``clip_grad_dict`` leaves on a tensor of norm n > max_norm: n * max_norm / (n + 1e-6) (train_whisper_ipa.py:295-298)"""
+    return n * max_norm / (n + 1e-6)

@@ -74,13 +74,18 @@ def test_bench_single_rank_contract_and_rooflines():
 
 
 def test_bench_experiment_flags_keep_the_ids():
-    """--encoder-cus (log-mel + encoder on a CU-limited stream, decode on the pass's own stream) and --new-tokens change the
-    schedule / the length, not the transcription: same checksum as the plain run at equal length."""
+    """The schedule and --new-tokens change when work runs / how long a row is, not the transcription: one pass at a time in the
+    same streaming-launch setting gives the checksum of two passes in flight.  The line says which scheduler was timed (the
+    package's, not one of bench.py's own) and on how many hardware queues, and carries the evaluate_model-style run."""
     base = ["--steps", "2", "--warmup", "1", "--model", "tiny", "--batch", "8", "--pipeline", "2", "--no-cpu-baseline"]
     plain = _run(base)
-    limited = _run(base + ["--encoder-cus", "64"])
-    assert limited["config"]["encoder_cus"] == 64 and limited["passes_identical"]
-    assert limited["tokens_checksum"] == plain["tokens_checksum"]
+    assert "whisper_ipa_amd.pipeline.TranscribePipeline" in plain["config"]["schedule"] and plain["config"]["hw_queues"] == 8
+    ev = plain["evaluate_style"]
+    assert ev["unit"] == "audio-s/s" and ev["value"] > 0 and ev["rows_transcribed"] == 8 * ev["batches"] and ev["decode_steps_per_batch"] == 64
+    assert abs(ev["frac_of_value"] - ev["value"] / plain["value"]) < 1e-3
+    serial = _run(["--steps", "2", "--warmup", "1", "--model", "tiny", "--batch", "8", "--pipeline", "1", "--cross-splits", "2", "--no-cpu-baseline"])
+    assert serial["config"]["cross_frame_splits"] == 2 and serial["passes_identical"]
+    assert serial["tokens_checksum"] == plain["tokens_checksum"]
     longer = _run(base + ["--new-tokens", "100"])
     assert longer["config"]["new_tokens"] == 100 and longer["passes_identical"]
     # --phase: the two halves of the pass alone (diagnostic lines that cannot be mistaken for the metric)

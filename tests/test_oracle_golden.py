@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from oracle import whisper_ref as R
+from parity_util import norm64
 
 MICRO = R.ModelDimensions(80, 1500, 128, 2, 2, 51865, 448, 128, 2, 2)
 
@@ -170,7 +171,7 @@ def test_clip_grad_dict_walks_dicts_only_as_the_reference_wrote_it():
     assert walked["decoder"]["blocks"] is tree["decoder"]["blocks"]  # :299-300: the very same list object comes back
     out = R.flatten_params(walked)
     for k, g in flat.items():
-        n0, n1 = float(g.norm()), float(out[k].norm())
+        n0, n1 = norm64(g), norm64(out[k])
         if ".blocks." in k:
             assert torch.equal(out[k], g) and not R.clipped_by_reference(k)
         elif n0 > 1:
@@ -179,7 +180,7 @@ def test_clip_grad_dict_walks_dicts_only_as_the_reference_wrote_it():
             assert torch.equal(out[k], g)
     assert R.clip_gradients(flat, 1.0, "reference").keys() == flat.keys()
     every = R.clip_gradients(flat, 1.0, "all")
-    assert all(float(every[k].norm()) <= 1.0 for k in flat)
+    assert all(norm64(every[k]) <= 1.0 + 1e-7 for k in flat)
     # the product marks the same tensors (what wipa_clip_adamw's seg_clip carries)
     from whisper_ipa_amd.training import clip_reaches
 
@@ -277,7 +278,7 @@ def test_wide_logits_loss_and_decoder_gradients_match_standin(gwide, wide):
         scale = float(np.abs(want).max()) + 1e-12
         assert float(np.abs(got.numpy() - want).max()) / scale < 2e-3, k
         norm = float(gwide[f"{name}_gradnorm__{key}"][0])
-        assert abs(float(g.norm()) - norm) / norm < 1e-3, k
+        assert abs(norm64(g) - norm) / norm < 1e-3, k
 
 
 def test_wide_language_detection_and_greedy_with_fp16_features(gwide, wide):

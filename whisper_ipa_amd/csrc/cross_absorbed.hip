@@ -615,15 +615,17 @@ struct MergeCfg {
     static constexpr int CL = WIPA_MERGE_CL;  // clips per workgroup (1, 2, 4, 8 or 16)
 };
 
-// SINGLE = the round-3 suspect re-built for the root-cause run (WIPA_MERGE_SINGLE=1, tests only): ONE thread computes the split
-// weights of the workgroup's clips into LDS and everybody reads them behind a workgroup barrier, instead of every lane
-// computing its own.  DESIGN.md section 8 records what the ISA and the determinism run showed.
+// Every lane computes the split weights of its own clip from the statistics it loaded itself.  BANNED here (DESIGN.md section
+// 8.1): one thread loading the statistics and computing the weights of the workgroup's clips into LDS for everybody to read
+// behind a barrier -- in this kernel that form gave whole wrong (head, 4-clip) workgroups on bit-identical inputs (round 3 / 4;
+// its seven diagnostic variants and their ISA are in the history at commit 65cd433, the audit in profiles/r05_merge_isa_audit.txt;
+// no mechanism was found, so the form stays out).
 // OUTP (round 4): the cross-attention OUT projection of the head rides in the same launch.  The head's value vector
 // v_h[clip][64] (bf16, with bv: exactly what the plain kernel stores) stays in LDS and is multiplied by Wo[:, h*64 .. h*64+63]^T on
 // MFMA (48 column tiles over the waves, the fragments requested with the first loads of the kernel): slab_h[clip][0..d) in f32,
 // one slab per head at slabs_out + h * slab_stride (head 0 carries the out-projection bias).  The next LayerNorm sums x + the H
 // slabs in head order (deterministic; add_slabs_layernorm takes up to 16).  One launch instead of two per layer.
-template <int D, int SINGLE = 0, bool OUTP = false>
+template <int D, bool OUTP = false>
 __global__ __launch_bounds__(64 * MergeCfg<D>::NWM) void cross_merge_proj_kernel(
     const float* __restrict__ part_m, const float* __restrict__ part_l, const float* __restrict__ part_o, int n_splits,
     const __bf16* __restrict__ wv, const float* __restrict__ bv, __bf16* __restrict__ out, int64_t o_rs, int B,
@@ -635,18 +637,10 @@ __global__ __launch_bounds__(64 * MergeCfg<D>::NWM) void cross_merge_proj_kernel
     constexpr int NTO = D / 16;                       // column tiles of the out projection
     constexpr int NTOW = (NTO + NWM - 1) / NWM;       // per wave (6 for d = 768)
     __shared__ __attribute__((aligned(16))) float red[NWM][CL][64 + 4];
-    __shared__ float dbg_ml[SINGLE == 5 ? CL : 1][8];
-    __shared__ float ws_single[SINGLE ? CL : 1][4];  // SINGLE: 1 = as the compiler builds it (SCALAR loads of the partials), 2 = the
-                                                     // same section with the index laundered through a vector register (VECTOR loads)
     __shared__ __attribute__((aligned(16))) __bf16 vh[OUTP ? CL : 1][64 + 8];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int h = blockIdx.x, b0 = blockIdx.y * CL;
-    if constexpr (SINGLE == 7) {  // poison WITHOUT a barrier: wave 1 marks the weight words at the very start of the kernel; thread 0
-                                  // overwrites them microseconds later (it waits for memory first).  A NaN in the output = a reader
-                                  // that saw the words as they were BEFORE thread 0's write, i.e. a read that overtook the write.
-        if (tid >= 64 && tid < 64 + CL * 4) ws_single[(tid - 64) >> 2][tid & 3] = __builtin_nanf("");
-    }
     // this lane's clip (A rows): only CL of the tile's 16 rows are distinct clips -- the others repeat them (same addresses, one
     // fetch) and their results are dropped; rows past B are clamped the same way
     const int bc = min(b0 + (l15 & (CL - 1)), B - 1);
@@ -692,58 +686,7 @@ __global__ __launch_bounds__(64 * MergeCfg<D>::NWM) void cross_merge_proj_kernel
     // split weights exp(m_s - M) / L: every lane computes them for itself (no shared array, no single-thread section: see the
     // determinism test)
     float ws[4];
-    if constexpr (SINGLE) {
-        if constexpr (SINGLE == 3) {  // poison run: a DIFFERENT wave fills the weights with NaN first; a NaN in the output = a read that
-                                      // overtook thread 0's write
-            if (tid >= 64 && tid < 64 + CL * 4) ws_single[(tid - 64) >> 2][tid & 3] = __builtin_nanf("");
-            __syncthreads();
-        }
-        if (tid == 0) {
-            int launder = 0;
-            if constexpr (SINGLE >= 2) asm volatile("" : "+v"(launder));  // a value the compiler cannot prove uniform: global_load, not s_load
-            for (int cl = 0; cl < CL; ++cl) {
-                const int bq = min(b0 + cl, B - 1) + launder;
-                float mm[4], ll[4], M = NEG_BIG, Lsum = 0.f;
-                for (int s = 0; s < 4; ++s) {
-                    const int sc = min(s, n_splits - 1);
-                    mm[s] = part_m[((int64_t)bq * n_splits + sc) * 16 + h];
-                    ll[s] = part_l[((int64_t)bq * n_splits + sc) * 16 + h];
-                    if (s < n_splits) M = fmaxf(M, mm[s]);
-                }
-                for (int s = 0; s < 4; ++s) {
-                    mm[s] = s < n_splits ? __expf(mm[s] - M) : 0.f;
-                    Lsum += mm[s] * ll[s];
-                }
-                const float inv = 1.0f / Lsum;
-                for (int s = 0; s < 4; ++s) ws_single[cl][s] = mm[s] * inv;
-            }
-        }
-        if constexpr (SINGLE == 5) {  // dump run: thread 0 also records the 16 + 16 statistics it loaded
-            if (tid == 0) {
-                for (int cl = 0; cl < CL; ++cl)
-                    for (int s = 0; s < 4; ++s) {
-                        const int bq = min(b0 + cl, B - 1);
-                        dbg_ml[cl][s] = part_m[((int64_t)bq * n_splits + min(s, n_splits - 1)) * 16 + h];
-                        dbg_ml[cl][4 + s] = part_l[((int64_t)bq * n_splits + min(s, n_splits - 1)) * 16 + h];
-                    }
-            }
-        }
-        if constexpr (SINGLE == 4) {  // an explicit full drain + raw barrier instead of __syncthreads()
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        } else {
-            __syncthreads();
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) ws[s] = ws_single[l15 & (CL - 1)][s];
-        if constexpr (SINGLE == 6) {
-            // the FULL kernel, plus: the weights as EVERY wave's lanes (l15 = clip, lane group 0) got them go to the never-read rows of
-            // the padded heads in part_o (head 12 + wave / 2 of split 0, floats [wave & 1][h][4])
-            if (g == 0 && l15 < CL && b0 + l15 < B) {
-                float* dbg = const_cast<float*>(part_o) + (((int64_t)(b0 + l15) * n_splits + 0) * 16 + 12 + (w >> 1)) * D + (w & 1) * 64 + h * 4;
-                for (int s = 0; s < 4; ++s) dbg[s] = ws[s];
-            }
-        }
-    } else {
+    {
         float M = NEG_BIG;
 #pragma unroll
         for (int s = 0; s < 4; ++s)
@@ -757,29 +700,6 @@ __global__ __launch_bounds__(64 * MergeCfg<D>::NWM) void cross_merge_proj_kernel
         const float inv = 1.0f / Lsum;
 #pragma unroll
         for (int s = 0; s < 4; ++s) ws[s] *= inv;
-    }
-    if constexpr (SINGLE == 5) {
-        // out rows b0 .. b0+3, columns h*64 ..: per clip 32 floats = [ws as lane (wave 3, l15 = cl) read it: 4][ws_single re-read by
-        // thread 0: 4][m: 4][l: 4][zeros]; the kernel then stops (no projection)
-        float* o32 = reinterpret_cast<float*>(out);
-        if (w == 3 && g == 0 && l15 < CL && b0 + l15 < B) {
-            float* dst = o32 + ((int64_t)(b0 + l15) * o_rs + h * 64) / 2;
-            for (int s = 0; s < 4; ++s) dst[s] = ws[s];
-        }
-        __syncthreads();
-        if (tid == 0) {
-            for (int cl = 0; cl < CL; ++cl) {
-                if (b0 + cl >= B) break;
-                float* dst = o32 + ((int64_t)(b0 + cl) * o_rs + h * 64) / 2;
-                for (int s = 0; s < 4; ++s) {
-                    dst[4 + s] = ws_single[cl][s];
-                    dst[8 + s] = dbg_ml[cl][s];
-                    dst[12 + s] = dbg_ml[cl][4 + s];
-                }
-                for (int s = 16; s < 32; ++s) dst[s] = 0.f;
-            }
-        }
-        return;
     }
     f32x4 acc[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -1029,12 +949,6 @@ int launch_attn(const AbsParams& p_in, int B, hipStream_t s) {
 
 }  // namespace
 
-// the single-thread-section variants of the merge kernel (root-cause runs of round 4; -DWIPA_MERGE_VARIANTS builds only)
-[[maybe_unused]] static int merge_single() {
-    static const int v = [] { const char* e = getenv("WIPA_MERGE_SINGLE"); return e ? atoi(e) : 0; }();
-    return v;
-}
-
 // Frame splits per clip: a clip's result must not depend on the batch it rides in (the partition of the frames fixes the order of
 // the softmax merges), so the count is a property of the CALL, never of B.  FOUR by default: a workgroup streams 375 frames at the
 // same per-CU rate whether 1 or 256 clips are decoded, and 64 clips x 4 splits are exactly one round on the 256 CUs (the kernel
@@ -1151,26 +1065,12 @@ extern "C" int wipa_cross_absorbed_attention(const void* q, int64_t q_row_stride
     int rc = WIPA_OK;
     const char* st_env = getenv("WIPA_ABS_STAGES");  // debugging: bit 0 absorb-q, bit 1 stream, bit 2 merge (default all)
     const int stages = st_env ? atoi(st_env) : 7;
-    // The root-cause variants of the merge kernel exist only in a build with -DWIPA_MERGE_VARIANTS
-    // (WIPA_EXTRA_HIPCC_FLAGS=-DWIPA_MERGE_VARIANTS python -c "import __graft_entry__ as g; g.build(force=True)"); WIPA_MERGE_SINGLE=1..7
-    // then selects one.  The shipped library has the every-lane kernel only.
-#ifdef WIPA_MERGE_VARIANTS
-#define ABS_MERGE_ONE(D, V)                                                                                                                \
-    if (merge_single() == V)                                                                                                               \
-        hipLaunchKernelGGL((cross_merge_proj_kernel<D, V>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o, S,             \
-                           (const __bf16*)wv, bv, (__bf16*)out, out_row_stride, B);                                                        \
-    else
-#define ABS_MERGE_VARIANTS(D) ABS_MERGE_ONE(D, 1) ABS_MERGE_ONE(D, 2) ABS_MERGE_ONE(D, 3) ABS_MERGE_ONE(D, 4) ABS_MERGE_ONE(D, 5) ABS_MERGE_ONE(D, 6) ABS_MERGE_ONE(D, 7)
-#else
-#define ABS_MERGE_VARIANTS(D)
-#endif
 #define ABS_RUN(D)                                                                                                                         \
     do {                                                                                                                                   \
         if (stages & 1)                                                                                                                    \
             hipLaunchKernelGGL((cross_absorb_q_kernel<D>), gq, dim3(64), 0, s, (const __bf16*)q, q_row_stride, (const __bf16*)wkT, qp, B, H, k_scale); \
         if (stages & 2) rc = launch_attn<D>(p, B, s);                                                                                      \
         if (rc == WIPA_OK && (stages & 4)) {                                                                                               \
-            ABS_MERGE_VARIANTS(D)                                                                                                          \
             hipLaunchKernelGGL((cross_merge_proj_kernel<D>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o, S,            \
                                (const __bf16*)wv, bv, (__bf16*)out, out_row_stride, B);                                                    \
         }                                                                                                                                  \
@@ -1180,7 +1080,6 @@ extern "C" int wipa_cross_absorbed_attention(const void* q, int64_t q_row_stride
     else if (d == 768) ABS_RUN(768);
     else ABS_RUN(1024);
 #undef ABS_RUN
-#undef ABS_MERGE_VARIANTS
     if (rc != WIPA_OK) return rc;
     WIPA_LAUNCH_CHECK();
     return WIPA_OK;
@@ -1251,7 +1150,7 @@ static int absorbed_block(const wipa_cross_block_desc* c, const void* wkT, const
         else hipLaunchKernelGGL((cross_absorb_prologue_kernel<D, 16>), gp, dim3(512), 0, s, q);                                            \
         rc = launch_attn<D>(p, B, s);                                                                                                      \
         if (rc == WIPA_OK && wo)                                                                                                           \
-            hipLaunchKernelGGL((cross_merge_proj_kernel<D, 0, true>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o,  \
+            hipLaunchKernelGGL((cross_merge_proj_kernel<D, true>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o,  \
                                S, (const __bf16*)wv, bv, (__bf16*)nullptr, (int64_t)d, B, (const __bf16*)wo, bo, slabs_out, slab_stride);  \
         else if (rc == WIPA_OK)                                                                                                            \
             hipLaunchKernelGGL((cross_merge_proj_kernel<D>), gm, dim3(64 * MergeCfg<D>::NWM), 0, s, part_m, part_l, part_o, S,             \
