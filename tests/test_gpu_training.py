@@ -180,7 +180,7 @@ def test_clip_adamw_kernel_exact(clip_scope):
             assert float(tr.coef[tr.names.index(n)]) == 1.0 and torch.equal(tr.g(n).cpu(), raw[n][0])
             n64 = norm64(raw[n][0])  # the kernel's f32 norm against the float64 one
             print(f"\n{n}: kernel norm {float(tr.norms[tr.names.index(n)]):.7f}, float64 {n64:.7f}, relative {abs(float(tr.norms[tr.names.index(n)]) - n64) / n64:.2e}")
-            assert abs(float(tr.norms[tr.names.index(n)]) - n64) < 1e-4 * n64
+            assert abs(float(tr.norms[tr.names.index(n)]) - n64) < 1e-6 * n64  # measured r05: <= 5.4e-8
         else:
             assert float(tr.coef[tr.names.index(n)]) < 1.0
     for n in tr.names:
