@@ -276,7 +276,7 @@ def _init_distributed():
 
 def train(model_name: str, train_data_path: str, test_data_path: str, output_dir: str, num_steps: int = 1000,
           batch_size: int = 4, learning_rate: float = 1e-5, validate_every: int = 100, save_every: int = 500,
-          test_run: bool = False, audio_root: str = "", seed: Optional[int] = None, fast_f32: bool = False,
+          test_run: bool = False, audio_root: str = "", seed: Optional[int] = None, exact_f32: bool = False,
           allow_byte_fallback: bool = False, cache_encoder_features: bool = True, feature_cache_clips: Optional[int] = None,
           clip_scope: str = "reference"):
     rank, world = _init_distributed()
@@ -292,7 +292,7 @@ def train(model_name: str, train_data_path: str, test_data_path: str, output_dir
         args_dict = {"model_name": model_name, "train_data_path": train_data_path, "test_data_path": test_data_path,
                      "num_steps": num_steps, "batch_size": batch_size, "learning_rate": learning_rate,
                      "validate_every": validate_every, "save_every": save_every, "test_run": test_run,
-                     "world_size": world, "f32_products": "split" if fast_f32 else "exact",
+                     "world_size": world, "f32_products": "exact" if exact_f32 else "split",
                      "cache_encoder_features": bool(cache_encoder_features), "clip_scope": clip_scope}
         save_training_config(output_dir, args_dict, get_hardware_info())
     logger = TrainingLogger(output_dir) if main else None
@@ -304,7 +304,7 @@ def train(model_name: str, train_data_path: str, test_data_path: str, output_dir
     freeze_encoder(model)
     # mlx AdamW defaults (reference :513); the clip reaches what the reference's clip_grad_dict reaches (:287-303: dicts only,
     # the decoder.blocks list passes through) unless --clip-scope all
-    trainer = DecoderTrainer(model, lr=learning_rate, f32_split=fast_f32, clip_scope=clip_scope)
+    trainer = DecoderTrainer(model, lr=learning_rate, f32_split=not exact_f32, clip_scope=clip_scope)
     n_mels = 128 if "large" in model_name else 80  # reference :517
     if model.dims.n_mels != n_mels:
         n_mels = model.dims.n_mels
@@ -432,9 +432,11 @@ def main():
     p.add_argument("--save-every", type=int, default=1000, help="Save checkpoint every N steps")
     p.add_argument("--test-run", action="store_true", help="Test run with only 100 samples")
     p.add_argument("--audio-root", type=str, default="", help="prefix for the relative audio_path entries of the JSON")
-    p.add_argument("--fast-f32", action="store_true",
-                   help="take the float32 products of the large GEMMs as split-bf16 MFMA terms (~2x faster, ~5e-6 relative); "
-                        "default: exact f32 products, as the reference trains")
+    p.add_argument("--exact-f32", action="store_true",
+                   help="exact f32 products on the f32 MFMA in the large GEMMs, as the reference trains (145 against 87 ms per 32-clip "
+                        "step); default since round 5: three split-bf16 MFMA terms per product (~5e-6 relative; loss within 1e-5 and "
+                        "every decoder gradient within 3e-5 of the float32 CPU checker)")
+    p.add_argument("--fast-f32", action="store_true", help="accepted for round-4 command lines: split products are the default now")
     p.add_argument("--no-cache-encoder-features", action="store_true",
                    help="recompute the frozen encoder for every clip of every step, as the reference does (default: keep each "
                         "clip's encoder output in HBM after its first use -- bit-identical results, about half the step time)")
@@ -451,7 +453,7 @@ def main():
     a = p.parse_args()
     train(model_name=a.model, train_data_path=a.train_data, test_data_path=a.test_data, output_dir=a.output_dir,
           num_steps=a.steps, batch_size=a.batch_size, learning_rate=a.lr, validate_every=a.validate_every,
-          save_every=a.save_every, test_run=a.test_run, audio_root=a.audio_root, fast_f32=a.fast_f32,
+          save_every=a.save_every, test_run=a.test_run, audio_root=a.audio_root, exact_f32=a.exact_f32,
           allow_byte_fallback=a.allow_byte_fallback, cache_encoder_features=not a.no_cache_encoder_features,
           feature_cache_clips=a.feature_cache_clips, clip_scope=a.clip_scope)
 

@@ -142,7 +142,7 @@ def clip_reaches(name: str, scope: str = "reference") -> bool:
 class DecoderTrainer:
     def __init__(self, model: Whisper, lr: float = 1e-5, max_grad_norm: float = 1.0, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.01, f32_split: Optional[bool] = None, clip_scope: str = "reference"):
-        """``f32_split`` (default: the model's setting, i.e. off): split-bf16 products in the large GEMMs of the step.
+        """``f32_split`` (default: the model's setting -- on unless the model was built with f32_split=False): split-bf16 products in the large GEMMs of the step.
         ``clip_scope``: which tensors the per-tensor clip reaches.  ``"reference"`` (default) is ``clip_grad_dict`` as the
         reference wrote it (train_whisper_ipa.py:287-303): it recurses through dict values only, so the ``decoder.blocks``
         LIST is passed through (:299-300) and only ``token_embedding.weight``, ``positional_embedding`` and ``ln.*`` are
