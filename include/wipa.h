@@ -428,8 +428,10 @@ typedef struct wipa_model_cfg {
                                  * cached K / V (every other configuration). */
     int32_t dec_cross_splits; /* dec_cross_absorbed = 1: frame splits per clip of the decode step's streaming launch
                                * (wipa_cross_block_desc.cross_splits): 0 = default (4: shortest lone step), 2 = half-chip launches
-                               * for callers that keep several passes in flight on one GPU.  Part of the step graph's key; the
-                               * prompt prefill (wipa_cross_absorbed_attention) always uses the default. */
+                               * for callers that keep several passes in flight on one GPU (whisper_ipa_amd.pipeline sets it).
+                               * Part of the step graph's and the prefill graph's key: wipa_decoder_prefill and wipa_decoder_run
+                               * use the SAME count, so a prompt pass followed by steps rounds as the steps alone do
+                               * (tests/test_gpu_model.py::test_prompt_prefill_equals_stepwise_prompt_absorbed). */
 } wipa_model_cfg;
 
 /* Encoder weight table (const void* [WIPA_ENC_GLOBAL + WIPA_ENC_PER_LAYER * n_layer]):

@@ -143,7 +143,9 @@ def value_and_grad(model, loss_fn):
     """``nn.value_and_grad(model, loss_fn)`` of the reference (:284) for a model whose decoder a DecoderTrainer owns: returns
     ``fn(model, batch, tokenizer) -> (loss, grads)`` with ``grads`` the nested dict of the TRAINABLE (decoder) tensors in
     mlx_whisper's names -- what ``clip_grad_dict`` (:287-303) walks.  The gradients are also left in the trainer's flat
-    buffer, so ``trainer.apply_update()`` (per-tensor clip + AdamW) can follow directly."""
+    buffer, so ``trainer.apply_update()`` (per-tensor clip + AdamW) can follow directly.  Inside ``fn`` -- and only there --
+    ``model.logits`` is the differentiable call (DecoderTrainer.differentiable_scope).  The flat gradient buffer is OVERWRITTEN
+    (nothing accumulates onto what loss_and_grads left there), and the backward reduces over no process group: single process."""
     trainer = getattr(model, "_trainer", None)
     if trainer is None:
         raise RuntimeError("value_and_grad: create a whisper_ipa_amd.training.DecoderTrainer(model) first (it owns the decoder tensors)")
@@ -155,9 +157,14 @@ def value_and_grad(model, loss_fn):
         leaves = trainer.leaves()
         for t in leaves.values():
             t.grad = None
-        with torch.enable_grad(), on_stream():
-            loss = loss_fn(model, batch, tokenizer)
-            loss.backward()
+        trainer.differentiable_scope = True  # model.logits inside loss_fn is the differentiable call, as under nn.value_and_grad
+        try:
+            with torch.enable_grad(), on_stream():
+                loss = loss_fn(model, batch, tokenizer)
+                loss.backward()
+        finally:
+            trainer.differentiable_scope = False
+        with on_stream():
             for n, t in leaves.items():  # the flat buffer holds d(logits-path) only if the loss used other leaves too: copy .grad
                 trainer.g(n).copy_(t.grad if t.grad is not None else torch.zeros_like(t))
         return loss.detach(), _unflatten({n: trainer.g(n) for n in trainer.names})

@@ -437,6 +437,34 @@ def test_cross_splits_is_a_model_setting_that_keeps_graph_eager_and_batch_invari
     assert _lib.lib().wipa_decoder_layout(C.byref(cached), 4, C.byref(_lib.DecLayout())) != 0
 
 
+@pytest.mark.parametrize("cross_splits", [0, 2])
+def test_prompt_prefill_equals_stepwise_prompt_absorbed(small2, monkeypatch, cross_splits):
+    """wipa_decoder_prefill and wipa_decoder_run take the SAME frame-split count from wipa_model_cfg.dec_cross_splits
+    (include/wipa.h), so on the absorbed form (whisper-small width, bf16) the batched prompt pass followed by steps gives the
+    ids of the position-by-position prompt in the library default AND in the several-passes-in-flight setting (2 splits);
+    the step logits after the prompt agree to bf16 rounding (the prompt pass batches 4 positions into one GEMM)."""
+    from whisper_ipa_amd.decoding import greedy_decode_tokens
+
+    W, mels, xa = small2
+    sp = R.SpecialTokens.multilingual()
+    always, first = R.suppress_lists(sp)
+    init = list(sp.sot_sequence_including_notimestamps(0))
+    m = _model(SMALL2, W, torch.bfloat16, cross_attention="absorbed")
+    m.cross_splits = cross_splits
+    feats = xa.cuda().to(torch.bfloat16)
+    a = greedy_decode_tokens(m, feats, init, always, first, sp.eot, max_new_tokens=16, stop_on_eot=False)
+    la = a.last_logits.float().cpu().clone()
+    monkeypatch.setenv("WIPA_NO_PREFILL", "1")
+    b = greedy_decode_tokens(m, feats, init, always, first, sp.eot, max_new_tokens=16, stop_on_eot=False)
+    lb = b.last_logits.float().cpu().clone()
+    monkeypatch.delenv("WIPA_NO_PREFILL")
+    assert (a.tokens == b.tokens).all(), (cross_splits, a.tokens.tolist(), b.tokens.tolist())
+    fin = torch.isfinite(la) & torch.isfinite(lb)
+    diff, spread = (la - lb)[fin].abs().max().item(), lb[fin].std().item()
+    print(f"\nprefill + steps vs stepwise prompt, absorbed, cross_splits {cross_splits}: last-step logits differ by {diff:.4f} = {diff / spread:.4f} of their std")
+    assert diff < 0.03 * spread, (diff, spread)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("mode", ["0", "1", "2"])
 def test_decode_never_reads_unwritten_state(micro, monkeypatch, dtype, mode):

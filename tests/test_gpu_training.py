@@ -294,7 +294,8 @@ def test_model_logits_is_differentiable_and_the_scripts_value_and_grad_matches_l
     (nn.value_and_grad).  (a) the script's compute_loss -- torch ops on model.logits -- through value_and_grad gives the loss
     and EVERY decoder gradient of DecoderTrainer.loss_and_grads (same HIP forward / backward, the CE in torch instead of the
     fused kernels) and of the oracle's autograd; (b) a MODIFIED loss (label smoothing 0.1, which the fused path cannot
-    express) matches the oracle's autograd of the same loss; (c) under no_grad the call is the forward-only pass."""
+    express) matches the oracle's autograd of the same loss; (c) outside value_and_grad the call is the forward-only pass, with
+    or without grad mode, unless ``differentiable=True`` asks."""
     import os
     import sys
     import types
@@ -347,9 +348,16 @@ def test_model_logits_is_differentiable_and_the_scripts_value_and_grad_matches_l
     with torch.no_grad():
         plain = m.logits(tokens[:, :-1].cuda(), xa.cuda())
     assert plain.grad_fn is None and (plain.cpu() - lg_ref.detach()).abs().max() < 1e-3
-    with torch.enable_grad():
-        diff = m.logits(tokens[:, :-1].cuda(), xa.cuda())
+    with torch.enable_grad():  # grad mode alone (torch's default) does NOT switch the path -- only value_and_grad's scope
+        still_plain = m.logits(tokens[:, :-1].cuda(), xa.cuda())  # or the explicit flag do
+        diff = m.logits(tokens[:, :-1].cuda(), xa.cuda(), differentiable=True)
+    assert still_plain.grad_fn is None and torch.equal(still_plain, plain)
     assert diff.grad_fn is not None and (diff.detach() - plain).abs().max() < 1e-3
+    assert tr.differentiable_scope is False  # value_and_grad left its scope
+    bf = Whisper(ModelDimensions(**MICRO.__dict__), dtype=torch.bfloat16)
+    bf.load_weights(W)
+    with pytest.raises(Exception):
+        bf.logits(tokens[:, :-1].cuda(), xa.cuda(), differentiable=True)  # no trainer, not float32: refused, not silently plain
 
 
 def test_train_script_end_to_end_artefacts(tmp_path, capsys):

@@ -448,7 +448,9 @@ __global__ __launch_bounds__(GS_THREADS) void greedy_tail_kernel(TailParams q) {
     __shared__ float s_red[4];
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int p = *q.pos;
+    // volatile: ONE load per thread at the kernel's start, never re-materialised by the compiler after the barrier below -- the
+    // last workgroup to arrive overwrites *q.pos while slower workgroups are still between their barrier and their exit
+    const int p = *(volatile const int32_t*)q.pos;
     const int V = q.V;
     // `next` is computed by EVERY thread from values all of them hold (no single-thread section that hands a value to the
     // workgroup through LDS: the pattern whose merge-kernel instance misbehaved); thread 0 alone writes
@@ -543,7 +545,9 @@ __global__ __launch_bounds__(GS_THREADS) void greedy_tail_kernel(TailParams q) {
     row_embed_layernorm<TO>(tid, next, min(p + 1, q.n_ctx - 1), q.emb, q.emb_dtype, q.emb_scale, q.pos_emb, q.x + (int64_t)b * q.D, q.ln_w,
                             q.ln_b, (TO*)q.y + (int64_t)b * q.D, q.D, q.eps, s_red);
     // position advance by the LAST workgroup: every thread of every workgroup read *pos at its start and has used it before
-    // its workgroup's barrier above, i.e. before its counter increment -- no workgroup can still see the old position late
+    // its workgroup's barrier above, i.e. before its counter increment -- no workgroup can still see the old position late.
+    // Needs *done_counter == 0 at launch and one launch in flight per state blob: wipa_decoder_run / _prefill zero the counter
+    // at the start of every call (a launch that died mid-grid must not leave later calls without a position advance)
     if (tid == 0) {
         const int arrived = atomicAdd(q.done_counter, 1);  // counts arrivals only: what the step wrote reaches the next launch at the kernel boundary
         if (arrived == (int)gridDim.x - 1) {

@@ -948,6 +948,8 @@ extern "C" int wipa_decoder_run(const wipa_model_cfg* cfg, const void* const* w,
     hipStream_t s = (hipStream_t)stream;
     RT_CALL(init_before_capture(cfg));
     if (n_steps == 0) return WIPA_OK;
+    // the greedy tail's arrival counter starts every call at zero (4 bytes, outside the step graph)
+    WIPA_CHECK_HIP(hipMemsetAsync(done_counter_of(st, L), 0, sizeof(int32_t), s));
     // the first step's input rows (embedding + first LayerNorm of the token at the current position): every later step gets
     // them from the previous step's last launch.  Outside the graph: once per call, whatever wrote the token (the greedy
     // update, the prompt, a forced history)
@@ -1026,6 +1028,7 @@ extern "C" int wipa_decoder_prefill(const wipa_model_cfg* cfg, const void* const
     };
     hipStream_t s = (hipStream_t)stream;
     RT_CALL(init_before_capture(cfg));
+    WIPA_CHECK_HIP(hipMemsetAsync(done_counter_of(st, L), 0, sizeof(int32_t), s));  // as wipa_decoder_run: the tail's counter starts at zero
     if (!use_graph || s == nullptr || !graphs_allowed()) return enqueue();
     hipGraphExec_t exec = nullptr;
     const GraphKey key(state, (const void*)w, (const void*)mask_first, (const void*)mask_always, B, n_init, eot, cfg->dtype * 2 + t_f32_split + 4 * decode_mode(cfg, B) + 16 * cfg->dec_w_dtype + 64 * cfg->dec_cross_absorbed * (absorbed_block_fused() ? 2 : 1) + 256 * (int)tail_fused() + 512 * (int)absorbed_merge_out() + 1024 * cfg->dec_cross_splits + 8192 * (int)(!use_fused_step(cfg, B) && logits_fused(cfg, B)), cfg->weights_generation, 1);

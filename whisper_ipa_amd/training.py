@@ -539,9 +539,18 @@ class DecoderTrainer:
             self._leaves = {n: self.p(n).detach().requires_grad_(True) for n in self.names}
         return self._leaves
 
+    differentiable_scope = False  # True inside value_and_grad(model, loss_fn): Whisper.logits then returns differentiable logits
+
     def differentiable_logits(self, tokens: torch.Tensor, audio_features: torch.Tensor) -> torch.Tensor:
         """logits [B, T, V] f32 with a grad_fn: the HIP forward of loss_and_grads, its hand-written backward behind
-        torch.autograd.Function, so ANY torch-written loss on the logits gets exact decoder gradients."""
+        torch.autograd.Function, so ANY torch-written loss on the logits gets exact decoder gradients.  The backward WRITES
+        self.flat_g (zeroed first: gradients accumulated there by loss_and_grads are lost) and returns clones of every decoder
+        gradient as the leaves' .grad (one more copy of the decoder's size); it reduces over no process group."""
+        from . import parallel
+
+        if parallel.world()[1] != 1:
+            raise _lib.WipaError("differentiable_logits is single-process (its backward runs without the data-parallel group); "
+                                 "use DecoderTrainer.train_step / loss_and_grads(group=...) under torch.distributed")
         leaves = self.leaves()
         return _DecoderLogits.apply(self, tokens, audio_features, *[leaves[n] for n in self.names])
 

@@ -517,15 +517,25 @@ class Whisper:
         return self.encode_padded(padded, B)
 
     # ---- teacher-forced decoder ----------------------------------------------------
-    def logits(self, tokens: torch.Tensor, audio_features: torch.Tensor) -> torch.Tensor:
+    def logits(self, tokens: torch.Tensor, audio_features: torch.Tensor, differentiable: Optional[bool] = None) -> torch.Tensor:
         """tokens [B,T] int, features [B,1500,d] -> logits [B,T,V] f32 (train_whisper_ipa.py:232).
 
-        DIFFERENTIABLE w.r.t. the decoder tensors when a ``DecoderTrainer`` owns the model's decoder
-        parameters and torch's grad mode is on: the call then goes through ``training._DecoderLogits`` (HIP forward with
-        saved activations, hand-written HIP backward) and ``loss.backward()`` on ANY torch-written loss fills the ``.grad`` of
-        ``trainer.leaves()``.  Under ``torch.no_grad()`` -- inference, validation -- it is the forward-only C++ pass."""
+        By default the forward-only C++ pass over the packed tables -- also in torch's (default-on) grad mode: an evaluation
+        caller outside ``torch.no_grad()`` gets no saved-activation forward and no grad_fn behind its back.
+        DIFFERENTIABLE w.r.t. the decoder tensors in exactly two cases, both needing a float32 model whose
+        decoder parameters a ``DecoderTrainer`` owns: (1) inside ``value_and_grad(model, loss_fn)`` of
+        scripts/train_whisper_ipa.py -- the reference's ``nn.value_and_grad`` (:284) is what makes ITS model call
+        differentiable, so a loss function written like the reference's needs no change; (2) ``differentiable=True``.  The call
+        then goes through ``training._DecoderLogits`` (HIP forward with saved activations, hand-written HIP backward) and
+        ``loss.backward()`` on ANY torch-written loss fills the ``.grad`` of ``trainer.leaves()``.  NOTE: that backward
+        OVERWRITES the trainer's flat gradient buffer (it does not accumulate onto gradients left there by
+        ``loss_and_grads``) and runs without a data-parallel group: single-process use; the DP step is ``train_step``."""
         tr = getattr(self, "_trainer", None)
-        if tr is not None and torch.is_grad_enabled() and self.dtype == torch.float32:
+        if differentiable is None:
+            differentiable = tr is not None and tr.differentiable_scope and torch.is_grad_enabled()
+        if differentiable:
+            if tr is None or self.dtype != torch.float32:
+                raise _lib.WipaError("Whisper.logits(differentiable=True) needs a float32 model and a DecoderTrainer(model) owning its decoder")
             return tr.differentiable_logits(tokens, audio_features)
         L = _lib.lib()
         pk = self.packed(teacher_forced=True)
