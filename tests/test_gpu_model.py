@@ -1007,6 +1007,20 @@ def test_transcribe_batches_early_stop_language_detection_and_order_match_decode
                     assert max(abs(a.language_probs[k] - b.language_probs[k]) for k in b.language_probs) < 1e-5
             lens.add(r.n_steps)
         assert len(lens) > 1 and min(lens) < 40, lens  # the passes did stop early, at different lengths
+    # decode groups (G consecutive batches decode as one chain of rows): every batch still gets the result it gets alone --
+    # its own early-stop length included -- with full and partial groups, with and without language detection
+    for language in ("en", None):
+        opts = wipa.DecodingOptions(language=language, without_timestamps=True, fp16=False, suppress_tokens=suppress, suppress_blank=False,
+                                    sample_len=40)
+        want = [wipa.decode(m, b.cuda(), opts) for b in batches]
+        for G, P in ((2, 2), (3, 1), (4, 2)):
+            got = list(wipa.transcribe_batches(m, batches, opts, passes_in_flight=P, check_every=3, decode_group=G))
+            assert [r.index for r in got] == list(range(len(batches))), (G, P)
+            for r, w in zip(got, want):
+                assert [x.tokens for x in r.results] == [x.tokens for x in w] and [x.language for x in r.results] == [x.language for x in w]
+                assert max(abs(a.avg_logprob - b.avg_logprob) for a, b in zip(r.results, w)) < 1e-4
+                alone = [len(x.tokens) for x in w]
+                assert r.n_steps <= 40 and (r.n_steps == 40 or r.n_steps == max(alone) + 1), (G, P, r.n_steps, alone)
     # the serial schedule and a prefetching iterator give the same
     opts = wipa.DecodingOptions(language="en", without_timestamps=True, fp16=False, suppress_tokens=suppress, suppress_blank=False, sample_len=40)
     a = [r.rows() for r in wipa.transcribe_batches(m, batches, opts, passes_in_flight=1)]
@@ -1061,6 +1075,8 @@ def test_transcribe_batches_320_clips_ids_identical_to_the_serial_path():
     assert all((g == w).all() for g, w in zip(armed, want))
     from_host = [r.tokens for r in transcribe_batches(m, host[:2], opts, passes_in_flight=2, max_new_tokens=n_new, stop_on_eot=False)]
     assert all((g == w).all() for g, w in zip(from_host, want))
+    grouped = [r.tokens for r in transcribe_batches(m, dev, opts, passes_in_flight=2, max_new_tokens=n_new, stop_on_eot=False, decode_group=2)]
+    assert len(grouped) == 5 and all((g == w).all() for g, w in zip(grouped, want))  # 128-row chains (and a last group of one batch)
     one = [r.tokens for r in transcribe_batches(m, dev[:2], opts, passes_in_flight=1, max_new_tokens=n_new, stop_on_eot=False)]
     dflt = serial(0)
     assert all((g == w).all() for g, w in zip(one, dflt))  # one batch at a time: the model's own setting

@@ -19,6 +19,13 @@ What the schedule sets, so that callers need not:
     starts, so the package sets it at import when nothing has initialised the GPU yet (``runtime.request_hw_queues``) and
     this module WARNS when it finds fewer than 8 in effect.
 
+Decode groups (``decode_group=G``, default 1 = off): the batches still go through log-mel and the encoder one by one, but the
+rows of G consecutive batches then decode as ONE chain of G x B rows -- fewer, fatter dependent-launch chains on the GPU (four
+chains active at once cost every chain ~2.6 x its launch gaps, profiles/r05_decode_gaps.txt) and the decoder weights streamed
+once per step for the group.  A clip's ids do not depend on the rows it decodes beside (every kernel is batch-invariant), so
+the results are those of G = 1; what changes is WHEN: the first batch of a group waits for the group's last encoder.
+``passes_in_flight`` then counts groups.
+
 Early stop: the reference's loop ends at the first step after which every row has emitted EOT.  Here the steps of a pass are
 enqueued in chunks of ``check_every``; after each chunk the last token column is copied to pinned host memory behind an
 event, and the host -- which is never blocked on one pass while another has room for work -- stops enqueueing for a pass once
@@ -120,6 +127,8 @@ class _Pass:
     lang_tok: Optional[torch.Tensor] = None
     lang_logits: Optional[torch.Tensor] = None
     keep: tuple = ()
+    sizes: tuple = ()      # clips of every batch of the decode group, in input order (sum = B)
+    indices: tuple = ()    # their positions in the input sequence
 
     @property
     def may_enqueue(self) -> bool:
@@ -158,7 +167,7 @@ class TranscribePipeline:
 
     def __init__(self, model, options: Optional[DecodingOptions] = None, passes_in_flight: int = 4, *,
                  max_new_tokens: Optional[int] = None, stop_on_eot: bool = True, check_every: int = 8,
-                 cross_splits: Optional[int] = None, use_graph: bool = True):
+                 cross_splits: Optional[int] = None, use_graph: bool = True, decode_group: int = 1):
         options = options or DecodingOptions(language="en", without_timestamps=True)
         if options.beam_size or (options.best_of or 1) > 1 or options.temperature != 0.0:
             raise NotImplementedError("the reference only ever runs greedy decode (SURVEY.md section 0)")
@@ -166,6 +175,10 @@ class TranscribePipeline:
             raise NotImplementedError("timestamp rules are not on the reference's path (without_timestamps=True everywhere)")
         if passes_in_flight < 1:
             raise _lib.WipaError(f"passes_in_flight must be >= 1, got {passes_in_flight}")
+        if decode_group < 1:
+            raise _lib.WipaError(f"decode_group must be >= 1, got {decode_group}")
+        self.G = int(decode_group)
+        self.pending: list = []   # (batch, index) waiting for their decode group to fill
         self.model, self.options, self.P = model, options, int(passes_in_flight)
         self.stop_on_eot, self.check_every, self.use_graph = bool(stop_on_eot), max(1, int(check_every)), bool(use_graph)
         d = model.dims
@@ -183,7 +196,8 @@ class TranscribePipeline:
         self._splits = (PIPELINE_CROSS_SPLITS if self.P >= 2 else model.cross_splits) if cross_splits is None else int(cross_splits)
         self._splits_before: Optional[int] = None
         self.inflight: Deque[_Pass] = deque()
-        self.submitted = 0
+        self.submitted = 0   # batches handed over
+        self.launched = 0    # passes (batches, or decode groups) enqueued
         self.hw_queues = hw_queues()
         if self.P >= 2 and self.hw_queues < PIPELINE_HW_QUEUES:
             warnings.warn(f"whisper_ipa_amd: {self.P} passes in flight on {self.hw_queues} hardware queues (GPU_MAX_HW_QUEUES); "
@@ -251,14 +265,18 @@ class TranscribePipeline:
                 ev.record(p.stream)
                 p.probes.append(_Probe(ev, col, p.enqueued))
 
-    def _launch(self, batch, index: int, slot: int) -> _Pass:
+    def _launch(self, group, slot: int) -> _Pass:
+        """``group``: [(batch, index), ...] -- one batch, or the batches of a decode group"""
         L = _lib.lib()
         m = self.model
         cur = torch.cuda.current_stream()
         with use_stream(slot) as s:
             if cur != s:
                 s.wait_stream(cur)  # the batch may have been produced on the caller's stream
-            feats = self._features(batch)
+            parts = [self._features(b) for b, _ in group]  # log-mel + encoder per batch, as without groups
+            sizes = tuple(int(f.shape[0]) for f in parts)
+            feats = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)  # the group's rows decode as one chain
+            del parts
             B = feats.shape[0]
             n_init = len(self.initial)
             total = (n_init - 1) + self.max_new
@@ -286,8 +304,8 @@ class TranscribePipeline:
             _lib.check(L.wipa_decoder_begin(cfg, blob, nb, B, init, n_init, sptr(s)), "wipa_decoder_begin")
             if lang_tok is not None:
                 st.tokens[:, 1].copy_(lang_tok)
-            p = _Pass(index, slot, s, st, pk, B, n_init, total, 0, (m_always, m_first), feats, int(self.tok.eot),
-                      lang_tok=lang_tok, lang_logits=lang_logits, keep=tuple(keep))
+            p = _Pass(group[0][1], slot, s, st, pk, B, n_init, total, 0, (m_always, m_first), feats, int(self.tok.eot),
+                      lang_tok=lang_tok, lang_logits=lang_logits, keep=tuple(keep), sizes=sizes, indices=tuple(i for _, i in group))
             if _use_prefill(n_init, total):  # the prompt positions and the first new token in one batched pass
                 _lib.check(L.wipa_decoder_prefill(cfg, tab, blob, nb, B, n_init, p.eot, ptr(m_first), ptr(m_always), int(self.use_graph),
                                                   sptr(s)), "wipa_decoder_prefill")
@@ -313,7 +331,7 @@ class TranscribePipeline:
         for p in self.inflight:
             self._advance(p)
 
-    def _collect(self, p: _Pass) -> PassResult:
+    def _collect(self, p: _Pass) -> List[PassResult]:
         """``p`` has left ``self.inflight``: drive it to its end (the younger passes keep their chunks topped up meanwhile)"""
         while self.stop_on_eot:
             self._advance(p)
@@ -327,46 +345,65 @@ class TranscribePipeline:
             lang_tok = p.lang_tok.cpu().numpy() if p.lang_tok is not None else None
             lang_logits = p.lang_logits.cpu() if p.lang_logits is not None else None
         p.stream.synchronize()
-        n_steps = p.enqueued - (p.n_init - 1)
-        if self.stop_on_eot:
-            # the reference stops at the first step after which every row ends in EOT (as decoding.greedy_decode_tokens)
-            all_eot = (toks[:, p.n_init:] == p.eot).all(axis=0)
-            if all_eot.any():
-                n_steps = int(np.argmax(all_eot)) + 1
-                toks = toks[:, : p.n_init + n_steps]
-        languages = [self.options.language or "en"] * p.B
-        probs: List[Optional[dict]] = [None] * p.B
+        languages_all = [self.options.language or "en"] * p.B
+        probs_all: List[Optional[dict]] = [None] * p.B
         if lang_tok is not None:
-            languages = [LANGUAGES[int(t) - self.tok.sot - 1] for t in lang_tok]
+            languages_all = [LANGUAGES[int(t) - self.tok.sot - 1] for t in lang_tok]
             pr = torch.softmax(lang_logits, dim=-1).numpy()
-            probs = [dict(zip(LANGUAGES[: self.tok.num_languages], row.tolist())) for row in pr]
-        return PassResult(toks, p.n_init, n_steps, slp, languages, probs, p.feats, index=p.index, _tok=self.tok, _eot=p.eot,
-                          _temperature=self.options.temperature)
+            probs_all = [dict(zip(LANGUAGES[: self.tok.num_languages], row.tolist())) for row in pr]
+        out, r0 = [], 0
+        for size, index in zip(p.sizes, p.indices):  # every batch of a decode group gets the result it gets alone
+            t = toks[r0:r0 + size]
+            n_steps = p.enqueued - (p.n_init - 1)
+            if self.stop_on_eot:
+                # the reference stops at the first step after which every row ends in EOT (as decoding.greedy_decode_tokens): per
+                # BATCH -- rows are EOT-latched, so the steps a batch rides along with its group change nothing
+                all_eot = (t[:, p.n_init:] == p.eot).all(axis=0)
+                if all_eot.any():
+                    n_steps = int(np.argmax(all_eot)) + 1
+                    t = t[:, : p.n_init + n_steps]
+            out.append(PassResult(t, p.n_init, n_steps, slp[r0:r0 + size], languages_all[r0:r0 + size], probs_all[r0:r0 + size],
+                                  p.feats[r0:r0 + size], index=index, _tok=self.tok, _eot=p.eot, _temperature=self.options.temperature))
+            r0 += size
+        return out
 
     # ---- the schedule
     def submit(self, batch) -> List[PassResult]:
         """enqueue one batch; when every slot is taken the OLDEST pass is collected first (its stream set is the one reused, so a
-        pass's work is never ordered behind a younger pass).  Returns what was collected: [] or [PassResult]."""
+        pass's work is never ordered behind a younger pass).  Returns what was collected, in input order (possibly nothing).
+        With ``decode_group`` G > 1 the batch waits until G are there (``drain`` flushes a partial group)."""
         if self._splits_before is None:
             raise _lib.WipaError("TranscribePipeline.submit outside its ``with`` block")
-        done = []
-        if len(self.inflight) == self.P:
-            done.append(self._collect(self.inflight.popleft()))
-        slot = self.submitted % self.P
-        self.inflight.append(self._launch(batch, self.submitted, slot))
+        self.pending.append((batch, self.submitted))
         self.submitted += 1
+        if len(self.pending) < self.G:
+            return []
+        return self._launch_pending()
+
+    def _launch_pending(self) -> List[PassResult]:
+        done: List[PassResult] = []
+        if len(self.inflight) == self.P:
+            done += self._collect(self.inflight.popleft())
+        slot = self.launched % self.P
+        group, self.pending = self.pending, []
+        self.inflight.append(self._launch(group, slot))
+        self.launched += 1
         if self.stop_on_eot:
             self._pump()
         return done
 
     def drain(self) -> Iterator[PassResult]:
+        if self.pending:
+            for r in self._launch_pending():
+                yield r
         while self.inflight:
-            yield self._collect(self.inflight.popleft())
+            for r in self._collect(self.inflight.popleft()):
+                yield r
 
 
 def transcribe_batches(model, batches: Iterable, options: Optional[DecodingOptions] = None, passes_in_flight: int = 4, *,
                        max_new_tokens: Optional[int] = None, stop_on_eot: bool = True, check_every: int = 8,
-                       cross_splits: Optional[int] = None, prefetch: int = 0) -> Iterator[PassResult]:
+                       cross_splits: Optional[int] = None, prefetch: int = 0, decode_group: int = 1) -> Iterator[PassResult]:
     """Transcribe a sequence of batches with ``passes_in_flight`` of them in flight; yields one ``PassResult`` per batch, in
     input order (``.results``: the reference's DecodingResult list; ``.texts``; ``.tokens``).
 
@@ -378,10 +415,11 @@ def transcribe_batches(model, batches: Iterable, options: Optional[DecodingOptio
     ``options``: as ``decode`` (language=None detects the language per clip on the device).  ``max_new_tokens`` (default
     ``options.sample_len`` or n_text_ctx // 2 = 224) and ``stop_on_eot`` as ``greedy_decode_tokens``; ``stop_on_eot=False``
     enqueues a pass's whole fixed-length decode at once.
-    ``passes_in_flight=1`` is the serial schedule (one batch at a time, the model's own ``cross_splits``)."""
+    ``passes_in_flight=1`` is the serial schedule (one batch at a time, the model's own ``cross_splits``).
+    ``decode_group=G``: G consecutive batches decode as one chain of rows (module docstring); results unchanged, still one per batch."""
     it = _prefetched(batches, prefetch) if prefetch > 0 else iter(batches)
     with TranscribePipeline(model, options, passes_in_flight, max_new_tokens=max_new_tokens, stop_on_eot=stop_on_eot,
-                            check_every=check_every, cross_splits=cross_splits) as pipe:
+                            check_every=check_every, cross_splits=cross_splits, decode_group=decode_group) as pipe:
         for batch in it:
             for r in pipe.submit(batch):
                 yield r
