@@ -243,6 +243,15 @@ def phase_enc_loop(model, audio, steps: int, pipeline: int) -> None:
         ev.synchronize()
 
 
+def latest_profile(suffix: str, fallback: str = ""):
+    """path of the newest committed counter summary profiles/r<NN>_<suffix> (counters are collected once per round by
+    tools/profile.sh + tools/summaries.py, in separate rocprofv3 --pmc passes; bench.py only reads them)"""
+    import glob
+
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{suffix}")))
+    return found[-1] if found else os.path.join(ROOT, "profiles", fallback)
+
+
 def roofline_cross_attn(model, B: int, iters: int = 48):
     """Dominant HBM-bound kernel: decode-step cross-attention (K11).  Algorithmic bytes per launch
     = B * 2 * H * 1500 * 64 * sizeof(bf16) (every cached K and V element once) + q/out.
@@ -359,7 +368,7 @@ def roofline_cross_attn(model, B: int, iters: int = 48):
     # quoted when it was collected for exactly this launch shape.
     traffic = None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_cross_block.json" if fused else "r01_pmc_cross_attn.json")))
+        pm = json.load(open(latest_profile("pmc_cross_block.json") if fused else os.path.join(ROOT, "profiles", "r01_pmc_cross_attn.json")))
         if pm.get("algorithmic_bytes_per_launch") == bytes_alg:
             traffic = pm["hbm_bytes_per_launch"]
     except Exception:
@@ -466,7 +475,7 @@ def roofline_cross_absorbed(model, B: int, st, iters: int = 48):
     achieved = bytes_alg / (ms * 1e-3) / 1e9
     traffic = None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_cross_absorbed.json" if S == 4 else f"r04_pmc_cross_absorbed_s{S}.json")))
+        pm = json.load(open(latest_profile("pmc_cross_absorbed.json" if S == 4 else f"pmc_cross_absorbed_s{S}.json")))
         if pm.get("algorithmic_bytes_per_launch") == bytes_alg:
             traffic = pm["hbm_bytes_per_launch"]
     except Exception:
@@ -493,7 +502,7 @@ def roofline_cross_absorbed(model, B: int, st, iters: int = 48):
                               "GB/s": round(kv_bytes / (ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(kv_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
 
 
-def roofline_mfma(model, audio, pmc_file: str = "r04_pmc_encoder_gemm.json"):
+def roofline_mfma(model, audio, pmc_file: str = "pmc_encoder_gemm.json"):
     """The MFMA-bound kernel set: every GEMM / conv-as-GEMM of one encoder pass plus the cross-K/V projection.
     Algorithmic FLOPs per clip are SURVEY.md App. B's (whisper-small: 261.2 + 42.5 GFLOP); the time is the sum of HIP-event
     spans around each GEMM launch of a real pass on the library stream (wipa_profile_begin / wipa_profile_end)."""
@@ -545,7 +554,7 @@ def roofline_mfma(model, audio, pmc_file: str = "r04_pmc_encoder_gemm.json"):
         out["fp8_mfma"] = {"fp8_share_of_flops": round(f8 / flops, 4), "peak_fp8": 5000.0, "frac_of_fp8_peak": round(achieved / 5000.0, 4),
                            "note": "whole GEMM set (fp8 and bf16 launches together) / its summed launch time; frac above is against the bf16 peak"}
     try:  # SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE per GEMM shape, separate rocprofv3 --pmc passes (profiles/)
-        out["mfma_busy_pmc"] = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
+        out["mfma_busy_pmc"] = json.load(open(latest_profile(pmc_file)))
     except Exception:
         pass
     return out

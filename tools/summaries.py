@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Turn gpurun_out/r04/ (tools/r04_gpu_profile.sh a | b) into the committed summaries under profiles/.  usage: tools/r04_summaries.py
-R04_SRC=r04s8 R04_SPLITS=2 tools/r04_summaries.py: the same from gpurun_out/r04s8/ (tools/r04_run8.sh: the streaming kernel at 2 frame
-splits -> profiles/r04_pmc_cross_absorbed_s2.json)."""
+"""Turn gpurun_out/$ROUND/ (tools/profile.sh bench | gemm | cross | train-size) into the committed summaries under profiles/.
+usage: ROUND=r05 SPLITS=2 python tools/summaries.py     (SPLITS: the frame splits the streaming kernel's counters were taken at ->
+profiles/<round>_pmc_cross_absorbed.json for 4, ..._s<SPLITS>.json otherwise; CROSS_TABLE=1 also rewrites the cached-vs-absorbed table)"""
 import collections
 import csv
 import glob
@@ -11,8 +11,9 @@ import re
 import shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", os.environ.get("R04_SRC", "r04"))
-SPLITS = int(os.environ.get("R04_SPLITS", "4"))
+ROUND = os.environ.get("ROUND", "r05")
+SRC = os.path.join(ROOT, "gpurun_out", os.environ.get("SRC", ROUND))
+SPLITS = int(os.environ.get("SPLITS", "2"))
 DST = os.path.join(ROOT, "profiles")
 
 
@@ -48,13 +49,13 @@ for tag, d, cmd in (("default_cmd", "kt", "python3 bench.py --no-cpu-baseline --
                     ("pipeline1", "kt1", "python3 bench.py --no-cpu-baseline --no-finetune --steps 3 --pipeline 1")):
     if not have(d, "bench_kernel_stats.csv"):
         continue
-    shutil.copy(os.path.join(SRC, d, "bench_kernel_stats.csv"), os.path.join(DST, f"r04_bench_{tag}_kernel_stats.csv"))
+    shutil.copy(os.path.join(SRC, d, "bench_kernel_stats.csv"), os.path.join(DST, f"{ROUND}_bench_{tag}_kernel_stats.csv"))
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(os.path.join(SRC, d, "bench_kernel_trace.csv"))):
         key = (short(r["Kernel_Name"]), f'{int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1)}x{r["Grid_Size_Y"]}x{r["Grid_Size_Z"]}')
         agg[key][0] += 1
         agg[key][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-    with open(os.path.join(DST, f"r04_bench_{tag}_by_grid.txt"), "w") as f:
+    with open(os.path.join(DST, f"{ROUND}_bench_{tag}_by_grid.txt"), "w") as f:
         f.write(f"# rocprofv3 --kernel-trace --stats --output-format csv -- {cmd}   (MI355X, round 4; all passes incl. warm-up and the roofline microbenches)\n")
         f.write(f"# total kernel time {sum(v[1] for v in agg.values()) / 1e3:.2f} ms over {sum(v[0] for v in agg.values())} dispatches\n")
         for (k, g), (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:44]:
@@ -86,7 +87,7 @@ if have("pmc_x1"):
            "avg_us_under_counters": [round(sum(d1) / max(len(d1), 1), 2), round(sum(d2) / max(len(d2), 1), 2)],
            "avg_us_event_timed_no_counters": ev}
     out["ratio_traffic_over_algorithmic"] = round(out["hbm_bytes_per_launch"] / alg, 4)
-    json.dump(out, open(os.path.join(DST, "r04_pmc_cross_absorbed.json" if SPLITS == 4 else f"r04_pmc_cross_absorbed_s{SPLITS}.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(DST, f"{ROUND}_pmc_cross_absorbed.json" if SPLITS == 4 else f"{ROUND}_pmc_cross_absorbed_s{SPLITS}.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 # ---- the dominant kernel of the default step: fused cross block on the cached K / V
@@ -115,7 +116,7 @@ if have("pmc_c1"):
            "avg_us_under_counters": [round(sum(d1) / max(len(d1), 1), 2), round(sum(d2) / max(len(d2), 1), 2)],
            "avg_us_event_timed_no_counters": ev}
     out["ratio_traffic_over_algorithmic"] = round(out["hbm_bytes_per_launch"] / alg, 4)
-    json.dump(out, open(os.path.join(DST, "r04_pmc_cross_block.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(DST, f"{ROUND}_pmc_cross_block.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 # ---- encoder GEMM counters + per-shape times
@@ -142,7 +143,7 @@ if have("pmc_g1"):
         rows = sorted((r for r in csv.DictReader(open(f)) if "gemm_nt" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
         dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
     gemm = {}
-    with open(os.path.join(DST, "r04_pmc_encoder_gemm.txt"), "w") as f:
+    with open(os.path.join(DST, f"{ROUND}_pmc_encoder_gemm.txt"), "w") as f:
         f.write("# rocprofv3 --pmc on tools/pmc_gemm.py (M = 96000 rows, the encoder GEMM shapes of whisper-small at B = 64; three launches per\n"
                 "# shape, counters averaged over the 2nd and 3rd), MI355X, round 4.\n"
                 "# passes: {SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES},\n"
@@ -169,8 +170,8 @@ if have("pmc_g1"):
             for cn, v in sorted(c.items()):
                 f.write(f"   {cn:34s} {v:.4g}\n")
             f.write(f"   -> MFMA utilisation {util:.3f}, waves parked {parked:.3f}\n")
-    json.dump({"source": "profiles/r04_pmc_encoder_gemm.txt", "definition": "SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GRBM_GUI_ACTIVE per XCD", "by_gemm": gemm},
-              open(os.path.join(DST, "r04_pmc_encoder_gemm.json"), "w"), indent=1)
+    json.dump({"source": f"profiles/{ROUND}_pmc_encoder_gemm.txt", "definition": "SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GRBM_GUI_ACTIVE per XCD", "by_gemm": gemm},
+              open(os.path.join(DST, f"{ROUND}_pmc_encoder_gemm.json"), "w"), indent=1)
     print(json.dumps(gemm, indent=1))
 
 # ---- log-mel
@@ -194,7 +195,7 @@ if have("kt_lm"):
            "algorithmic_bytes_per_batch": 64 * 2880000,
            "correction": "FETCH_SIZE doubled for wide coalesced 16 B/lane streams (MI355X_MICROARCH.md); the fused kernel reads the audio with 4-byte "
                          "coalesced loads, so the doubled figure is an upper bound"}
-    json.dump(out, open(os.path.join(DST, "r04_logmel.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(DST, f"{ROUND}_logmel.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 # ---- cached K / V vs absorbed projections: one table
@@ -210,16 +211,16 @@ for i, (label, pat) in enumerate(cases):
     if all(have(f) and os.path.getsize(os.path.join(SRC, f)) > 0 for f in files):
         c, a = (json.loads(open(os.path.join(SRC, f)).read().strip().splitlines()[-1]) for f in files)
         rows.append((label, c["ms_per_step"], c["value"], a["ms_per_step"], a["value"]))
-# (sessions 5-6 data, 4 frame splits; R04_CROSS_TABLE=1 rewrites the table -- a later bench_default.json is a 2-split run from another box)
-if rows and os.environ.get("R04_CROSS_TABLE") == "1":
-    with open(os.path.join(DST, "r04_cached_vs_absorbed.txt"), "w") as f:
-        f.write("# bench.py --no-cpu-baseline --no-finetune --cross-attention {cached,absorbed} [...]   (MI355X, round 4; tools/r04_gpu_profile.sh, tools/r04_cross_sweep.sh)\n")
+# (CROSS_TABLE=1 rewrites the table from the sw_*.json runs of `tools/profile.sh cross`)
+if rows and os.environ.get("CROSS_TABLE") == "1":
+    with open(os.path.join(DST, f"{ROUND}_cached_vs_absorbed.txt"), "w") as f:
+        f.write("# bench.py --no-cpu-baseline --no-finetune --cross-attention {cached,absorbed} [...]   (MI355X; tools/profile.sh crosseep.sh)\n")
         f.write(f"# {'workload':66s} {'cached ms':>10s} {'audio-s/s':>10s} {'absorbed ms':>12s} {'audio-s/s':>10s} {'absorbed vs cached':>19s}\n")
         for label, cm, cv, am, av in rows:
             f.write(f"  {label:66s} {cm:10.2f} {cv:10.0f} {am:12.2f} {av:10.0f} {100 * (av / cv - 1):+18.1f}%\n")
-    print(open(os.path.join(DST, "r04_cached_vs_absorbed.txt")).read())
+    print(open(os.path.join(DST, f"{ROUND}_cached_vs_absorbed.txt")).read())
 
 for n in ("bench_default.json", "bench_cached.json", "bench_cached_n224.json", "size_medium_b256_cached.json", "train_exact.json", "train_split.json", "size_small_n224.json", "size_small_n224_absorbed.json", "size_medium_b256.json",
           "size_large_b128_bf16.json", "size_large_b128_fp8.json", "size_large_b128_fp8_act.json", "size_small_fp8.json", "size_small_p1.json"):
     if have(n) and os.path.getsize(os.path.join(SRC, n)) > 0:
-        shutil.copy(os.path.join(SRC, n), os.path.join(DST, "r04_" + n))
+        shutil.copy(os.path.join(SRC, n), os.path.join(DST, ROUND + "_" + n))
