@@ -12,17 +12,24 @@
 #   gemm-probe   tools/micro/gemm_loop_probe.hip: the encoder GEMM's loop taken apart, + MFMA-busy counters of every variant
 #   group-sweep  tools/group_sweep.py: decode groups x groups in flight
 #   final        the tree's final check: pytest -m gpu, smoke(), the default bench line
-# Everything lands under gpurun_out/$ROUND/; `ROUND=r05 python tools/summaries.py` turns it into the committed summaries under
-# profiles/ (profiles/README.md maps every committed profile to its mode).  Programs go directly after `--` under rocprofv3, and
+# RAW rocprofv3 output stays on the GPU box (/tmp/wipa_prof/$ROUND: a traced bench run is > 64 MiB, more than gpurun copies back);
+# every mode ends by running tools/summaries.py THERE, so what comes back under gpurun_out/$ROUND/ is the summaries (named as they
+# are committed: copy them into profiles/) and the small JSON lines / logs.  profiles/README.md maps every committed profile to its mode.  Programs go directly after `--` under rocprofv3, and
 # counter passes never share a run with a trace domain other than --kernel-trace.
 set -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 ROUND=${ROUND:-r05}
 SPLITS=${SPLITS:-2}
 export SPLITS   # tools/pmc_cross_absorbed.py reads it: the frame splits of the streaming launch (2 = several passes in flight, 4 = lone decode)
-OUT=$ROOT/gpurun_out/$ROUND
-mkdir -p $OUT
+KEEP=$ROOT/gpurun_out/$ROUND          # what gpurun copies back: summaries, JSON lines, logs
+OUT=/tmp/wipa_prof/$ROUND             # raw traces and counter CSVs: stay on the box
+mkdir -p $OUT $KEEP
 MODE=$1
+reduce() {  # raw -> summaries (in $KEEP, under their committed names) + the small files
+  SRC=$OUT DST=$KEEP ROUND=$ROUND SPLITS=$SPLITS CROSS_TABLE=${CROSS_TABLE:-0} python3 $ROOT/tools/summaries.py > $KEEP/summaries_$MODE.log 2>&1 || { tail -5 $KEEP/summaries_$MODE.log; return 1; }
+  find $OUT -maxdepth 1 -type f -size -2M \( -name "*.json" -o -name "*.txt" -o -name "*.log" -o -name "*.err" \) -exec cp {} $KEEP/ \;
+  du -sh $KEEP | cut -f1
+}
 cd /tmp && export TMPDIR=/tmp
 B="python3 $ROOT/bench.py --no-cpu-baseline --no-finetune --no-other-configs"
 case "$MODE" in
@@ -40,7 +47,8 @@ bench)
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_c1 -- python3 $ROOT/tools/pmc_cross_block.py > $OUT/pmc_c1.log 2>&1 || exit 1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_c2 -- python3 $ROOT/tools/pmc_cross_block.py > $OUT/pmc_c2.log 2>&1 || exit 1
   python3 $ROOT/tools/pmc_cross_block.py > $OUT/pmc_c_timing.log 2>&1 || exit 1
-  cat $OUT/bench_default.json | cut -c1-600 ;;
+  reduce || exit 1
+  cat $OUT/bench_default.json | cut -c1-400 ;;
 gemm)
   echo "== counters: encoder GEMMs"
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/pmc_g1 -- python3 $ROOT/tools/pmc_gemm.py > $OUT/pmc_g1.log 2>&1 || exit 1
@@ -57,7 +65,8 @@ gemm)
   $B --cross-attention cached > $OUT/bench_cached.json 2> /dev/null || exit 1
   $B --cross-attention cached --new-tokens 224 --steps 6 > $OUT/bench_cached_n224.json 2> /dev/null || exit 1
   $B --new-tokens 224 --steps 6 > $OUT/size_small_n224.json 2> /dev/null || exit 1   # cross_attention=auto: picks cached K / V here (64 clips, >= 192 new tokens)
-  $B --cross-attention absorbed --new-tokens 224 --steps 6 > $OUT/size_small_n224_absorbed.json 2> /dev/null || exit 1 ;;
+  $B --cross-attention absorbed --new-tokens 224 --steps 6 > $OUT/size_small_n224_absorbed.json 2> /dev/null || exit 1
+  reduce || exit 1 ;;
 cross)
   for mode in cached absorbed; do
     timeout -k 10 300 $B --cross-attention $mode --new-tokens 32 --steps 12 > $OUT/sw_${mode}_s64_n32.json 2>/dev/null || exit 1
@@ -65,7 +74,8 @@ cross)
     timeout -k 10 400 $B --cross-attention $mode --batch 128 --steps 6 > $OUT/sw_${mode}_s128_n64.json 2>/dev/null || exit 1
     timeout -k 10 400 $B --cross-attention $mode --batch 128 --new-tokens 224 --steps 4 > $OUT/sw_${mode}_s128_n224.json 2>/dev/null || exit 1
     timeout -k 10 500 $B --cross-attention $mode --model medium --batch 256 --pipeline 2 --new-tokens 224 --steps 3 > $OUT/sw_${mode}_m256_n224.json 2>/dev/null || exit 1
-  done ;;
+  done
+  CROSS_TABLE=1 reduce || exit 1 ;;
 train-size)
   echo "== fine-tune step"
   python3 $ROOT/bench.py --mode train --steps 5 --warmup 1 --f32 exact > $OUT/train_exact.json 2> $OUT/train_exact.err || exit 1
@@ -77,7 +87,8 @@ train-size)
   echo "== large-v3 B=128 fp8 w+a"; $B --model large-v3 --batch 128 --pipeline 2 --steps 4 --weights fp8 --activations fp8 > $OUT/size_large_b128_fp8_act.json 2> /dev/null || exit 1
   echo "== small fp8";             $B --weights fp8 > $OUT/size_small_fp8.json 2> /dev/null || exit 1
   echo "== small pipeline 1";      $B --pipeline 1 --steps 4 > $OUT/size_small_p1.json 2> /dev/null || exit 1
-  for f in $OUT/size_*.json $OUT/train_*.json; do echo "$(basename $f): $(python3 -c "import json,sys; d=json.load(open('$f')); print(d['ms_per_step'], d['value'], d.get('decode_step',{}).get('ms_per_step'), d.get('roofline',{}).get('frac'), d.get('roofline_mfma',{}).get('frac'))")"; done ;;
+  for f in $OUT/size_*.json $OUT/train_*.json; do echo "$(basename $f): $(python3 -c "import json,sys; d=json.load(open('$f')); print(d['ms_per_step'], d['value'], d.get('decode_step',{}).get('ms_per_step'), d.get('roofline',{}).get('frac'), d.get('roofline_mfma',{}).get('frac'))")"; done
+  reduce || exit 1 ;;
 gaps)
   for BATCH in 8 64; do for P in 4 1; do
     timeout -k 10 200 python3 $ROOT/bench.py --phase dec --batch $BATCH --pipeline $P --steps 8 --warmup 1 2>/dev/null | tail -1 | tee -a $OUT/gaps_untraced.txt || exit 1
@@ -86,24 +97,25 @@ gaps)
     timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/gaps_p$P -o t -- python3 $ROOT/bench.py --phase dec --batch 8 --pipeline $P --steps 8 --warmup 1 > $OUT/gaps_p$P.log 2>&1 || exit 1
     grep -h diagnostic_phase $OUT/gaps_p$P.log
   done
-  echo "then: python tools/decode_gaps.py gpurun_out/$ROUND/gaps_p4/t_kernel_trace.csv gpurun_out/$ROUND/gaps_p1/t_kernel_trace.csv" ;;
+  python3 $ROOT/tools/decode_gaps.py $(find $OUT/gaps_p4 -name "*kernel_trace.csv" | head -1) $(find $OUT/gaps_p1 -name "*kernel_trace.csv" | head -1) | tee $KEEP/decode_gaps_table.txt
+  cp $OUT/gaps_untraced.txt $KEEP/ ;;
 chain-probe)
   hipcc --offload-arch=gfx950 -O3 -o /tmp/chain_probe $ROOT/tools/micro/chain_probe.hip 2>/dev/null || exit 1
-  timeout -k 10 240 /tmp/chain_probe 48 | tee $OUT/chain_probe.txt ;;
+  timeout -k 10 240 /tmp/chain_probe 48 | tee $KEEP/chain_probe.txt ;;
 gemm-probe)
   hipcc --offload-arch=gfx950 -O3 -o /tmp/gemm_loop_probe $ROOT/tools/micro/gemm_loop_probe.hip 2>/dev/null || exit 1
-  timeout -k 10 200 /tmp/gemm_loop_probe | tee $OUT/gemm_loop_probe.txt || exit 1
-  timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $OUT/glp_pmc_a -o t -- /tmp/gemm_loop_probe > $OUT/glp_pmc_a.log 2>&1 || exit 1
-  timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/glp_pmc_b -o t -- /tmp/gemm_loop_probe > $OUT/glp_pmc_b.log 2>&1 || exit 1 ;;
+  timeout -k 10 200 /tmp/gemm_loop_probe | tee $KEEP/gemm_loop_probe.txt || exit 1
+  timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $KEEP/glp_pmc_a -o t -- /tmp/gemm_loop_probe > $KEEP/glp_pmc_a.log 2>&1 || exit 1
+  timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $KEEP/glp_pmc_b -o t -- /tmp/gemm_loop_probe > $KEEP/glp_pmc_b.log 2>&1 || exit 1 ;;  # ~170 KB of counter CSVs
 group-sweep)
-  timeout -k 10 600 python3 $ROOT/tools/group_sweep.py 24 2>/dev/null | tee $OUT/group_sweep.txt ;;
+  timeout -k 10 600 python3 $ROOT/tools/group_sweep.py 24 2>/dev/null | tee $KEEP/group_sweep.txt ;;
 final)
   cd $ROOT
-  timeout -k 10 1000 python -m pytest tests -m gpu -q > $OUT/final_tests.log 2>&1; tail -3 $OUT/final_tests.log
-  timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/final_smoke.log 2>&1; tail -1 $OUT/final_smoke.log
-  S=$(date +%s); python bench.py > $OUT/final_bench.json 2> $OUT/final_bench.err; echo "bench rc=$? wall=$(( $(date +%s) - S )) s"
+  timeout -k 10 1000 python -m pytest tests -m gpu -q > $KEEP/final_tests.log 2>&1; tail -3 $KEEP/final_tests.log
+  timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" > $KEEP/final_smoke.log 2>&1; tail -1 $KEEP/final_smoke.log
+  S=$(date +%s); python bench.py > $KEEP/final_bench.json 2> $KEEP/final_bench.err; echo "bench rc=$? wall=$(( $(date +%s) - S )) s"
   python3 -c "
-import json; d=json.loads(open('$OUT/final_bench.json').read().strip().splitlines()[-1])
+import json; d=json.loads(open('$KEEP/final_bench.json').read().strip().splitlines()[-1])
 print('ms/pass', d['ms_per_step'], 'value', d['value'], 'single', d['ms_per_pass_single_in_flight'], 'evaluate-style', d['evaluate_style']['frac_of_value'],
       'step', d['decode_step']['ms_per_step'], 'roofline', d['roofline']['frac'], 'mfma', d['roofline_mfma']['frac'],
       'parity', d['parity_vs_cpu']['token_match'], d['parity_vs_cpu_peaky']['rows_identical'], 'other', {k: v['ms_per_step'] for k, v in d.get('other_configs', {}).items()})" ;;

@@ -14,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ROUND = os.environ.get("ROUND", "r05")
 SRC = os.path.join(ROOT, "gpurun_out", os.environ.get("SRC", ROUND))
 SPLITS = int(os.environ.get("SPLITS", "2"))
-DST = os.path.join(ROOT, "profiles")
+DST = os.environ.get("DST") or os.path.join(ROOT, "profiles")  # on the GPU box: gpurun_out/<round>/ (tools/profile.sh)
+os.makedirs(DST, exist_ok=True)
 
 
 def counters(d):
@@ -45,8 +46,8 @@ def have(*parts):
 
 
 # ---- kernel stats of the default bench command (4 passes in flight) and of --pipeline 1
-for tag, d, cmd in (("default_cmd", "kt", "python3 bench.py --no-cpu-baseline --no-finetune --steps 6"),
-                    ("pipeline1", "kt1", "python3 bench.py --no-cpu-baseline --no-finetune --steps 3 --pipeline 1")):
+for tag, d, cmd in (("default_cmd", "kt", "python3 bench.py --no-cpu-baseline --no-finetune --no-other-configs --steps 6"),
+                    ("pipeline1", "kt1", "python3 bench.py --no-cpu-baseline --no-finetune --no-other-configs --steps 3 --pipeline 1")):
     if not have(d, "bench_kernel_stats.csv"):
         continue
     shutil.copy(os.path.join(SRC, d, "bench_kernel_stats.csv"), os.path.join(DST, f"{ROUND}_bench_{tag}_kernel_stats.csv"))
@@ -56,7 +57,7 @@ for tag, d, cmd in (("default_cmd", "kt", "python3 bench.py --no-cpu-baseline --
         agg[key][0] += 1
         agg[key][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     with open(os.path.join(DST, f"{ROUND}_bench_{tag}_by_grid.txt"), "w") as f:
-        f.write(f"# rocprofv3 --kernel-trace --stats --output-format csv -- {cmd}   (MI355X, round 4; all passes incl. warm-up and the roofline microbenches)\n")
+        f.write(f"# rocprofv3 --kernel-trace --stats --output-format csv -- {cmd}   (MI355X, {ROUND}; all passes incl. warm-up, the evaluate-style run and the roofline microbenches; the tracer runs the passes in flight one after another)\n")
         f.write(f"# total kernel time {sum(v[1] for v in agg.values()) / 1e3:.2f} ms over {sum(v[0] for v in agg.values())} dispatches\n")
         for (k, g), (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:44]:
             f.write(f"{k:82s} grid={g:>14s} calls={n:6d} total_ms={t / 1e3:9.2f} avg_us={t / n:9.2f}\n")
@@ -145,7 +146,7 @@ if have("pmc_g1"):
     gemm = {}
     with open(os.path.join(DST, f"{ROUND}_pmc_encoder_gemm.txt"), "w") as f:
         f.write("# rocprofv3 --pmc on tools/pmc_gemm.py (M = 96000 rows, the encoder GEMM shapes of whisper-small at B = 64; three launches per\n"
-                "# shape, counters averaged over the 2nd and 3rd), MI355X, round 4.\n"
+                "# shape, counters averaged over the 2nd and 3rd), MI355X, " + ROUND + ".\n"
                 "# passes: {SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES},\n"
                 "# {GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16}, {SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD}; durations from a\n"
                 "# separate --kernel-trace run (no counters).  MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs).\n")
