@@ -40,6 +40,11 @@ const char* wipa_last_error(void);
  * i is CU i/8 of XCD i%8, so every XCD keeps n_cus/8 of its 32 CUs; n_cus a multiple of 8).  Serving keeps several passes in
  * flight; giving the MFMA-bound encoder of one pass fewer than all CUs leaves the rest to the HBM-/latency-bound decode loop of
  * another (bench.py --encoder-cus).  The caller destroys the stream after synchronising it. */
+/* A plain non-blocking HIP stream created by the library, in the order the host asks for them.  ROCm hands hardware queues to
+ * streams in creation order (GPU_MAX_HW_QUEUES of them, then shared), so a host that keeps several passes in flight
+ * (whisper_ipa_amd/pipeline.py; reference: the batch loops of scripts/evaluate_model.py:181-212) creates its pass streams -- and,
+ * before them, any idle padding streams -- itself instead of taking them from a framework's pool. */
+int wipa_stream_create(wipa_stream_t* out);
 int wipa_stream_create_cu_limited(int n_cus, wipa_stream_t* out);
 int wipa_stream_destroy(wipa_stream_t s);
 

@@ -80,6 +80,10 @@ struct Shape {
     int grid, block, lds_bytes, work;
 };
 
+// PAD idle streams are created BEFORE the working ones (env CHAIN_PAD): shifts which hardware queue each working stream lands on
+// (ROCm hands queues out in creation order); PRIO (env CHAIN_PRIO=1): the working streams alternate between the two priorities
+// HIP offers, which also moves them to other queues.
+static int g_pad = 0, g_prio = 0;
 static void run(const Shape& sh, int S, int N, int R) {
     std::vector<hipStream_t> st(S);
     std::vector<hipGraphExec_t> ge(S);
@@ -87,7 +91,13 @@ static void run(const Shape& sh, int S, int N, int R) {
     std::vector<float*> bufs;
     double host_us = 0;
     for (int s = 0; s < S; ++s) {
-        CK(hipStreamCreateWithFlags(&st[s], hipStreamNonBlocking));
+        if (g_prio) {
+            int lo = 0, hi = 0;
+            CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            CK(hipStreamCreateWithPriority(&st[s], hipStreamNonBlocking, (s & 1) ? hi : lo));
+        } else {
+            CK(hipStreamCreateWithFlags(&st[s], hipStreamNonBlocking));
+        }
         Probe& p = pr[s];
         p.n_links = N;
         p.max_rep = R;
@@ -169,6 +179,18 @@ static void run(const Shape& sh, int S, int N, int R) {
 int main(int argc, char** argv) {
     setenv("GPU_MAX_HW_QUEUES", "8", 0);  // before the runtime starts: as the package asks (runtime.request_hw_queues)
     const int N = 136, R = argc > 1 ? atoi(argv[1]) : 48;  // the decode step: ~136 dependent launches, replayed once per position
+    g_pad = getenv("CHAIN_PAD") ? atoi(getenv("CHAIN_PAD")) : 0;
+    g_prio = getenv("CHAIN_PRIO") ? atoi(getenv("CHAIN_PRIO")) : 0;
+    const bool quick = getenv("CHAIN_QUICK") != nullptr;  // the two lightest shapes, S = 3 and 4 only
+    std::vector<hipStream_t> pad(g_pad);
+    unsigned int* touch = nullptr;
+    CK(hipMalloc(&touch, sizeof(unsigned int)));
+    for (int i = 0; i < g_pad; ++i) {
+        CK(hipStreamCreateWithFlags(&pad[i], hipStreamNonBlocking));
+        CK(hipMemsetAsync(touch, 0, sizeof(unsigned int), pad[i]));  // use the stream once so that its hardware queue exists
+    }
+    CK(hipDeviceSynchronize());
+    printf("GPU_MAX_HW_QUEUES=%s, %d idle stream(s) created first, priorities %s\n", getenv("GPU_MAX_HW_QUEUES"), g_pad, g_prio ? "alternating" : "default");
     const Shape shapes[] = {
         {"1 wg x 64 thr (dispatch only)", 1, 64, 0, 1},
         {"96 wg x 512 thr, 4 round trips", 96, 512, 0, 4},                 // the prologue / merge kernels' shape
@@ -176,7 +198,14 @@ int main(int argc, char** argv) {
         {"384 wg x 256 thr, 64 KB LDS each", 384, 256, 64 * 1024, 4},      // ... that only fits two to a CU
         {"128 wg x 192 thr, 144 KB LDS each", 128, 192, 144 * 1024, 16},   // the half-chip streaming launch's footprint
     };
-    for (const Shape& sh : shapes)
-        for (int S : {1, 2, 3, 4}) run(sh, S, N, R);
+    int si = 0;
+    for (const Shape& sh : shapes) {
+        if (quick && si++ >= 2) break;
+        for (int S : {1, 2, 3, 4, 5, 6}) {
+            if (quick && S < 3) continue;
+            if (!quick && S > 4) continue;
+            run(sh, S, N, R);
+        }
+    }
     return 0;
 }

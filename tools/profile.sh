@@ -10,6 +10,7 @@
 #   gaps         decode phase with 4 and 1 passes in flight: untraced ms per pass, and kernel traces (tools/decode_gaps.py reads them)
 #   chain-probe  tools/micro/chain_probe.hip: dependent-launch chains on 1-4 streams, timed from inside the kernels
 #   gemm-probe   tools/micro/gemm_loop_probe.hip: the encoder GEMM's loop taken apart, + MFMA-busy counters of every variant
+#   chain-pad    the chain probe and the real decode loops against GPU_MAX_HW_QUEUES x idle padding streams x the library's own streams
 #   group-sweep  tools/group_sweep.py: decode groups x groups in flight
 #   final        the tree's final check: pytest -m gpu, smoke(), the default bench line
 # RAW rocprofv3 output stays on the GPU box (/tmp/wipa_prof/$ROUND: a traced bench run is > 64 MiB, more than gpurun copies back);
@@ -102,6 +103,14 @@ gaps)
 chain-probe)
   hipcc --offload-arch=gfx950 -O3 -o /tmp/chain_probe $ROOT/tools/micro/chain_probe.hip 2>/dev/null || exit 1
   timeout -k 10 240 /tmp/chain_probe 48 | tee $KEEP/chain_probe.txt ;;
+chain-pad)
+  hipcc --offload-arch=gfx950 -O3 -o /tmp/chain_probe $ROOT/tools/micro/chain_probe.hip 2>/dev/null || exit 1
+  for Q in 8 16 4; do for PAD in 0 1 2 3; do
+    GPU_MAX_HW_QUEUES=$Q CHAIN_PAD=$PAD CHAIN_QUICK=1 timeout -k 10 60 /tmp/chain_probe 32 | cut -c1-190 | tee -a $KEEP/chain_pad.txt || exit 1
+  done; done
+  GPU_MAX_HW_QUEUES=8 CHAIN_PRIO=1 CHAIN_QUICK=1 timeout -k 10 60 /tmp/chain_probe 32 | cut -c1-190 | tee -a $KEEP/chain_pad.txt
+  echo "== the decode loops themselves (8 clips, 4 passes in flight): torch's pool streams, then the library's own streams" | tee -a $KEEP/queue_pad_sweep.txt
+  cd $ROOT && bash tools/queue_pad_sweep.sh 2>&1 | tee -a $KEEP/queue_pad_sweep.txt ;;
 gemm-probe)
   hipcc --offload-arch=gfx950 -O3 -o /tmp/gemm_loop_probe $ROOT/tools/micro/gemm_loop_probe.hip 2>/dev/null || exit 1
   timeout -k 10 200 /tmp/gemm_loop_probe | tee $KEEP/gemm_loop_probe.txt || exit 1
@@ -119,6 +128,6 @@ import json; d=json.loads(open('$KEEP/final_bench.json').read().strip().splitlin
 print('ms/pass', d['ms_per_step'], 'value', d['value'], 'single', d['ms_per_pass_single_in_flight'], 'evaluate-style', d['evaluate_style']['frac_of_value'],
       'step', d['decode_step']['ms_per_step'], 'roofline', d['roofline']['frac'], 'mfma', d['roofline_mfma']['frac'],
       'parity', d['parity_vs_cpu']['token_match'], d['parity_vs_cpu_peaky']['rows_identical'], 'other', {k: v['ms_per_step'] for k, v in d.get('other_configs', {}).items()})" ;;
-*) echo "usage: bash tools/profile.sh bench|gemm|cross|train-size|gaps|chain-probe|gemm-probe|group-sweep|final   (ROUND=r05 SPLITS=2)"; exit 2 ;;
+*) echo "usage: bash tools/profile.sh bench|gemm|cross|train-size|gaps|chain-probe|chain-pad|gemm-probe|group-sweep|final   (ROUND=r05 SPLITS=2)"; exit 2 ;;
 esac
 echo "== done $MODE"

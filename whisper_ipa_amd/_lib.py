@@ -96,6 +96,7 @@ _P = C.POINTER
 SIGNATURES = {
     "wipa_version": (c_int, []),
     "wipa_last_error": (C.c_char_p, []),
+    "wipa_stream_create": (c_int, [C.POINTER(c_void_p)]),
     "wipa_stream_create_cu_limited": (c_int, [c_int, C.POINTER(c_void_p)]),
     "wipa_stream_destroy": (c_int, [c_void_p]),
     "wipa_logmel_tables_bytes": (c_size_t, [c_int]),

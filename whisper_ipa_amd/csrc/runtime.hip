@@ -43,6 +43,13 @@ extern "C" int wipa_stream_create_cu_limited(int n_cus, wipa_stream_t* out) {
     *out = (wipa_stream_t)s;
     return WIPA_OK;
 }
+extern "C" int wipa_stream_create(wipa_stream_t* out) {
+    WIPA_REQUIRE(out, "wipa_stream_create: null out");
+    hipStream_t s = nullptr;
+    WIPA_CHECK_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out = (wipa_stream_t)s;
+    return WIPA_OK;
+}
 extern "C" int wipa_stream_destroy(wipa_stream_t s) {
     WIPA_REQUIRE(s, "wipa_stream_destroy: null stream");
     WIPA_CHECK_HIP(hipStreamDestroy((hipStream_t)s));

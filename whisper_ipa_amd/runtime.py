@@ -21,6 +21,8 @@ import torch
 from . import _lib
 
 _streams = {}
+_pad_streams = []  # WIPA_PAD_STREAMS: idle streams created before the library's own (kept alive)
+_own_streams = {}  # device -> the library's own streams, created together (WIPA_OWN_STREAMS=1)
 _stream_cus = {}  # library stream id -> CU limit (limit_stream_cus), read when the stream is first used
 _tls = threading.local()
 
@@ -77,7 +79,27 @@ def stream(sid: Optional[int] = None) -> torch.cuda.Stream:
     s = _streams.get(key)
     if s is None:
         n_cus = _stream_cus.get(sid)
-        if n_cus is None:
+        if n_cus is None and os.environ.get("WIPA_OWN_STREAMS", "0") == "1":
+            # EXPERIMENT: the library's own HIP streams instead of torch's pool -- ALL of them created at the first
+            # request, before any of them carries work (WIPA_PAD_STREAMS idle ones first, then sids 0 .. WIPA_OWN_STREAM_COUNT - 1),
+            # each used once so that its hardware queue exists: which queue a pass's stream lands on follows the creation order
+            if not _own_streams.get(key[0]):
+                def make():
+                    raw = C.c_void_p()
+                    _lib.check(_lib.lib().wipa_stream_create(C.byref(raw)), "wipa_stream_create")
+                    st = torch.cuda.ExternalStream(raw.value, device=key[0])  # lives as long as the process
+                    with torch.cuda.stream(st):
+                        torch.zeros(1, device=torch.device("cuda", key[0]))
+                    return st
+                for _ in range(int(os.environ.get("WIPA_PAD_STREAMS", "0"))):
+                    _pad_streams.append(make())
+                _own_streams[key[0]] = [make() for _ in range(int(os.environ.get("WIPA_OWN_STREAM_COUNT", "4")))]
+                torch.cuda.synchronize(key[0])
+            own = _own_streams[key[0]]
+            if sid >= len(own):
+                raise _lib.WipaError(f"WIPA_OWN_STREAMS: library stream {sid} requested, {len(own)} created (WIPA_OWN_STREAM_COUNT)")
+            s = own[sid]
+        elif n_cus is None:
             s = torch.cuda.Stream(device=key[0])
         else:
             raw = C.c_void_p()
