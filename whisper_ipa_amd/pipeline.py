@@ -163,7 +163,9 @@ def _prefetched(it: Iterable, depth: int) -> Iterator:
 class TranscribePipeline:
     """The scheduler behind ``transcribe_batches``; usable directly when batches arrive one by one:
     ``with TranscribePipeline(model, options) as p: p.submit(batch) ...; for r in p.drain(): ...``.
-    ``submit`` returns the results that had to be collected to make room (possibly none), in input order."""
+    ``submit`` returns the results that had to be collected to make room (possibly none), in input order.
+    One pipeline per model at a time, driven from ONE thread: the passes share the model's per-stream workspaces and decode
+    states (keyed by library stream 0 .. passes_in_flight - 1), and ``cross_splits`` is the model's while the block is open."""
 
     def __init__(self, model, options: Optional[DecodingOptions] = None, passes_in_flight: int = 4, *,
                  max_new_tokens: Optional[int] = None, stop_on_eot: bool = True, check_every: int = 8,
@@ -215,11 +217,12 @@ class TranscribePipeline:
     def __exit__(self, *exc):
         try:
             if exc[0] is None:
-                assert not self.inflight, "TranscribePipeline closed with passes in flight: drain() first"
-            else:  # an error: let the enqueued work finish before the states are reused
+                assert not self.inflight and not self.pending, "TranscribePipeline closed with batches pending or in flight: drain() first"
+            else:  # an error: let the enqueued work finish before the states are reused; drop what was never launched
                 for p in self.inflight:
                     p.stream.synchronize()
                 self.inflight.clear()
+                self.pending.clear()
         finally:
             if self._splits_before is not None and self.model.cross_splits != self._splits_before:
                 self.model.cross_splits = self._splits_before
