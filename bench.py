@@ -1057,7 +1057,9 @@ def evaluate_style(model, audio_dev, args, world: int, value: float):
 def other_configs(args):
     """BASELINE.json configs[3] and configs[4] through the same product path, next to the headline (outside its timed region):
     whisper-medium bf16, 256 clips per batch, and whisper-large-v3 with fp8 e4m3 weights + fp8 x fp8 encoder GEMMs, 128 clips per
-    batch; two batches in flight each, NEW_TOKENS = 64 positions, fixed length.  Each entry carries its own rooflines."""
+    batch; THREE batches in flight each (profiles/r05_other_configs_sweep.txt: medium 910 / 830 / 803 / 809 ms per batch with 1 / 2 /
+    3 / 4 in flight, large-v3 824 / 754 / 744 / 742 -- and 82 / 152 GiB of HBM at three), NEW_TOKENS = 64 positions, fixed length.
+    Each entry carries its own rooflines."""
     import gc
 
     from whisper_ipa_amd.pipeline import TranscribePipeline
@@ -1067,7 +1069,7 @@ def other_configs(args):
         t_cfg = time.perf_counter()
         model = build_model(name, "bf16", weights, acts)
         audio = torch.from_numpy(synthetic_audio(0, B)).cuda()
-        P, steps = 2, 4
+        P, steps = 3, 6
         with TranscribePipeline(model, bench_options(), P, max_new_tokens=NEW_TOKENS, stop_on_eot=False) as pipe:
             for _ in range(P):
                 pipe.submit(audio)
