@@ -9,10 +9,12 @@ resident in HBM: log-mel -> encoder -> cross-K/V -> prompt + 64 greedy decode po
 prefill pass, as the reference's decoder does) -> token ids on the host.
 N > 1: clips are sharded data-parallel, one process per GPU, no data-path collective
 (weak scaling); the only collective is the barrier / max-reduce of the timing itself.
-Consecutive passes are software-pipelined: up to `--pipeline` (default 4) passes are in flight on
-separate HIP streams with separate workspaces / KV caches, each doing ALL of its work inside the
-timed region, so the encoder of one batch overlaps the decode loop of the previous one
-(`ms_per_step` = timed wall time / steps, i.e. the steady-state time per 64-clip batch).
+THE TIMED REGION IS THE PRODUCT PATH: whisper_ipa_amd.pipeline.TranscribePipeline, the scheduler behind
+`transcribe_batches(model, batches, options, passes_in_flight=...)` that scripts/evaluate_model.py and validate() call.
+Up to `--pipeline` (default 4) passes are in flight on separate HIP streams with separate workspaces / decode states, each
+doing ALL of its work inside the timed region, so the encoder of one batch overlaps the decode loop of the previous one
+(`ms_per_step` = timed wall time / steps, i.e. the steady-state time per 64-clip batch).  The schedule -- not this file --
+sets the streaming launch's frame splits (2 with several passes in flight) and the package asks for 8 hardware queues at import.
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment makes this process a LAUNCHER: it starts N rank processes
 (one per GPU, RCCL rendezvous on 127.0.0.1) without touching the GPU itself and relays rank 0's JSON line.  Under
@@ -24,8 +26,11 @@ Prints ONE JSON line (rank 0) with
                    peak, from HIP events around every GEMM launch of a real pass (wipa_profile_begin/end);
   `decode_step`    one whole decode step (graph replay, ONE pass in flight) against the HBM peak: SURVEY section 8d bytes
                    (B x cross-K/V + self-K/V + decoder weights) / event-timed step;
-  `parity_vs_cpu`  token ids of clips 0..7 against the CPU oracle's ids for the same weights and clips;
-  `cpu_baseline`   the CPU oracle (a port) timed on this box's host cores on a bounded sample (rank 0, N = 1 only).
+  `evaluate_style` the same workload the way the reference's batch caller consumes it (transcribe_batches with early stop armed, every
+                   row turned into text), as a fraction of `value`;
+  `parity_vs_cpu`  token ids of clips 0..7 against the CPU oracle's ids for the same weights and clips (+ `parity_vs_cpu_peaky`);
+  `cpu_baseline`   the CPU oracle (a port) timed on this box's host cores on a bounded sample (rank 0, N = 1 only);
+  `finetune_step`  the decoder fine-tune step (exact f32 products), `other_configs` BASELINE configs[3] / [4] through the same path.
 `--mode train` times the decoder fine-tune step instead (one rank's share of BASELINE.json configs[2]).
 """
 from __future__ import annotations
