@@ -45,9 +45,6 @@ const char* wipa_last_error(void);
  * (whisper_ipa_amd/pipeline.py; reference: the batch loops of scripts/evaluate_model.py:181-212) creates its pass streams -- and,
  * before them, any idle padding streams -- itself instead of taking them from a framework's pool. */
 int wipa_stream_create(wipa_stream_t* out);
-/* The same with a priority class: -1 = the device's highest stream priority, 0 = normal, 1 = its lowest
- * (hipDeviceGetStreamPriorityRange).  Used by the scheduling experiments of DESIGN.md 8.2; the shipped schedule uses normal streams. */
-int wipa_stream_create_with_priority(int priority_class, wipa_stream_t* out);
 int wipa_stream_create_cu_limited(int n_cus, wipa_stream_t* out);
 int wipa_stream_destroy(wipa_stream_t s);
 

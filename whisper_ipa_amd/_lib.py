@@ -97,7 +97,6 @@ SIGNATURES = {
     "wipa_version": (c_int, []),
     "wipa_last_error": (C.c_char_p, []),
     "wipa_stream_create": (c_int, [C.POINTER(c_void_p)]),
-    "wipa_stream_create_with_priority": (c_int, [c_int, C.POINTER(c_void_p)]),
     "wipa_stream_create_cu_limited": (c_int, [c_int, C.POINTER(c_void_p)]),
     "wipa_stream_destroy": (c_int, [c_void_p]),
     "wipa_logmel_tables_bytes": (c_size_t, [c_int]),

@@ -50,16 +50,6 @@ extern "C" int wipa_stream_create(wipa_stream_t* out) {
     *out = (wipa_stream_t)s;
     return WIPA_OK;
 }
-extern "C" int wipa_stream_create_with_priority(int priority_class, wipa_stream_t* out) {
-    WIPA_REQUIRE(out && priority_class >= -1 && priority_class <= 1, "wipa_stream_create_with_priority: class %d not in {-1 high, 0 normal, 1 low}", priority_class);
-    int least = 0, greatest = 0;  // HIP: numerically lower = higher priority; the range is [greatest, least]
-    WIPA_CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    const int prio = priority_class < 0 ? greatest : (priority_class > 0 ? least : (least + greatest) / 2);
-    hipStream_t s = nullptr;
-    WIPA_CHECK_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio));
-    *out = (wipa_stream_t)s;
-    return WIPA_OK;
-}
 extern "C" int wipa_stream_destroy(wipa_stream_t s) {
     WIPA_REQUIRE(s, "wipa_stream_destroy: null stream");
     WIPA_CHECK_HIP(hipStreamDestroy((hipStream_t)s));

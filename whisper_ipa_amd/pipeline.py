@@ -49,13 +49,9 @@ import torch
 from . import _lib
 from . import audio as A
 from .decoding import (DecodingOptions, DecodingResult, _mask, _packed_for, _state_for, _suppress_lists, _use_prefill)
-import os
-
-from .runtime import _streams, hw_queues, ptr, set_stream_priority, sptr, use_stream
+from .runtime import hw_queues, ptr, sptr, use_stream
 from .tokenizer import LANGUAGES, get_tokenizer
 
-ENC_STREAM_BASE = 100           # EXPERIMENT WIPA_PIPE_PRIO=1: a pass's log-mel + encoder on library stream 100 + slot (default priority),
-                                # its decode loop on stream slot created with HIGH priority: freed CUs go to waiting decode kernels first
 PIPELINE_HW_QUEUES = 8          # what 4 passes in flight want (one queue per pass is not enough: copies and graph launches share them)
 PIPELINE_CROSS_SPLITS = 2       # Whisper.cross_splits while >= 2 passes are in flight
 CHUNKS_AHEAD = 2                # chunks of decode steps kept enqueued per pass while its EOT probes are outstanding
@@ -201,14 +197,6 @@ class TranscribePipeline:
         # the setting for several passes in flight; an explicit cross_splits wins
         self._splits = (PIPELINE_CROSS_SPLITS if self.P >= 2 else model.cross_splits) if cross_splits is None else int(cross_splits)
         self._splits_before: Optional[int] = None
-        mode = os.environ.get("WIPA_PIPE_PRIO", "0")  # EXPERIMENTS: 1 = decode loops HIGH, encoders normal; 2 = decode loops normal, encoders LOW
-        self.split_streams = mode in ("1", "2")
-        if mode == "2":
-            from .runtime import stream as _stream
-            for slot in range(self.P):  # all encoder streams created together, before any pass starts (a stream created while
-                if not any(k[1] == ENC_STREAM_BASE + slot for k in _streams):  # others carry work can land on a busy queue)
-                    set_stream_priority(ENC_STREAM_BASE + slot, 1)
-                    _stream(ENC_STREAM_BASE + slot)
         self.inflight: Deque[_Pass] = deque()
         self.submitted = 0   # batches handed over
         self.launched = 0    # passes (batches, or decode groups) enqueued
@@ -285,21 +273,10 @@ class TranscribePipeline:
         L = _lib.lib()
         m = self.model
         cur = torch.cuda.current_stream()
-        parts = None
-        if self.split_streams:  # EXPERIMENT: encoder on its own (default-priority) stream, the decode loop on the high-priority one
-            with use_stream(ENC_STREAM_BASE + slot) as se:
-                if cur != se:
-                    se.wait_stream(cur)
-                parts = [self._features(b) for b, _ in group]
         with use_stream(slot) as s:
-            if parts is not None:
-                s.wait_stream(se)
-                for f in parts:
-                    f.record_stream(s)
-            elif cur != s:
+            if cur != s:
                 s.wait_stream(cur)  # the batch may have been produced on the caller's stream
-            if parts is None:
-                parts = [self._features(b) for b, _ in group]  # log-mel + encoder per batch, as without groups
+            parts = [self._features(b) for b, _ in group]  # log-mel + encoder per batch, as without groups
             sizes = tuple(int(f.shape[0]) for f in parts)
             feats = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)  # the group's rows decode as one chain
             del parts

@@ -21,7 +21,6 @@ import torch
 from . import _lib
 
 _streams = {}
-_stream_prio = {}  # library stream id -> torch stream priority (0 = default, -1 = high), read when the stream is first created
 _pad_streams = []  # WIPA_PAD_STREAMS: idle streams created before the library's own (kept alive)
 _own_streams = {}  # device -> the library's own streams, created together (WIPA_OWN_STREAMS=1)
 _stream_cus = {}  # library stream id -> CU limit (limit_stream_cus), read when the stream is first used
@@ -100,28 +99,14 @@ def stream(sid: Optional[int] = None) -> torch.cuda.Stream:
             if sid >= len(own):
                 raise _lib.WipaError(f"WIPA_OWN_STREAMS: library stream {sid} requested, {len(own)} created (WIPA_OWN_STREAM_COUNT)")
             s = own[sid]
-        elif n_cus is None and _stream_prio.get(sid) == 1:
-            # a LOW-priority stream (torch offers normal and high only): the library's own
-            raw = C.c_void_p()
-            _lib.check(_lib.lib().wipa_stream_create_with_priority(1, C.byref(raw)), "wipa_stream_create_with_priority")
-            s = torch.cuda.ExternalStream(raw.value, device=key[0])  # lives as long as the process
         elif n_cus is None:
-            # EXPERIMENT WIPA_PIPE_PRIO=1 (pipeline.py): the pass streams (sid < 100) at HIGH priority, the encoder streams (100 + slot) default
-            exp_high = os.environ.get("WIPA_PIPE_PRIO", "0") == "1" and sid < 100
-            s = torch.cuda.Stream(device=key[0], priority=_stream_prio.get(sid, -1 if exp_high else 0))
+            s = torch.cuda.Stream(device=key[0])
         else:
             raw = C.c_void_p()
             _lib.check(_lib.lib().wipa_stream_create_cu_limited(int(n_cus), C.byref(raw)), "wipa_stream_create_cu_limited")
             s = torch.cuda.ExternalStream(raw.value, device=key[0])  # lives as long as the process
         _streams[key] = s
     return s
-
-
-def set_stream_priority(sid: int, priority: int) -> None:
-    """Library stream ``sid`` (not yet used) will be created with this priority (0 default, -1 high: a higher hardware-queue priority)."""
-    if any(k[1] == sid for k in _streams):
-        raise _lib.WipaError(f"library stream {sid} already exists; set its priority before first use")
-    _stream_prio[sid] = int(priority)
 
 
 def limit_stream_cus(sid: int, n_cus: Optional[int]) -> None:
