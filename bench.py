@@ -1067,50 +1067,76 @@ def other_configs(args):
     Each entry carries its own rooflines."""
     import gc
 
-    from whisper_ipa_amd.pipeline import TranscribePipeline
-
     res = {}
     for key, name, B, weights, acts in (("configs[3]", "medium", 256, "bf16", "bf16"), ("configs[4]", "large-v3", 128, "fp8", "fp8")):
-        t_cfg = time.perf_counter()
-        model = build_model(name, "bf16", weights, acts)
-        audio = torch.from_numpy(synthetic_audio(0, B)).cuda()
-        P, steps = 3, 6
-        with TranscribePipeline(model, bench_options(), P, max_new_tokens=NEW_TOKENS, stop_on_eot=False) as pipe:
-            for _ in range(P):
-                pipe.submit(audio)
-            warm = [r.tokens for r in pipe.drain()]
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            got = []
-            for _ in range(steps):
-                got += [r.tokens for r in pipe.submit(audio)]
-            got += [r.tokens for r in pipe.drain()]
-            dt = time.perf_counter() - t0
-            splits = model.cross_splits
-        absorbed = bench_absorbed(model, B)
-        model.cross_splits = splits if absorbed else 0
-        one_pass(model, audio)  # stream 0's state in the timed setting for the step roofline
-        entry = {
-            "metric": f"audio-seconds/sec transcribed (whisper-{name}, 30s clips)", "value": round(B * 30.0 * steps / dt, 1), "unit": "audio-s/s",
-            "ms_per_step": round(1e3 * dt / steps, 2), "steps": steps, "n_gpus": 1, "dtype": "bf16",
-            "config": {"workload": f"whisper-{name} bf16{' (fp8 e4m3 weights, fp8 x fp8 encoder GEMMs)' if weights == 'fp8' else ''} batched inference, "
-                                   f"batch={B}x30s synthetic clips, log-mel + encoder{'' if absorbed else ' + cross-K/V projection'} + {NEW_TOKENS} greedy "
-                                   f"KV-cached decode steps; {P} such passes in flight",
-                       "weights": model.weights_format, "encoder_activations": model.activations_format,
-                       "cross_attention": "absorbed" if absorbed else "cached", "clips_per_gpu": B, "passes_in_flight": P,
-                       "cross_frame_splits": (splits or 4) if absorbed else None},
-            "passes_identical": bool(all((t == warm[0]).all() for t in got + warm)),
-            "roofline": roofline_cross_attn(model, B, iters=24),
-            "decode_step": decode_step_roofline(model, B, n_steps=16),
-        }
-        if B <= 128:
-            entry["roofline_mfma"] = roofline_mfma(model, audio)
-        res[key] = entry
-        del model, audio, pipe
+        entry = optional_leg(res, key, lambda: one_other_config(key, name, B, weights, acts))
+        if entry is not None:
+            res[key] = entry
         gc.collect()
         torch.cuda.empty_cache()
-        log(f"other_configs {key}: {entry['ms_per_step']} ms per {B}-clip pass ({time.perf_counter() - t_cfg:.1f} s incl. weights)")
     return res
+
+
+def one_other_config(key: str, name: str, B: int, weights: str, acts: str):
+    """one entry of `other_configs`: the model built, P passes in flight through the product path, its rooflines"""
+    from whisper_ipa_amd.pipeline import TranscribePipeline
+
+    t_cfg = time.perf_counter()
+    model = build_model(name, "bf16", weights, acts)
+    audio = torch.from_numpy(synthetic_audio(0, B)).cuda()
+    P, steps = 3, 6
+    with TranscribePipeline(model, bench_options(), P, max_new_tokens=NEW_TOKENS, stop_on_eot=False) as pipe:
+        for _ in range(P):
+            pipe.submit(audio)
+        warm = [r.tokens for r in pipe.drain()]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        got = []
+        for _ in range(steps):
+            got += [r.tokens for r in pipe.submit(audio)]
+        got += [r.tokens for r in pipe.drain()]
+        dt = time.perf_counter() - t0
+        splits = model.cross_splits
+    absorbed = bench_absorbed(model, B)
+    model.cross_splits = splits if absorbed else 0
+    one_pass(model, audio)  # stream 0's state in the timed setting for the step roofline
+    entry = {
+        "metric": f"audio-seconds/sec transcribed (whisper-{name}, 30s clips)", "value": round(B * 30.0 * steps / dt, 1), "unit": "audio-s/s",
+        "ms_per_step": round(1e3 * dt / steps, 2), "steps": steps, "n_gpus": 1, "dtype": "bf16",
+        "config": {"workload": f"whisper-{name} bf16{' (fp8 e4m3 weights, fp8 x fp8 encoder GEMMs)' if weights == 'fp8' else ''} batched inference, "
+                               f"batch={B}x30s synthetic clips, log-mel + encoder{'' if absorbed else ' + cross-K/V projection'} + {NEW_TOKENS} greedy "
+                               f"KV-cached decode steps; {P} such passes in flight",
+                   "weights": model.weights_format, "encoder_activations": model.activations_format,
+                   "cross_attention": "absorbed" if absorbed else "cached", "clips_per_gpu": B, "passes_in_flight": P,
+                   "cross_frame_splits": (splits or 4) if absorbed else None},
+        "passes_identical": bool(all((t == warm[0]).all() for t in got + warm)),
+        "roofline": roofline_cross_attn(model, B, iters=24),
+        "decode_step": decode_step_roofline(model, B, n_steps=16),
+    }
+    if B <= 128:
+        entry["roofline_mfma"] = roofline_mfma(model, audio)
+    del model, audio, pipe
+    log(f"other_configs {key}: {entry['ms_per_step']} ms per {B}-clip pass ({time.perf_counter() - t_cfg:.1f} s incl. weights)")
+    return entry
+
+
+def optional_leg(out: dict, name: str, fn):
+    """Run one OPTIONAL leg of the line (everything but the headline, its id checks, `roofline`, `decode_step` and `cpu_baseline`, which
+    stay hard failures): an exception -- e.g. out of memory in the large-v3 leg -- is logged with its traceback and recorded under
+    `leg_errors` instead of costing the whole line, headline included.  Returns fn()'s value or None."""
+    import traceback
+
+    try:
+        return fn()
+    except Exception as e:  # noqa: BLE001 -- the point is to keep the measured headline
+        log(f"OPTIONAL LEG '{name}' FAILED: {e!r}")
+        traceback.print_exc(file=sys.stderr)
+        out.setdefault("leg_errors", {})[name] = repr(e)[:500]
+        try:
+            torch.cuda.synchronize()
+        except Exception:
+            pass
+        return None
 
 
 def main():
@@ -1259,7 +1285,9 @@ def main():
         out["value_single_in_flight"] = round(world * B * 30.0 / (out["ms_per_pass_single_in_flight"] * 1e-3), 1)
         assert (single == tokens).all(), "the pipelined and the single pass disagree on the ids"
         assert out["passes_identical"], "timed passes over the same clips produced different ids"
-        out["evaluate_style"] = evaluate_style(model, audio_dev, args, world, out["value"])
+        ev = optional_leg(out, "evaluate_style", lambda: evaluate_style(model, audio_dev, args, world, out["value"]))
+        if ev is not None:
+            out["evaluate_style"] = ev
         log("evaluate-style run done")
         one_pass(model, audio_dev)  # stream 0's decode state back to the timed setting (evaluate_style re-captured nothing else)
         out["roofline"] = roofline_cross_attn(model, B)
@@ -1286,7 +1314,9 @@ def main():
             model.cross_splits = keep
             one_pass(model, audio_dev)  # back to the timed setting: the parity legs below check what was timed
         if args.dtype == "bf16" and args.batch <= 128:
-            out["roofline_mfma"] = roofline_mfma(model, audio_dev)
+            rm = optional_leg(out, "roofline_mfma", lambda: roofline_mfma(model, audio_dev))
+            if rm is not None:
+                out["roofline_mfma"] = rm
         log("roofline microbenches done")
         if world == 1 and not args.no_cpu_baseline and args.model == "small" and B >= 8:
             out["cpu_baseline"], ref, xa_ref = cpu_baseline(8)  # ~25 s of host work
@@ -1314,9 +1344,10 @@ def main():
             del model
             gc.collect()  # the decode states reference the model (cycle): collect before returning the 20+ GB of caches
             torch.cuda.empty_cache()
-            ft = measure_train(args, 0, 1, None, steps=3, warmup=1)
-            out["finetune_step"] = {k: ft[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "stages", "roofline", "loss",
-                                                       "with_feature_cache")}
+            ft = optional_leg(out, "finetune_step", lambda: measure_train(args, 0, 1, None, steps=3, warmup=1))
+            if ft is not None:
+                out["finetune_step"] = {k: ft[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "stages", "roofline", "loss",
+                                                           "with_feature_cache")}
             log("fine-tune step measured")
             model = None
         if (world == 1 and not args.no_other_configs and args.model == "small" and args.dtype == "bf16" and args.weights == "bf16"
@@ -1326,7 +1357,9 @@ def main():
             model = None
             gc.collect()
             torch.cuda.empty_cache()
-            out["other_configs"] = other_configs(args)
+            oc = optional_leg(out, "other_configs", lambda: other_configs(args))
+            if oc is not None:
+                out["other_configs"] = oc
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -874,3 +874,22 @@ def test_hw_queue_request_and_batch_prefetch(monkeypatch):
     assert next(it) == 1
     with pytest.raises(OSError):
         next(it)
+
+
+def test_bench_optional_legs_do_not_cost_the_line(capsys):
+    """bench.py: an exception in an OPTIONAL leg (evaluate-style, MFMA roofline, fine-tune, other_configs -- e.g. out of memory in the
+    large-v3 leg) is recorded under `leg_errors` with its traceback on stderr; the headline and the other legs survive.  The id checks,
+    `roofline`, `decode_step` and `cpu_baseline` are not wrapped: they stay hard failures."""
+    import bench
+
+    out = {}
+    assert bench.optional_leg(out, "fine", lambda: {"v": 1}) == {"v": 1} and "leg_errors" not in out
+    assert bench.optional_leg(out, "configs[4]", lambda: (_ for _ in ()).throw(MemoryError("HIP out of memory"))) is None
+    assert "MemoryError" in out["leg_errors"]["configs[4]"]
+    err = capsys.readouterr().err
+    assert "OPTIONAL LEG 'configs[4]' FAILED" in err and "Traceback" in err
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = src[src.index("def main():"):]
+    for hard in ('out["roofline"] = roofline_cross_attn(model, B)', 'out["decode_step"] = decode_step_roofline(model, B)',
+                 'out["cpu_baseline"], ref, xa_ref = cpu_baseline(8)', 'assert (single == tokens).all()'):
+        assert hard in main, hard  # not behind optional_leg
