@@ -36,7 +36,10 @@ def request_hw_queues(n: int = 8) -> int:
     ONCE, when the HIP runtime starts.  Several passes in flight (pipeline.transcribe_batches) want 8: with 4 passes on 4 queues
     a pass takes 86-88 ms, on 8 queues 72 ms (whisper-small, 64 clips).  Called when the package is imported:
     if the user has not set the variable and nothing has initialised the GPU yet, set it; a user's own value is never
-    overridden.  Returns the count that will be (or is) in effect."""
+    overridden.  Returns the count that will be (or is) in effect.
+    LIMIT of what the host can know: "nothing has initialised the GPU yet" is judged by torch.cuda.is_initialized(), but a bare
+    torch.cuda.is_available() / device_count() can start the HIP runtime without setting that flag -- import the package before
+    ANY torch.cuda call (bench.py, the scripts and __graft_entry__.smoke() do) and hw_queues() is right."""
     if "GPU_MAX_HW_QUEUES" in os.environ:
         if _hwq["requested_in_time"] is None:
             _hwq["requested_in_time"] = not torch.cuda.is_initialized()  # set by the user (or an earlier import) before HIP started?
