@@ -1082,3 +1082,33 @@ def test_transcribe_batches_320_clips_ids_identical_to_the_serial_path():
     assert all((g == w).all() for g, w in zip(one, dflt))  # one batch at a time: the model's own setting
     match = np.mean([(g[:, 4:] == w[:, 4:]).mean() for g, w in zip(got, dflt)])
     print(f"\n4 passes in flight (2 frame splits) vs serial default (4 splits), random-init bf16: token match {match:.4f}")
+
+
+@pytest.mark.parametrize("form", ["cached", "fp8-weights", "f32"])
+def test_transcribe_batches_other_model_forms_match_the_serial_path(small2, form):
+    """The forms `bench.py`'s other_configs drive through the schedule besides absorbed bf16: mlx_whisper's cached K / V
+    (what whisper-large-v3's 20 heads take), fp8 e4m3 weights, and a float32 model -- 3 passes in flight over 5 ragged batches give
+    every clip the ids of one batch at a time through greedy_decode_tokens on the same features, bit for bit."""
+    from whisper_ipa_amd.decoding import DecodingOptions, greedy_decode_tokens
+    from whisper_ipa_amd.pipeline import transcribe_batches
+
+    W, mels, xa = small2
+    sp = R.SpecialTokens.multilingual()
+    always, first = R.suppress_lists(sp)
+    init = list(sp.sot_sequence_including_notimestamps(0))
+    dtype = torch.float32 if form == "f32" else torch.bfloat16
+    m = _model(SMALL2, W, dtype, cross_attention="cached" if form == "cached" else "auto")
+    if form == "fp8-weights":
+        m.quantize_weights("fp8_e4m3")
+    torch.manual_seed(5)
+    base = xa.cuda().to(dtype)
+    batches = [(base[torch.randint(0, 2, (b,))] + 0.05 * torch.randn(b, 1500, SMALL2.n_audio_state, device="cuda").to(dtype)).contiguous()
+               for b in (3, 5, 2, 4, 3)]
+    opts = DecodingOptions(language="en", without_timestamps=True, fp16=False)
+    want = [greedy_decode_tokens(m, f, init, always, first, sp.eot, max_new_tokens=12, stop_on_eot=False).tokens for f in batches]
+    got = [r.tokens for r in transcribe_batches(m, batches, opts, passes_in_flight=3, max_new_tokens=12, stop_on_eot=False,
+                                                cross_splits=m.cross_splits)]
+    assert len(got) == 5 and all(g.shape == w.shape and (g == w).all() for g, w in zip(got, want)), form
+    # not vacuous: the batches are drawn from the fixture's TWO clips (the 0.05 noise does not move their greedy ids: measured 2-3
+    # distinct rows), and both clips' ids appear
+    assert len({tuple(r) for g in got for r in g[:, 4:].tolist()}) >= 2
