@@ -1268,3 +1268,29 @@ print("OK", worst)
     env = dict(os.environ, WIPA_GEMM_FP8_TILE="384", PYTHONPATH=root)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:] + r.stdout[-500:]
+
+
+def test_library_streams_are_the_librarys_own_and_created_together():
+    """runtime.stream(): the library's own HIP streams (wipa_stream_create), the first OWN_STREAM_COUNT created TOGETHER at the
+    first request -- ROCm hands hardware queues to streams in creation order, so the passes in flight of pipeline.py sit on
+    distinct queues even with the default four (bench: 71.8 ms per pass at GPU_MAX_HW_QUEUES=4 against 85.9 with
+    torch's pool streams).  Distinct handles, usable, stable across calls; ids beyond the eager set are created on demand."""
+    from whisper_ipa_amd import runtime as RT
+
+    s0 = RT.stream(0)
+    own = RT._own_streams[torch.cuda.current_device()]
+    assert len(own) == RT.OWN_STREAM_COUNT == 8 and own[0] is s0
+    handles = {s.cuda_stream for s in own}
+    assert len(handles) == 8 and 0 not in handles  # eight different HIP streams, none of them the null stream
+    assert all(isinstance(s, torch.cuda.ExternalStream) for s in own)
+    assert RT.stream(3) is own[3] and RT.stream(3) is RT.stream(3)
+    far = RT.stream(4242)
+    assert far.cuda_stream not in handles and RT.stream(4242) is far
+    x = torch.arange(1024, device="cuda", dtype=torch.float32)
+    outs = []
+    for i in range(8):
+        with RT.use_stream(i) as s:
+            s.wait_stream(torch.cuda.current_stream())
+            outs.append((x * (i + 1)).sum())
+    torch.cuda.synchronize()
+    assert [float(o) for o in outs] == [float(x.sum()) * (i + 1) for i in range(8)]

@@ -14,10 +14,14 @@ What the schedule sets, so that callers need not:
   * the library streams 0 .. passes_in_flight-1 (``runtime.use_stream``), one decode state per stream;
   * ``Whisper.cross_splits`` = 2 while >= 2 passes are in flight (half-chip streaming launches: two passes' cross-attention
     launches run side by side instead of queueing for all 256 CUs), the model's own setting otherwise; restored afterwards;
-  * the hardware-queue count: ROCm multiplexes HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4; measured
-    with 4 passes in flight: 4 queues 86.5-88 ms per pass, 8 queues 72 ms).  The variable is read when the HIP runtime
-    starts, so the package sets it at import when nothing has initialised the GPU yet (``runtime.request_hw_queues``) and
-    this module WARNS when it finds fewer than 8 in effect.
+  * which hardware queue a pass lands on.  ROCm multiplexes HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in
+    creation order.  The library streams are the library's OWN (``wipa_stream_create``), the first eight created together
+    before any carries work, so up to four passes in flight sit on distinct queues even with four (72.0 / 71.3 ms per pass
+    against 72.1 / 71.8 / 71.3 with eight); torch's pool streams on four queues share them (86-88 ms), and a stream created
+    while others carry work can land on a busy queue (85 ms on the decode loops).  The package still asks for 8 queues at
+    import when nothing has initialised the GPU yet (``runtime.request_hw_queues``: headroom for other streams of the process,
+    not speed), and this module warns only about what can still cost: torch's pool streams below 8 queues
+    (``WIPA_OWN_STREAMS=0``), or more passes in flight than streams created together.
 
 Decode groups (``decode_group=G``, default 1 = off): the batches still go through log-mel and the encoder one by one, but the
 rows of G consecutive batches then decode as ONE chain of G x B rows -- fewer, fatter dependent-launch chains on the GPU (four
@@ -49,7 +53,9 @@ import torch
 from . import _lib
 from . import audio as A
 from .decoding import (DecodingOptions, DecodingResult, _mask, _packed_for, _state_for, _suppress_lists, _use_prefill)
-from .runtime import hw_queues, ptr, sptr, use_stream
+import os
+
+from .runtime import OWN_STREAM_COUNT, hw_queues, ptr, sptr, use_stream
 from .tokenizer import LANGUAGES, get_tokenizer
 
 PIPELINE_HW_QUEUES = 8          # what 4 passes in flight want (one queue per pass is not enough: copies and graph launches share them)
@@ -201,10 +207,13 @@ class TranscribePipeline:
         self.submitted = 0   # batches handed over
         self.launched = 0    # passes (batches, or decode groups) enqueued
         self.hw_queues = hw_queues()
-        if self.P >= 2 and self.hw_queues < PIPELINE_HW_QUEUES:
-            warnings.warn(f"whisper_ipa_amd: {self.P} passes in flight on {self.hw_queues} hardware queues (GPU_MAX_HW_QUEUES); "
-                          f"{PIPELINE_HW_QUEUES} are wanted (measured: 4 passes on 4 queues 86-88 ms per pass, on 8 queues 72 ms). "
-                          "Import whisper_ipa_amd before anything initialises the GPU, or export GPU_MAX_HW_QUEUES=8.",
+        own = os.environ.get("WIPA_OWN_STREAMS", "1") == "1"
+        if self.P > OWN_STREAM_COUNT or (not own and self.P >= 2 and self.hw_queues < PIPELINE_HW_QUEUES):
+            # with the library's own streams (the default) four hardware queues serve four passes as well as eight; what is left to
+            # warn about: more passes than streams created together, or torch's pool streams on fewer than 8 queues (they share)
+            warnings.warn(f"whisper_ipa_amd: {self.P} passes in flight on {self.hw_queues} hardware queues"
+                          + (" with torch's pool streams (WIPA_OWN_STREAMS=0): they share queues below 8 (measured: 86-88 ms per pass "
+                             "against 72)" if not own else f", more than the {OWN_STREAM_COUNT} library streams that are created together"),
                           RuntimeWarning, stacklevel=3)
 
     # ---- context: the model's streaming-launch setting belongs to the schedule while it runs

@@ -22,7 +22,8 @@ from . import _lib
 
 _streams = {}
 _pad_streams = []  # WIPA_PAD_STREAMS: idle streams created before the library's own (kept alive)
-_own_streams = {}  # device -> the library's own streams, created together (WIPA_OWN_STREAMS=1)
+_own_streams = {}  # device -> the library's own streams 0 .. OWN_STREAM_COUNT - 1, created together
+OWN_STREAM_COUNT = 8
 _stream_cus = {}  # library stream id -> CU limit (limit_stream_cus), read when the stream is first used
 _tls = threading.local()
 
@@ -82,26 +83,29 @@ def stream(sid: Optional[int] = None) -> torch.cuda.Stream:
     s = _streams.get(key)
     if s is None:
         n_cus = _stream_cus.get(sid)
-        if n_cus is None and os.environ.get("WIPA_OWN_STREAMS", "0") == "1":
-            # EXPERIMENT: the library's own HIP streams instead of torch's pool -- ALL of them created at the first
-            # request, before any of them carries work (WIPA_PAD_STREAMS idle ones first, then sids 0 .. WIPA_OWN_STREAM_COUNT - 1),
-            # each used once so that its hardware queue exists: which queue a pass's stream lands on follows the creation order
+        if n_cus is None and os.environ.get("WIPA_OWN_STREAMS", "1") == "1":
+            # The library's OWN HIP streams (wipa_stream_create), not torch's pool -- and the first OWN_STREAM_COUNT of them created
+            # TOGETHER at the first request, before any of them carries work, each used once so that its hardware queue exists.
+            # ROCm hands hardware queues to streams in creation order: created together, the streams of up to four passes in
+            # flight sit on distinct queues even with ROCm's default of four (72.0 / 71.3 ms per pass against 72.1 / 71.8 / 71.3
+            # with eight queues), whereas torch's pool streams on four queues share them (86-88 ms), and a stream created WHILE
+            # others carry work can land on a busy queue (the passes then run one after another: 85 ms on the decode loops).
+            # DESIGN.md 8.2, profiles/r05_queue_pad_sweep.txt.  WIPA_OWN_STREAMS=0 restores torch's pool (A/B);
+            # WIPA_PAD_STREAMS=n creates n idle streams first (experiments).
+            def make():
+                raw = C.c_void_p()
+                _lib.check(_lib.lib().wipa_stream_create(C.byref(raw)), "wipa_stream_create")
+                st = torch.cuda.ExternalStream(raw.value, device=key[0])  # lives as long as the process
+                with torch.cuda.stream(st):
+                    torch.zeros(1, device=torch.device("cuda", key[0]))
+                return st
             if not _own_streams.get(key[0]):
-                def make():
-                    raw = C.c_void_p()
-                    _lib.check(_lib.lib().wipa_stream_create(C.byref(raw)), "wipa_stream_create")
-                    st = torch.cuda.ExternalStream(raw.value, device=key[0])  # lives as long as the process
-                    with torch.cuda.stream(st):
-                        torch.zeros(1, device=torch.device("cuda", key[0]))
-                    return st
                 for _ in range(int(os.environ.get("WIPA_PAD_STREAMS", "0"))):
                     _pad_streams.append(make())
-                _own_streams[key[0]] = [make() for _ in range(int(os.environ.get("WIPA_OWN_STREAM_COUNT", "4")))]
+                _own_streams[key[0]] = [make() for _ in range(int(os.environ.get("WIPA_OWN_STREAM_COUNT", str(OWN_STREAM_COUNT))))]
                 torch.cuda.synchronize(key[0])
             own = _own_streams[key[0]]
-            if sid >= len(own):
-                raise _lib.WipaError(f"WIPA_OWN_STREAMS: library stream {sid} requested, {len(own)} created (WIPA_OWN_STREAM_COUNT)")
-            s = own[sid]
+            s = own[sid] if 0 <= sid < len(own) else make()  # ids beyond the eager set: on demand (no pass in flight uses one)
         elif n_cus is None:
             s = torch.cuda.Stream(device=key[0])
         else:
